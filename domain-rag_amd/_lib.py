@@ -1,0 +1,69 @@
+"""ctypes loader for libdomainrag_hip.so — the only way host code reaches the HIP kernels."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdomainrag_hip.so")
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+
+class GemmArgs(ctypes.Structure):
+    """mirror of ``drag_gemm_args`` (include/domainrag_hip.h)"""
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("C", c_void_p),
+        ("bias", c_void_p), ("gate", c_void_p), ("resid", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("a_rows_per_batch", c_int), ("a_batch_stride", c_int64),
+        ("ldc", c_int), ("c_rows_per_batch", c_int), ("c_batch_stride", c_int64),
+        ("ldg", c_int), ("act", c_int), ("act_n0", c_int), ("out_f32", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/domainrag_hip.h declares
+SIGNATURES = {
+    "drag_version": (c_int, []),
+    "drag_last_error": (ctypes.c_char_p, []),
+    "drag_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
+    "drag_qk_norm_rope_vt_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
+    "drag_attention_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float, c_void_p]),
+    "drag_layernorm_modulate_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_int64, c_int, c_int, c_float, c_void_p]),
+    "drag_act_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "drag_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "drag_flow_euler_step_bf16": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "drag_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "drag_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "drag_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "drag_cosine_topk_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "drag_cosine_topk_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "drag_l2_normalize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library, binding every declared symbol.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "domain-rag_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().drag_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

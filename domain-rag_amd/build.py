@@ -1,0 +1,89 @@
+"""Build libdomainrag_hip.so (gfx950 only) from csrc/*.hip with hipcc.
+
+In-tree build: objects go to ``domain-rag_amd/build/`` and the shared library to
+``domain-rag_amd/lib/libdomainrag_hip.so`` so that the built library travels with the source tree
+(it is git-ignored, not gpurun-ignored).  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdomainrag_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
+         "-ffp-contract=on"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libdomainrag_hip.so cannot be built")
+
+
+def _sources() -> list[str]:
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path: str, extra: list[str]) -> str:
+    h = hashlib.sha256()
+    for p in [path] + extra:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers.append(os.path.join(HERE, "..", "include", "domainrag_hip.h"))
+    jobs = []
+    objs = []
+    for src in _sources():
+        obj = os.path.join(BUILD, os.path.basename(src)[:-4] + ".o")
+        stamp = obj + ".sha"
+        dig = _digest(src, headers)
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        jobs.append((src, obj, stamp, dig))
+
+    def compile_one(job):
+        src, obj, stamp, dig = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(dig)
+        return src
+
+    if jobs:
+        if verbose:
+            print(f"[domain-rag_amd] compiling {len(jobs)} HIP source(s) for {ARCH} ...", file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+        if verbose:
+            print(f"[domain-rag_amd] built {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

@@ -1,0 +1,319 @@
+// attention.hip — Flux joint attention on gfx950: q/k RMSNorm + RoPE + V^T repack, then a
+// flash-style MFMA attention (head_dim 128, bf16, no mask).
+//
+// Replaces FluxAttnProcessor2_0 (diffusers 0.33.1, un-vendored): norm_q/norm_k(/norm_added_*),
+// apply_rotary_emb and F.scaled_dot_product_attention, reached on every denoise step from
+// batch_generate_flux_kshot.py:467-474 and outpainting_updown_sampling_redux.py:1246-1257.
+//
+// Attention structure: block = 4 waves x 32 queries; KV tile = 64 keys; K tile [64][128] and
+// V^T tile [128][64] arrive by LDS-DMA (buffer_load ... lds), double-buffered, one barrier per
+// tile, XOR-swizzled on the source address + on the ds_read_b128.  QK^T is computed swapped
+// (S^T = K Q^T, v_mfma_f32_32x32x16_bf16) so each lane owns ONE query column: the online
+// softmax is lane-local apart from one lane<->lane^32 exchange, and the packed P registers are
+// directly the B operand of O^T += V^T P^T.  The V^T image is stored with keys permuted inside
+// groups of 16 so that a plain 16-byte read yields exactly the keys a lane's P registers hold
+// (no transposes, no cross-lane traffic in the loop).
+#include "drag_common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------
+// q/k RMSNorm + RoPE in place, V -> V^T.   grid (ceil(S/64), H, B), block 256.
+// --------------------------------------------------------------------------------------------
+struct PrepArgs {
+  bf16_t* qkv;
+  bf16_t* vt;
+  const bf16_t *wq_txt, *wk_txt, *wq_img, *wk_img;
+  const float *cosT, *sinT;
+  int B, S, H, ld, s_txt, s_pad;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(PrepArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sv[64 * 136];  // V tile, row padded to 136 (272 B)
+  const int tid = threadIdx.x;
+  const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int HD = p.H * 128;
+  bf16_t* base = p.qkv + (long long)b * p.S * p.ld;
+
+  // ---- q and k: 16 lanes per row, 8 elements per lane ----
+  const int sub = tid & 15;        // which 8-element group of the 128
+  const int rloc = tid >> 4;       // 0..15
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    for (int it = 0; it < 4; ++it) {
+      const int s = s0 + it * 16 + rloc;
+      const bool ok = s < p.S;
+      const int sc = ok ? s : p.S - 1;
+      bf16_t* ptr = base + (long long)sc * p.ld + which * HD + h * 128 + sub * 8;
+      const u32x4_t raw = *(const u32x4_t*)ptr;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[2 * j] = bf2f((bf16_t)(raw[j] & 0xffff));
+        x[2 * j + 1] = bf2f((bf16_t)(raw[j] >> 16));
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+      ss += __shfl_xor(ss, 8, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 1, 64);
+      const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
+      const bf16_t* wsel = which == 0 ? (sc < p.s_txt ? p.wq_txt : p.wq_img) : (sc < p.s_txt ? p.wk_txt : p.wk_img);
+      const u32x4_t wr = *(const u32x4_t*)(wsel + sub * 8);
+      const f32x4_t c4 = *(const f32x4_t*)(p.cosT + (long long)sc * 64 + sub * 4);
+      const f32x4_t s4 = *(const f32x4_t*)(p.sinT + (long long)sc * 64 + sub * 4);
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // diffusers RMSNorm: (x * rsqrt(var+eps)).to(bf16) * weight(bf16) -> bf16
+        const float a0 = rbf(rbf(x[2 * j] * rs) * bf2f((bf16_t)(wr[j] & 0xffff)));
+        const float a1 = rbf(rbf(x[2 * j + 1] * rs) * bf2f((bf16_t)(wr[j] >> 16)));
+        // apply_rotary_emb (use_real, unbind_dim=-1): out = x*cos + rot(x)*sin in fp32
+        const float r0 = a0 * c4[j] - a1 * s4[j];
+        const float r1 = a1 * c4[j] + a0 * s4[j];
+        o[j] = pack2bf(r0, r1);
+      }
+      if (ok) *(u32x4_t*)ptr = o;
+    }
+  }
+
+  // ---- v: stage [64 keys][128 d] in LDS, write V^T[d][pos(key)] ----
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    const int s = s0 + r;
+    u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+    if (s < p.S) v = *(const u32x4_t*)(base + (long long)s * p.ld + 2 * HD + h * 128 + c * 8);
+    *(u32x4_t*)(sv + r * 136 + c * 8) = v;
+  }
+  __syncthreads();
+  bf16_t* vtb = p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad + s0;
+  for (int i = tid; i < 128 * 8; i += 256) {
+    const int d = i >> 3, g8 = i & 7;  // 8 positions [8*g8, 8*g8+8) of row d
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      // position q = 8*g8 + j  ->  group = q>>4, within = q&15 = 8h+jj -> key offset 8*(jj>>2)+4h+(jj&3)
+      const int q0 = 8 * g8 + j, q1 = q0 + 1;
+      const int k0 = (q0 & ~15) + 8 * (((q0 & 15) & 7) >> 2) + 4 * ((q0 & 15) >> 3) + (q0 & 3);
+      const int k1 = (q1 & ~15) + 8 * (((q1 & 15) & 7) >> 2) + 4 * ((q1 & 15) >> 3) + (q1 & 3);
+      w[j >> 1] = (uint32_t)sv[k0 * 136 + d] | ((uint32_t)sv[k1 * 136 + d] << 16);
+    }
+    *(u32x4_t*)(vtb + (long long)d * p.s_pad + 8 * g8) = (u32x4_t){w[0], w[1], w[2], w[3]};
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// flash attention, D = 128.   grid (ceil(S/128), H, B), block 256.
+// --------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const bf16_t *q, *k, *vt;
+  bf16_t* out;
+  int B, S, H, ld_qk, ld_o, s_pad;
+  long long qk_bs, o_bs;
+  float c;  // scale * log2(e)
+  unsigned k_bytes, vt_bytes;
+};
+
+constexpr int KT_BYTES = 64 * 256;   // K tile   [64 keys][128 d] bf16
+constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
+
+__global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
+  const int w = wave_id(), l = lane_id();
+  const int hh = l >> 5;            // half-wave
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + w * 32;
+
+  // ---- Q fragments stay in registers: B operand, lane -> query (l&31), k = 16ks + 8hh .. +8 ----
+  bf16x8_t qf[8];
+  {
+    const int qr = min(q0 + (l & 31), p.S - 1);
+    const bf16_t* qp = p.q + (long long)b * p.qk_bs + (long long)qr * p.ld_qk + h * 128 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
+  }
+
+  // ---- staging descriptors ----
+  const bf16_t* kbase = p.k + (long long)b * p.qk_bs + h * 128;
+  const bf16_t* vbase = p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
+  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.vt_bytes, 0x00020000);
+  // K chunk c (1 KiB) = key rows 4c..4c+3; lane: row 4c + (l>>4), physical slot l&15
+  // V chunk c (1 KiB) = d rows 8c..8c+7;   lane: row 8c + (l>>3), physical slot l&7
+  int krow[4];
+  unsigned kslot[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = w * 4 + i;
+    krow[i] = c * 4 + (l >> 4);
+    kslot[i] = (unsigned)(((l & 15) ^ (krow[i] & 15)) * 16);
+    const int vrow = c * 8 + (l >> 3);
+    const int vslot = (l & 7) ^ ((vrow >> 1) & 7);
+    voff[i] = (unsigned)(((long long)vrow * p.s_pad + vslot * 8) * 2);
+  }
+  auto stage = [&](int buf, int kv0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = w * 4 + i;
+      const int kr = min(kv0 + krow[i], p.S - 1);
+      const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
+      DRAG_LDS char* dK = (DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024;
+      DRAG_LDS char* dV = (DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)dK, 16, ko, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, voff[i], kv0 * 2, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets ----
+  // K: row (l&31)+32t, logical slot 2ks+hh, physical = logical ^ (row&15)
+  const int krd = (l & 31) * 256;
+  const int kx = l & 15;
+  // V^T: row (l&31)+32dt, logical slot 2s+hh, physical = logical ^ ((row>>1)&7)
+  const int vrd = (l & 31) * 128;
+  const int vx = ((l & 31) >> 1) & 7;
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkv = p.s_pad / 64;
+  stage(0, 0);
+  for (int it = 0; it < nkv; ++it) {
+    const int buf = it & 1;
+    const int kv0 = it * 64;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 < nkv) stage(buf ^ 1, kv0 + 64);
+    const char* sK = smem + buf * KT_BYTES;
+    const char* sV = smem + 2 * KT_BYTES + buf * VT_BYTES;
+
+    // ---- S^T = K Q^T ----
+    f32x16_t sacc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(sK + krd + t * (32 * 256) + (((2 * ks + hh) ^ kx) << 4));
+        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t], 0, 0, 0);
+      }
+    }
+    // lane holds S[query l&31][key kv0 + 32t + (r&3) + 8(r>>2) + 4hh]
+    if (kv0 + 64 > p.S) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= p.S) sacc[t][r] = -INFINITY;
+        }
+    }
+    // ---- online softmax (exp2 domain) ----
+    float mt = sacc[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = exp2f((m_run - m_new) * p.c);
+    const float mc = m_new * p.c;
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(sacc[t][r] * p.c - mc);
+        sacc[t][r] = e;
+        ps += e;
+      }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    // ---- P -> bf16 B-operand fragments: k-step s uses regs 8(s&1)..+8 of tile s>>1 ----
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4_t pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        pk[j] = pack2bf(sacc[s >> 1][8 * (s & 1) + 2 * j], sacc[s >> 1][8 * (s & 1) + 2 * j + 1]);
+      pf[s] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8_t vf = *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[dt], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: lane holds O[query l&31][d = 32dt + 8(r>>2) + 4hh + (r&3)] ----
+  const float lt = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / lt;
+  const int qrow = q0 + (l & 31);
+  if (qrow < p.S) {
+    bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t o;
+        o[0] = pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv);
+        o[1] = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+        *(u32x2_t*)(op + 32 * dt + 8 * g) = o;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt, const void* wk_txt,
+                                         const void* wq_img, const void* wk_img, const float* rope_cos,
+                                         const float* rope_sin, int32_t B, int32_t S, int32_t H, int32_t ld,
+                                         int32_t s_txt, float eps, void* stream) {
+  DRAG_CHECK(qkv && vt && wq_txt && wk_txt && wq_img && wk_img && rope_cos && rope_sin,
+             "drag_qk_norm_rope_vt_bf16: null pointer");
+  DRAG_CHECK(B > 0 && S > 0 && H > 0 && ld >= 3 * H * 128 && ld % 8 == 0, "drag_qk_norm_rope_vt_bf16: bad shape");
+  PrepArgs p;
+  p.qkv = (bf16_t*)qkv; p.vt = (bf16_t*)vt;
+  p.wq_txt = (const bf16_t*)wq_txt; p.wk_txt = (const bf16_t*)wk_txt;
+  p.wq_img = (const bf16_t*)wq_img; p.wk_img = (const bf16_t*)wk_img;
+  p.cosT = rope_cos; p.sinT = rope_sin;
+  p.B = B; p.S = S; p.H = H; p.ld = ld; p.s_txt = s_txt; p.s_pad = (S + 63) / 64 * 64; p.eps = eps;
+  hipLaunchKernelGGL(qk_norm_rope_vt_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, p);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S,
+                                   int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
+                                   int64_t o_batch_stride, float scale, void* stream) {
+  DRAG_CHECK(q && k && vt && out, "drag_attention_bf16: null pointer");
+  DRAG_CHECK(B > 0 && S > 0 && H > 0, "drag_attention_bf16: bad shape");
+  DRAG_CHECK(ld_qk % 8 == 0 && ld_o % 4 == 0, "drag_attention_bf16: ld_qk %% 8, ld_o %% 4 required");
+  AttnArgs p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.out = (bf16_t*)out;
+  p.B = B; p.S = S; p.H = H; p.ld_qk = ld_qk; p.ld_o = ld_o; p.s_pad = (S + 63) / 64 * 64;
+  p.qk_bs = qk_batch_stride; p.o_bs = o_batch_stride;
+  p.c = scale * 1.4426950408889634f;
+  const long long kspan = ((long long)(S - 1) * ld_qk + 128) * 2;
+  const long long vspan = (long long)128 * p.s_pad * 2;
+  DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");
+  p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
+  hipLaunchKernelGGL(attention_d128_kernel, dim3((S + 127) / 128, H, B), dim3(256), 0, (hipStream_t)stream, p);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,100 @@
+// drag_common.h — shared device helpers for libdomainrag_hip.so (gfx950 / CDNA4 only).
+//
+// Everything in csrc/ is written directly for MI355X: 64-wide wavefronts, MFMA
+// matrix cores, LDS-DMA (buffer_load ... lds).  There is no CUDA path and no
+// portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/domainrag_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define DRAG_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN kept quiet: same rule as torch's float->bfloat16 cast
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+// round a float through bf16 (mirrors an intermediate bf16 tensor in the reference's bf16 pipeline)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// --- activations (fp32 math; match torch's definitions) ---
+__device__ __forceinline__ float act_gelu_tanh(float x) {
+  // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case DRAG_ACT_GELU_TANH: return act_gelu_tanh(x);
+    case DRAG_ACT_SILU: return act_silu(x);
+    case DRAG_ACT_QUICK_GELU: return act_quick_gelu(x);
+    case DRAG_ACT_GELU_ERF: return act_gelu_erf(x);
+    default: return x;
+  }
+}
+
+// XCD-aware block remap: dispatcher places block b on XCD b%8 (speed only, never
+// correctness).  Gives every XCD a contiguous run of logical tile ids so that tiles
+// sharing an operand panel hit the same private L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// wave-wide reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// error plumbing shared by the C ABI
+void drag_set_error(const char* msg);
+#define DRAG_CHECK(cond, msg)          \
+  do {                                 \
+    if (!(cond)) {                     \
+      drag_set_error(msg);             \
+      return -1;                       \
+    }                                  \
+  } while (0)
+#define DRAG_LAUNCH_CHECK()                                  \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) {                                 \
+      drag_set_error(hipGetErrorString(e__));                \
+      return -2;                                             \
+    }                                                        \
+  } while (0)

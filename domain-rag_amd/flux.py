@@ -1,0 +1,260 @@
+"""FluxTransformerHIP — host driver of the Flux DiT forward on MI355X.
+
+Mirrors ``FluxTransformer2DModel.forward`` (diffusers 0.33.1; the call the reference reaches on
+every denoise step from batch_generate_flux_kshot.py:467-474 and
+outpainting_updown_sampling_redux.py:1246-1257).  All arithmetic is in libdomainrag_hip.so; torch
+only owns the device buffers.  MI355X-first layout decisions:
+
+* text and image streams live in ONE joint activation buffer ``x[B, S_txt+S_img, D]`` for the
+  whole forward (the GEMM / LayerNorm kernels address "batched rows"), so there are no concat /
+  split copies between double-stream and single-stream blocks;
+* q/k/v projections are fused into one [3D, D] weight; single-stream blocks write attention and
+  MLP outputs side by side into one [M, 5D] buffer that feeds proj_out directly;
+* every block's AdaLN modulation is computed by ONE GEMM per forward (all modulation weights are
+  stacked), instead of 76 tiny launches;
+* workspaces are allocated once per (B, S) and reused: 288 GB of HBM keeps weights (23.7 GB bf16)
+  plus B=8 activations resident.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .flux_params import FluxConfig
+
+
+def rope_tables(ids: torch.Tensor, axes_dims=(16, 56, 56), theta: float = 10000.0):
+    """FluxPosEmbed on the host in float64 (as diffusers does off-MPS) -> fp32 [S, 64] cos / sin."""
+    cos, sin = [], []
+    pos = ids.detach().to("cpu", torch.float64)
+    for i, d in enumerate(axes_dims):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        ang = torch.outer(pos[:, i], freqs)
+        cos.append(ang.cos().float())
+        sin.append(ang.sin().float())
+    return torch.cat(cos, dim=1).contiguous(), torch.cat(sin, dim=1).contiguous()
+
+
+def latent_image_ids(h: int, w: int) -> torch.Tensor:
+    ids = torch.zeros(h, w, 3)
+    ids[..., 1] = torch.arange(h)[:, None]
+    ids[..., 2] = torch.arange(w)[None, :]
+    return ids.reshape(h * w, 3)
+
+
+class FluxTransformerHIP:
+    def __init__(self, cfg: FluxConfig, params: dict, device="cuda"):
+        if cfg.attention_head_dim != 128:
+            raise ValueError("the HIP attention kernel is specialised for head_dim 128 (all FLUX.1 models)")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        D = cfg.dim
+        dev = self.device
+
+        def g(name):
+            return params[name].to(dev, torch.bfloat16).contiguous()
+
+        def cat(names):
+            return torch.cat([params[n].to(dev, torch.bfloat16) for n in names], dim=0).contiguous()
+
+        self.w = {}
+        for n in ("x_embedder", "context_embedder", "proj_out",
+                  "time_text_embed.timestep_embedder.linear_1", "time_text_embed.timestep_embedder.linear_2",
+                  "time_text_embed.text_embedder.linear_1", "time_text_embed.text_embedder.linear_2"):
+            self.w[n + ".weight"], self.w[n + ".bias"] = g(n + ".weight"), g(n + ".bias")
+        if cfg.guidance_embeds:
+            for n in ("time_text_embed.guidance_embedder.linear_1", "time_text_embed.guidance_embedder.linear_2"):
+                self.w[n + ".weight"], self.w[n + ".bias"] = g(n + ".weight"), g(n + ".bias")
+
+        # ---- stacked modulation weights: [double i: norm1 (6D) | norm1_context (6D)]*L, [single: 3D]*Ls, norm_out 2D
+        mod_w, mod_b = [], []
+        self.mod_off = {}
+        off = 0
+        for i in range(cfg.num_layers):
+            for nm in ("norm1", "norm1_context"):
+                key = f"transformer_blocks.{i}.{nm}.linear"
+                mod_w.append(key + ".weight"); mod_b.append(key + ".bias")
+                self.mod_off[(i, nm)] = off
+                off += 6 * D
+        for i in range(cfg.num_single_layers):
+            key = f"single_transformer_blocks.{i}.norm.linear"
+            mod_w.append(key + ".weight"); mod_b.append(key + ".bias")
+            self.mod_off[("s", i)] = off
+            off += 3 * D
+        mod_w.append("norm_out.linear.weight"); mod_b.append("norm_out.linear.bias")
+        self.mod_off["out"] = off
+        off += 2 * D
+        self.mod_total = off
+        self.mod_w, self.mod_b = cat(mod_w), cat(mod_b)
+
+        self.double = []
+        for i in range(cfg.num_layers):
+            p = f"transformer_blocks.{i}."
+            self.double.append(dict(
+                wqkv=cat([p + "attn.to_q.weight", p + "attn.to_k.weight", p + "attn.to_v.weight"]),
+                bqkv=cat([p + "attn.to_q.bias", p + "attn.to_k.bias", p + "attn.to_v.bias"]),
+                cwqkv=cat([p + "attn.add_q_proj.weight", p + "attn.add_k_proj.weight", p + "attn.add_v_proj.weight"]),
+                cbqkv=cat([p + "attn.add_q_proj.bias", p + "attn.add_k_proj.bias", p + "attn.add_v_proj.bias"]),
+                nq=g(p + "attn.norm_q.weight"), nk=g(p + "attn.norm_k.weight"),
+                cnq=g(p + "attn.norm_added_q.weight"), cnk=g(p + "attn.norm_added_k.weight"),
+                wo=g(p + "attn.to_out.0.weight"), bo=g(p + "attn.to_out.0.bias"),
+                cwo=g(p + "attn.to_add_out.weight"), cbo=g(p + "attn.to_add_out.bias"),
+                w1=g(p + "ff.net.0.proj.weight"), b1=g(p + "ff.net.0.proj.bias"),
+                w2=g(p + "ff.net.2.weight"), b2=g(p + "ff.net.2.bias"),
+                cw1=g(p + "ff_context.net.0.proj.weight"), cb1=g(p + "ff_context.net.0.proj.bias"),
+                cw2=g(p + "ff_context.net.2.weight"), cb2=g(p + "ff_context.net.2.bias")))
+        self.single = []
+        for i in range(cfg.num_single_layers):
+            p = f"single_transformer_blocks.{i}."
+            self.single.append(dict(
+                wqkv=cat([p + "attn.to_q.weight", p + "attn.to_k.weight", p + "attn.to_v.weight"]),
+                bqkv=cat([p + "attn.to_q.bias", p + "attn.to_k.bias", p + "attn.to_v.bias"]),
+                nq=g(p + "attn.norm_q.weight"), nk=g(p + "attn.norm_k.weight"),
+                wm=g(p + "proj_mlp.weight"), bm=g(p + "proj_mlp.bias"),
+                wo=g(p + "proj_out.weight"), bo=g(p + "proj_out.bias")))
+        self._ws_key = None
+        self._rope_key = None
+
+    # ------------------------------------------------------------------ workspaces
+    def _workspace(self, B, St, Si):
+        key = (B, St, Si)
+        if self._ws_key == key:
+            return self._ws
+        cfg, dev = self.cfg, self.device
+        D, S, H = cfg.dim, St + Si, cfg.num_attention_heads
+        F = cfg.mlp_ratio * D
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        s_pad = (S + 63) // 64 * 64
+        ws = dict(
+            x=torch.empty((B, S, D), **bf),
+            nrm=torch.empty((B * S, D), **bf),
+            qkv=torch.empty((B, S, 3 * D), **bf),
+            vt=torch.empty((B, H, 128, s_pad), **bf),
+            attn=torch.empty((B, S, D), **bf),
+            cat=torch.empty((B * S, D + F), **bf),      # single: [attn | mlp]; double: MLP hidden (prefix)
+            mod=torch.empty((B, self.mod_total), **bf),
+            out=torch.empty((B * Si, cfg.out_channels), **bf),
+        )
+        self._ws_key, self._ws = key, ws
+        return ws
+
+    def _rope(self, txt_ids, img_ids):
+        key = (tuple(txt_ids.shape), tuple(img_ids.shape), float(img_ids.sum()), float(txt_ids.sum()))
+        if self._rope_key != key:
+            cos, sin = rope_tables(torch.cat([txt_ids.cpu().float(), img_ids.cpu().float()], dim=0), self.cfg.axes_dims_rope)
+            self._rope_cs = (cos.to(self.device), sin.to(self.device))
+            self._rope_key = key
+        return self._rope_cs
+
+    # ------------------------------------------------------------------ pieces
+    def _temb(self, timestep, guidance, pooled):
+        """CombinedTimestep(Guidance)TextProjEmbeddings.  timestep/guidance: host fp32 tensors [B]
+        (sigma, guidance scale); diffusers rounds them to bf16 and multiplies by 1000 in bf16."""
+        w = self.w
+        t1000 = (timestep.to(torch.bfloat16) * 1000).float().to(self.device)
+        tp = ops.timestep_embedding(t1000, 256)
+        pre = "time_text_embed."
+        h = ops.gemm(tp, w[pre + "timestep_embedder.linear_1.weight"], bias=w[pre + "timestep_embedder.linear_1.bias"], act=ops.ACT_SILU)
+        emb = ops.gemm(h, w[pre + "timestep_embedder.linear_2.weight"], bias=w[pre + "timestep_embedder.linear_2.bias"])
+        if self.cfg.guidance_embeds:
+            g1000 = (guidance.to(torch.bfloat16) * 1000).float().to(self.device)
+            gp = ops.timestep_embedding(g1000, 256)
+            h = ops.gemm(gp, w[pre + "guidance_embedder.linear_1.weight"], bias=w[pre + "guidance_embedder.linear_1.bias"], act=ops.ACT_SILU)
+            emb = ops.gemm(h, w[pre + "guidance_embedder.linear_2.weight"], bias=w[pre + "guidance_embedder.linear_2.bias"], resid=emb)
+        h = ops.gemm(pooled, w[pre + "text_embedder.linear_1.weight"], bias=w[pre + "text_embedder.linear_1.bias"], act=ops.ACT_SILU)
+        return ops.gemm(h, w[pre + "text_embedder.linear_2.weight"], bias=w[pre + "text_embedder.linear_2.bias"], resid=emb)
+
+    def forward(self, hidden, enc, pooled, timestep, img_ids, txt_ids, guidance=None, taps: dict | None = None):
+        """hidden bf16 [B, S_img, in]; enc bf16 [B, S_txt, J]; pooled bf16 [B, P]; timestep / guidance
+        fp32 [B] host or device; returns bf16 [B, S_img, out] (a view of an internal workspace)."""
+        cfg = self.cfg
+        D, H = cfg.dim, cfg.num_attention_heads
+        F = cfg.mlp_ratio * D
+        B, Si, _ = hidden.shape
+        St = enc.shape[1]
+        S = St + Si
+        ws = self._workspace(B, St, Si)
+        x, nrm, qkv, vt, attn, catb, mod = ws["x"], ws["nrm"], ws["qkv"], ws["vt"], ws["attn"], ws["cat"], ws["mod"]
+        cos, sin = self._rope(txt_ids, img_ids)
+        hidden = hidden.contiguous(); enc = enc.contiguous(); pooled = pooled.contiguous()
+        Mi, Mt, M = B * Si, B * St, B * S
+        x_img = x.view(-1)[St * D:]          # joint buffer, image rows of batch 0 onwards
+        scale = 1.0 / math.sqrt(cfg.attention_head_dim)
+
+        # embedders write straight into the joint buffer
+        ops.gemm(hidden.view(Mi, -1), self.w["x_embedder.weight"], out=x_img, bias=self.w["x_embedder.bias"], M=Mi,
+                 c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D)
+        ops.gemm(enc.view(Mt, -1), self.w["context_embedder.weight"], out=x, bias=self.w["context_embedder.bias"], M=Mt,
+                 c_rows_per_batch=St, c_batch_stride=S * D, ldc=D)
+        temb = self._temb(torch.as_tensor(timestep, dtype=torch.float32).cpu().reshape(-1),
+                          None if guidance is None else torch.as_tensor(guidance, dtype=torch.float32).cpu().reshape(-1),
+                          pooled)
+        st = ops.act(temb, ops.ACT_SILU)
+        ops.gemm(st, self.mod_w, out=mod, bias=self.mod_b)          # every block's modulation in one GEMM
+        modv = mod.view(-1)
+        LM = self.mod_total
+        if taps is not None:
+            taps["temb"] = temb.clone()
+            taps["x_embed"] = x[:, St:].clone(); taps["ctx_embed"] = x[:, :St].clone()
+
+        nrm_img = nrm.view(-1)[: Mi * D]
+        nrm_txt = nrm.view(-1)[Mi * D: (Mi + Mt) * D]
+        qkv_img = qkv.view(-1)[St * 3 * D:]
+        attn_img = attn.view(-1)[St * D:]
+        hid = catb.view(-1)                   # MLP hidden scratch for double blocks
+
+        for i, blk in enumerate(self.double):
+            mo, cmo = self.mod_off[(i, "norm1")], self.mod_off[(i, "norm1_context")]
+            # chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+            ops.layernorm(x_img, nrm_img, Mi, D, scale=modv[mo + D:], shift=modv[mo:], ldx=D, rows_per_batch=Si,
+                          x_batch_stride=S * D, ld_mod=LM)
+            ops.layernorm(x, nrm_txt, Mt, D, scale=modv[cmo + D:], shift=modv[cmo:], ldx=D, rows_per_batch=St,
+                          x_batch_stride=S * D, ld_mod=LM)
+            ops.gemm(nrm_img, blk["wqkv"], out=qkv_img, bias=blk["bqkv"], M=Mi, lda=D, c_rows_per_batch=Si,
+                     c_batch_stride=S * 3 * D, ldc=3 * D)
+            ops.gemm(nrm_txt, blk["cwqkv"], out=qkv, bias=blk["cbqkv"], M=Mt, lda=D, c_rows_per_batch=St,
+                     c_batch_stride=S * 3 * D, ldc=3 * D)
+            ops.qk_norm_rope_vt(qkv, vt, blk["cnq"], blk["cnk"], blk["nq"], blk["nk"], cos, sin, B, S, H, 3 * D, St)
+            ops.attention(qkv, qkv.view(-1)[D:], vt, attn, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
+            ops.gemm(attn_img, blk["wo"], out=x_img, bias=blk["bo"], M=Mi, a_rows_per_batch=Si, a_batch_stride=S * D,
+                     lda=D, c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D, gate=modv[mo + 2 * D:], resid=x_img, ldg=LM)
+            ops.gemm(attn, blk["cwo"], out=x, bias=blk["cbo"], M=Mt, a_rows_per_batch=St, a_batch_stride=S * D,
+                     lda=D, c_rows_per_batch=St, c_batch_stride=S * D, ldc=D, gate=modv[cmo + 2 * D:], resid=x, ldg=LM)
+            # MLPs
+            ops.layernorm(x_img, nrm_img, Mi, D, scale=modv[mo + 4 * D:], shift=modv[mo + 3 * D:], ldx=D,
+                          rows_per_batch=Si, x_batch_stride=S * D, ld_mod=LM)
+            ops.gemm(nrm_img, blk["w1"], out=hid, bias=blk["b1"], act=ops.ACT_GELU_TANH, M=Mi, lda=D, ldc=F)
+            ops.gemm(hid, blk["w2"], out=x_img, bias=blk["b2"], M=Mi, lda=F, c_rows_per_batch=Si,
+                     c_batch_stride=S * D, ldc=D, gate=modv[mo + 5 * D:], resid=x_img, ldg=LM)
+            ops.layernorm(x, nrm_txt, Mt, D, scale=modv[cmo + 4 * D:], shift=modv[cmo + 3 * D:], ldx=D,
+                          rows_per_batch=St, x_batch_stride=S * D, ld_mod=LM)
+            ops.gemm(nrm_txt, blk["cw1"], out=hid, bias=blk["cb1"], act=ops.ACT_GELU_TANH, M=Mt, lda=D, ldc=F)
+            ops.gemm(hid, blk["cw2"], out=x, bias=blk["cb2"], M=Mt, lda=F, c_rows_per_batch=St,
+                     c_batch_stride=S * D, ldc=D, gate=modv[cmo + 5 * D:], resid=x, ldg=LM)
+            if taps is not None:
+                taps[f"double.{i}"] = x.clone()
+
+        cat_mlp = catb.view(-1)[D:]
+        for i, blk in enumerate(self.single):
+            mo = self.mod_off[("s", i)]      # shift, scale, gate
+            ops.layernorm(x, nrm, M, D, scale=modv[mo + D:], shift=modv[mo:], ldx=D, ld_mod=LM, rows_per_batch=S,
+                          x_batch_stride=S * D)
+            ops.gemm(nrm, blk["wqkv"], out=qkv, bias=blk["bqkv"], M=M, lda=D, ldc=3 * D)
+            ops.gemm(nrm, blk["wm"], out=cat_mlp, bias=blk["bm"], act=ops.ACT_GELU_TANH, M=M, lda=D, ldc=D + F)
+            ops.qk_norm_rope_vt(qkv, vt, blk["nq"], blk["nk"], blk["nq"], blk["nk"], cos, sin, B, S, H, 3 * D, 0)
+            ops.attention(qkv, qkv.view(-1)[D:], vt, catb, B, S, H, 3 * D, S * 3 * D, D + F, S * (D + F), scale)
+            ops.gemm(catb, blk["wo"], out=x, bias=blk["bo"], M=M, lda=D + F, c_rows_per_batch=S, c_batch_stride=S * D,
+                     ldc=D, gate=modv[mo + 2 * D:], resid=x, ldg=LM)
+            if taps is not None:
+                taps[f"single.{i}"] = x.clone()
+
+        mo = self.mod_off["out"]             # AdaLayerNormContinuous: scale, shift
+        ops.layernorm(x_img, nrm_img, Mi, D, scale=modv[mo:], shift=modv[mo + D:], ldx=D, rows_per_batch=Si,
+                      x_batch_stride=S * D, ld_mod=LM)
+        ops.gemm(nrm_img, self.w["proj_out.weight"], out=ws["out"], bias=self.w["proj_out.bias"], M=Mi, lda=D,
+                 ldc=cfg.out_channels)
+        return ws["out"].view(B, Si, cfg.out_channels)
+
+    __call__ = forward

@@ -1,0 +1,174 @@
+"""Thin Python wrappers over the C ABI (include/domainrag_hip.h).
+
+Tensors are torch CUDA(ROCm) tensors used only as device-memory handles: every wrapper hands raw
+pointers + sizes to libdomainrag_hip.so on torch's current stream.  No arithmetic is done by torch
+here, and nothing falls back to torch when the library is missing (``_lib.load()`` raises).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2, 3, 4
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (domain-rag_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, bias=None, act: int = ACT_NONE,
+         act_n0: int = 0, gate=None, resid=None, out_f32: bool = False, M: int | None = None,
+         a_rows_per_batch: int = 0, a_batch_stride: int = 0, lda: int | None = None,
+         c_rows_per_batch: int = 0, c_batch_stride: int = 0, ldc: int | None = None, ldg: int = 0) -> torch.Tensor:
+    """out = epi(a @ w.T).  ``a`` / ``out`` may be views into larger buffers: pass the logical row
+    count ``M`` and the batched-row addressing (rows_per_batch, batch_stride, ld) explicitly; by
+    default ``a`` is a dense [M, K] matrix and ``out`` a dense [M, N] one."""
+    lib = _lib.load()
+    _need(a, torch.bfloat16, "gemm.a")
+    _need(w, torch.bfloat16, "gemm.w")
+    N, K = w.shape
+    if not w.is_contiguous():
+        raise ValueError("gemm.w must be contiguous [N, K]")
+    if M is None:
+        M = a.numel() // K
+        if lda is None:
+            if a.dim() < 2 or a.stride(-1) != 1:
+                raise ValueError("gemm.a must have unit inner stride")
+            lda = a.stride(-2) if a.dim() >= 2 else K
+    if lda is None:
+        lda = K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    if ldc is None:
+        ldc = N
+    args = GemmArgs()
+    args.A, args.W, args.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.gate = gate.data_ptr() if gate is not None else None
+    args.resid = resid.data_ptr() if resid is not None else None
+    args.M, args.N, args.K = M, N, K
+    args.lda, args.a_rows_per_batch, args.a_batch_stride = lda, a_rows_per_batch, a_batch_stride
+    args.ldc, args.c_rows_per_batch, args.c_batch_stride = ldc, c_rows_per_batch, c_batch_stride
+    args.ldg, args.act, args.act_n0, args.out_f32 = ldg, act, act_n0, int(out_f32)
+    check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
+    return out
+
+
+def qk_norm_rope_vt(qkv: torch.Tensor, vt: torch.Tensor, wq_txt, wk_txt, wq_img, wk_img, rope_cos, rope_sin,
+                    B: int, S: int, H: int, ld: int, s_txt: int, eps: float = 1e-6) -> None:
+    lib = _lib.load()
+    _need(qkv, torch.bfloat16, "qkv")
+    _need(vt, torch.bfloat16, "vt")
+    _need(rope_cos, torch.float32, "rope_cos")
+    check(lib.drag_qk_norm_rope_vt_bf16(_p(qkv), _p(vt), _p(wq_txt), _p(wk_txt), _p(wq_img), _p(wk_img),
+                                        _p(rope_cos), _p(rope_sin), B, S, H, ld, s_txt, eps, _stream()),
+          "drag_qk_norm_rope_vt_bf16")
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int,
+              ld_qk: int, qk_batch_stride: int, ld_o: int, o_batch_stride: int, scale: float) -> None:
+    lib = _lib.load()
+    _need(q, torch.bfloat16, "q")
+    _need(out, torch.bfloat16, "out")
+    check(lib.drag_attention_bf16(_p(q), _p(k), _p(vt), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o,
+                                  o_batch_stride, scale, _stream()), "drag_attention_bf16")
+
+
+def layernorm(x: torch.Tensor, y: torch.Tensor, M: int, D: int, *, scale=None, shift=None, gamma=None, beta=None,
+              ldx: int | None = None, rows_per_batch: int = 0, x_batch_stride: int = 0, ldy: int | None = None,
+              ld_mod: int = 0, eps: float = 1e-6) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, torch.bfloat16, "x")
+    _need(y, torch.bfloat16, "y")
+    check(lib.drag_layernorm_modulate_bf16(_p(x), _p(y), _p(scale), _p(shift), _p(gamma), _p(beta), M, D,
+                                           ldx if ldx is not None else D, rows_per_batch, x_batch_stride,
+                                           ldy if ldy is not None else D, ld_mod, eps, _stream()),
+          "drag_layernorm_modulate_bf16")
+    return y
+
+
+def act(x: torch.Tensor, kind: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, torch.bfloat16, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.drag_act_bf16(_p(x), _p(out), x.numel(), kind, _stream()), "drag_act_bf16")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    lib = _lib.load()
+    _need(t, torch.float32, "t")
+    out = torch.empty((t.numel(), dim), dtype=torch.bfloat16, device=t.device)
+    check(lib.drag_timestep_embedding_bf16(_p(t), _p(out), t.numel(), dim, _stream()), "drag_timestep_embedding_bf16")
+    return out
+
+
+def flow_euler_step(x: torch.Tensor, v: torch.Tensor, dt: float) -> None:
+    lib = _lib.load()
+    _need(x, torch.bfloat16, "x")
+    _need(v, torch.bfloat16, "v")
+    check(lib.drag_flow_euler_step_bf16(_p(x), _p(v), dt, x.numel(), _stream()), "drag_flow_euler_step_bf16")
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    lib = _lib.load()
+    _need(a, torch.bfloat16, "a")
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.drag_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "drag_add_bf16")
+    return out
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.drag_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "drag_cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, torch.bfloat16, "x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib.drag_cast_bf16_to_f32(_p(x), _p(out), x.numel(), _stream()), "drag_cast_bf16_to_f32")
+    return out
+
+
+def cosine_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int):
+    """(D, I) = exact inner-product top-k; D f32 [Q, k] descending, I int64 [Q, k]."""
+    lib = _lib.load()
+    _need(corpus, torch.float32, "corpus")
+    _need(queries, torch.float32, "queries")
+    N, d = corpus.shape
+    Q = queries.shape[0]
+    ws_bytes = lib.drag_cosine_topk_workspace_bytes(N, Q)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=corpus.device)
+    D = torch.empty((Q, k), dtype=torch.float32, device=corpus.device)
+    I = torch.empty((Q, k), dtype=torch.int64, device=corpus.device)
+    check(lib.drag_cosine_topk_f32(_p(corpus), _p(queries), N, d, Q, k, _p(D), _p(I), _p(ws), _stream()),
+          "drag_cosine_topk_f32")
+    return D, I
+
+
+def l2_normalize_(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    check(lib.drag_l2_normalize_f32(_p(x), x.shape[0], x.shape[1], _stream()), "drag_l2_normalize_f32")
+    return x

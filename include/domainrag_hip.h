@@ -1,0 +1,133 @@
+/* domainrag_hip.h — C ABI of libdomainrag_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for Domain-RAG's retrieve-then-generate hot path.  The
+ * reference (LiYu0524/Domain-RAG) has no FFI of its own: all arithmetic happens inside
+ * third-party wheels behind the Python call sites cited per entry point below
+ * (paths are relative to the reference checkout).  Each function here replaces the vendor
+ * kernels those call sites reach.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is owned by the caller (device memory
+ *     unless stated), kernels never allocate; workspace sizes come from *_workspace_bytes().
+ *   - asynchronous on the caller's HIP stream (`stream` is a hipStream_t passed as void*);
+ *     no hidden synchronisation.
+ *   - return 0 on success, negative on error; drag_last_error() returns the message
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - bf16 tensors are raw uint16 bit patterns; "f32" is IEEE binary32.
+ */
+#ifndef DOMAINRAG_HIP_H
+#define DOMAINRAG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int drag_version(void);
+const char* drag_last_error(void);
+
+/* activation codes used by epilogues */
+#define DRAG_ACT_NONE 0
+#define DRAG_ACT_GELU_TANH 1
+#define DRAG_ACT_SILU 2
+#define DRAG_ACT_QUICK_GELU 3
+#define DRAG_ACT_GELU_ERF 4
+
+/* ---------------------------------------------------------------------------------------
+ * drag_gemm_bf16 — C = epi(A[M,K] · W[N,K]^T), bf16 in, fp32 accumulate on MFMA.
+ * Replaces torch.nn.Linear inside FluxTransformer2DModel / SiglipVisionModel / ReduxImageEncoder /
+ * clip VisionTransformer, reached from batch_generate_flux_kshot.py:459-474,
+ * outpainting_updown_sampling_redux.py:1237-1257 and
+ * retrieval/clip100_resnet_style_all_shots.py:171.
+ *   logical row r of A lives at A + (r / a_rows_per_batch) * a_batch_stride + (r % a_rows_per_batch) * lda
+ *   (elements); same for C / resid with the c_* fields; *_rows_per_batch <= 0 means "one batch".
+ *   epilogue:  v = acc + bias[n];  v = act(v) for n >= act_n0;
+ *              gate != NULL:  C = resid + gate[r / c_rows_per_batch, n] * v   (bf16-rounded like torch)
+ *              else resid != NULL: C = resid + v
+ *   Requires K % 64 == 0, N % 4 == 0, lda % 8 == 0, ldc % 4 == 0, operand spans < 2 GiB.
+ */
+typedef struct drag_gemm_args {
+  const void* A;
+  const void* W;
+  void* C;
+  const void* bias;
+  const void* gate;
+  const void* resid;
+  int32_t M, N, K;
+  int32_t lda, a_rows_per_batch;
+  int64_t a_batch_stride;
+  int32_t ldc, c_rows_per_batch;
+  int64_t c_batch_stride;
+  int32_t ldg;
+  int32_t act, act_n0;
+  int32_t out_f32;
+} drag_gemm_args;
+int drag_gemm_bf16(const drag_gemm_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * drag_qk_norm_rope_vt_bf16 — per-head RMSNorm(128) on q,k + interleaved-pair RoPE, in place,
+ * and V -> V^T repack for the attention kernel.  Replaces FluxAttnProcessor2_0's norm_q/norm_k/
+ * norm_added_q/norm_added_k + apply_rotary_emb (diffusers 0.33.1, un-vendored; call sites as above).
+ *   qkv: [B, S, ld] rows, q at column 0, k at column H*128, v at column 2*H*128.
+ *   rows s < s_txt use (wq_txt, wk_txt), rows >= s_txt use (wq_img, wk_img) (bf16 [128] each).
+ *   rope_cos / rope_sin: f32 [S, 64].
+ *   vt: [B, H, 128, s_pad] bf16, s_pad = ceil(S/64)*64, keys permuted inside each group of 16
+ *       (position 8h+j  <->  key 8*(j>>2) + 4h + (j&3)) to match the MFMA accumulator layout; the
+ *       pad keys are written as zeros.
+ */
+int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt, const void* wk_txt,
+                              const void* wq_img, const void* wk_img, const float* rope_cos,
+                              const float* rope_sin, int32_t B, int32_t S, int32_t H, int32_t ld,
+                              int32_t s_txt, float eps, void* stream);
+
+/* drag_attention_bf16 — softmax(q k^T / sqrt(128)) v, flash-style on MFMA, head_dim 128, no mask.
+ * Replaces F.scaled_dot_product_attention in FluxAttnProcessor2_0.
+ *   q, k: [B, S, *] rows with row stride ld_qk (elements), head h at column h*128 from q / k.
+ *   vt as written by drag_qk_norm_rope_vt_bf16.  out: [B, S, *] row stride ld_o, head h at column h*128.
+ */
+int drag_attention_bf16(const void* q, const void* k, const void* vt, void* out, int32_t B,
+                        int32_t S, int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
+                        int64_t o_batch_stride, float scale, void* stream);
+
+/* drag_layernorm_modulate_bf16 — y = LN(x) * (1 + scale[b]) + shift[b]   (no affine LN, eps given)
+ * or, with gamma/beta != NULL, y = LN(x) * gamma + beta (affine LayerNorm, scale/shift NULL).
+ * Replaces AdaLayerNormZero / AdaLayerNormZeroSingle / AdaLayerNormContinuous and nn.LayerNorm.
+ *   x rows: batched-row addressing (rows_per_batch, x_batch_stride, ldx); y dense rows of ldy.
+ *   scale, shift: bf16 [B, ld_mod] row b.
+ */
+int drag_layernorm_modulate_bf16(const void* x, void* y, const void* scale, const void* shift,
+                                 const void* gamma, const void* beta, int32_t M, int32_t D,
+                                 int32_t ldx, int32_t rows_per_batch, int64_t x_batch_stride,
+                                 int32_t ldy, int32_t ld_mod, float eps, void* stream);
+
+/* elementwise helpers (bf16) */
+int drag_act_bf16(const void* x, void* y, int64_t n, int32_t act, void* stream);
+/* sinusoidal embedding as diffusers get_timestep_embedding(t, dim, flip_sin_to_cos=True,
+ * downscale_freq_shift=0): out[b] = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) * i / (dim/2)); bf16 out */
+int drag_timestep_embedding_bf16(const float* t, void* out, int32_t B, int32_t dim, void* stream);
+/* FlowMatchEulerDiscreteScheduler.step: x = bf16(float(x) + dt * float(v)) */
+int drag_flow_euler_step_bf16(void* x, const void* v, float dt, int64_t n, void* stream);
+/* y = a + b (bf16) */
+int drag_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* f32 <-> bf16 casts */
+int drag_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int drag_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * drag_cosine_topk_f32 — exact inner-product top-k (faiss.IndexFlatIP.add/search,
+ * retrieval/clip100_resnet_style_all_shots.py:425-434).
+ *   corpus f32 [N, d] (d % 16 == 0, d <= 2048), queries f32 [Q, d]; out_d f32 [Q, k] descending,
+ *   out_i int64 [Q, k].  Score = fp32 fma chain in the fixed order documented in oracle/topk.c;
+ *   ties -> lower index first; k <= min(N, 2048); if k > N the tail is (-inf, -1) like faiss.
+ *   workspace: drag_cosine_topk_workspace_bytes(N, Q) bytes of device memory.
+ */
+int64_t drag_cosine_topk_workspace_bytes(int64_t N, int32_t Q);
+int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, int32_t d,
+                         int32_t Q, int32_t k, float* out_d, int64_t* out_i, void* workspace,
+                         void* stream);
+/* L2-normalise rows in place (image_embedding / image_embedding.norm(dim=-1), retrieval/...:172) */
+int drag_l2_normalize_f32(float* x, int64_t rows, int32_t d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

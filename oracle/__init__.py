@@ -1,0 +1,13 @@
+"""oracle/ — CPU restatements of the reference's algorithm for the retrieve-then-generate hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg
+may import anything from here, and only as the checker — never as the thing measured or shipped.
+The product path (domain-rag_amd/) never imports this package and has no CPU fallback.
+
+PARITY UNPINNED: the reference (LiYu0524/Domain-RAG) ships no tests or golden vectors, and the
+wheels that hold its arithmetic (diffusers 0.33.1, transformers 4.46.3, openai/CLIP@dcba3cb,
+faiss 1.10.0, torchvision 0.22.0 — requirements.txt:4,7,8,9,60,62) are neither vendored under
+/root/reference nor installable offline.  The restatements are anchored on the reference's call
+sites (cited per function) and, where possible, cross-checked against `transformers` modules that
+ARE importable here (tests/test_oracle_crosscheck.py).
+"""

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """Build (or reuse) libdomainrag_hip.so; hipcc cross-compiles without a GPU."""
+    import __graft_entry__ as ge
+    ge.build()
+    from domain_rag_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu(built_lib):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("test is marked gpu but no GPU is visible (domain-rag_amd has no CPU fallback)")
+    return torch.device("cuda:0")

@@ -1,0 +1,216 @@
+"""Parity of each HIP kernel (through the C ABI) against the CPU oracle on seeded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _randn(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).bfloat16()
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (16, 256, 128), (200, 136, 192), (1000, 384, 3072), (333, 3072, 1024)])
+def test_gemm_plain(gpu, M, N, K):
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    a, w, b = _randn((M, K), 1), _randn((N, K), 2, 0.05), _randn((N,), 3)
+    out = ops.gemm(a.to(gpu), w.to(gpu), bias=b.to(gpu)).cpu()
+    ref64 = (a.double() @ w.double().T + b.double())
+    # asymmetric, transpose-detecting: compare against fp64 with bf16 output tolerance
+    assert _rel(out, ref64) < 6e-3
+    assert torch.allclose(out.float(), ops_ref.gemm_ref(a, w, b).float(), rtol=2e-2, atol=2e-2 * ref64.abs().max().item() / 8)
+
+
+def test_gemm_identity_asymmetric(gpu):
+    """A = I with an asymmetric W catches a row<->col swap in the C write."""
+    from domain_rag_amd import ops
+    K = N = 128
+    a = torch.eye(K).bfloat16()
+    w = (torch.arange(N)[:, None] * 1.0 + torch.arange(K)[None, :] * 0.001).bfloat16()
+    out = ops.gemm(a.to(gpu), w.to(gpu)).cpu()
+    assert torch.equal(out, w.T.contiguous())
+
+
+@pytest.mark.parametrize("act", [1, 2, 3, 4])
+def test_gemm_act(gpu, act):
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    a, w, b = _randn((300, 256), 4), _randn((512, 256), 5, 0.1), _randn((512,), 6)
+    out = ops.gemm(a.to(gpu), w.to(gpu), bias=b.to(gpu), act=act).cpu()
+    ref = ops_ref.gemm_ref(a, w, b, act=act)
+    assert _rel(out, ref) < 1e-2
+
+
+def test_gemm_gate_resid_batched_rows(gpu):
+    """x[:, St:] += gate[b] * (a @ w.T + bias) inside a joint [B, S, D] buffer (in place)."""
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    B, St, Si, D, K = 3, 24, 200, 256, 128
+    S = St + Si
+    x = _randn((B, S, D), 7)
+    a = _randn((B, S, K), 8)           # A also lives in a joint buffer
+    w, b = _randn((D, K), 9, 0.1), _randn((D,), 10)
+    mod = _randn((B, 6 * D), 11)
+    xd, ad, modd = x.to(gpu), a.to(gpu), mod.to(gpu)
+    ops.gemm(ad.view(-1)[St * K:], w.to(gpu), out=xd.view(-1)[St * D:], bias=b.to(gpu), M=B * Si,
+             a_rows_per_batch=Si, a_batch_stride=S * K, lda=K, c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D,
+             gate=modd.view(-1)[2 * D:], resid=xd.view(-1)[St * D:], ldg=6 * D)
+    got = xd.cpu()
+    gate = mod[:, 2 * D:3 * D]
+    ref_img = ops_ref.gemm_ref(a[:, St:].reshape(-1, K), w, b, gate=gate, resid=x[:, St:].reshape(-1, D), rows_per_batch=Si)
+    assert torch.equal(got[:, :St], x[:, :St]), "text rows must be untouched"
+    assert _rel(got[:, St:].reshape(-1, D), ref_img) < 1e-2
+
+
+def test_gemm_f32_out_and_errors(gpu):
+    from domain_rag_amd import ops
+    a, w = _randn((64, 128), 12), _randn((64, 128), 13)
+    out = ops.gemm(a.to(gpu), w.to(gpu), out_f32=True).cpu()
+    assert out.dtype == torch.float32
+    assert _rel(out, a.double() @ w.double().T) < 1e-5
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(_randn((8, 96), 1).to(gpu), _randn((8, 96), 2).to(gpu))
+
+
+# ------------------------------------------------------------------ elementwise
+def test_layernorm_modulate(gpu):
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    B, S, D = 2, 37, 3072
+    x, sc, sh = _randn((B, S, D), 1, 2.0), _randn((B, D), 2, 0.3), _randn((B, D), 3, 0.3)
+    mod = torch.cat([sh, sc], dim=1).contiguous()
+    y = torch.empty((B * S, D), dtype=torch.bfloat16, device=gpu)
+    md = mod.to(gpu)
+    ops.layernorm(x.to(gpu), y, B * S, D, scale=md.view(-1)[D:], shift=md.view(-1), ldx=D, rows_per_batch=S,
+                  x_batch_stride=S * D, ld_mod=2 * D)
+    ref = ops_ref.layernorm_modulate_ref(x, sc, sh).reshape(B * S, D)
+    assert _rel(y.cpu(), ref) < 1e-2
+    # affine LayerNorm (ViT), odd width
+    D2 = 1152
+    x2, g, b = _randn((5, 7, D2), 4), _randn((D2,), 5), _randn((D2,), 6)
+    y2 = torch.empty((35, D2), dtype=torch.bfloat16, device=gpu)
+    ops.layernorm(x2.to(gpu), y2, 35, D2, gamma=g.to(gpu), beta=b.to(gpu), eps=1e-5)
+    assert _rel(y2.cpu(), ops_ref.layernorm_modulate_ref(x2, gamma=g, beta=b, eps=1e-5).reshape(35, D2)) < 1e-2
+
+
+def test_small_elementwise(gpu):
+    from domain_rag_amd import ops
+    from oracle import flux as oflux
+    x, v = _randn((3, 1001), 1), _randn((3, 1001), 2)
+    assert torch.equal(ops.add(x.to(gpu), v.to(gpu)).cpu(), x + v)
+    xd = x.to(gpu).clone()
+    ops.flow_euler_step(xd, v.to(gpu), -0.0371)
+    assert torch.equal(xd.cpu(), oflux.euler_step(x, v, 0.5371, 0.5))
+    assert _rel(ops.act(x.to(gpu), ops.ACT_SILU).cpu(), torch.nn.functional.silu(x)) < 1e-2
+    t = torch.tensor([0.0, 1.0, 356.0, 1000.0])
+    te = ops.timestep_embedding(t.to(gpu), 256).cpu().float()
+    assert torch.allclose(te, oflux.timestep_proj(t).bfloat16().float(), atol=2e-2)
+    f = torch.randn(1000)
+    assert torch.equal(ops.to_bf16(f.to(gpu)).cpu(), f.bfloat16())
+    assert torch.equal(ops.to_f32(x.to(gpu)).cpu(), x.float())
+
+
+# ------------------------------------------------------------------ attention
+def _attn_case(gpu, B, S, H, s_txt, seed, spike=False):
+    from domain_rag_amd import ops
+    from oracle import flux as oflux, ops_ref
+    D = H * 128
+    qkv = _randn((B, S, 3 * D), seed)
+    if spike:  # force a large running-max jump mid-sequence (online-softmax rescale path)
+        qkv[0, 5, 0:128] = 4.0
+        qkv[0, S // 2, D:D + 128] = 4.0
+    wq, wk, cwq, cwk = (1 + 0.1 * _randn((128,), seed + i).float()).bfloat16() if False else None, None, None, None
+    wq = (1 + 0.1 * torch.randn(128, generator=torch.Generator().manual_seed(seed + 1))).bfloat16()
+    wk = (1 + 0.1 * torch.randn(128, generator=torch.Generator().manual_seed(seed + 2))).bfloat16()
+    cwq = (1 + 0.1 * torch.randn(128, generator=torch.Generator().manual_seed(seed + 3))).bfloat16()
+    cwk = (1 + 0.1 * torch.randn(128, generator=torch.Generator().manual_seed(seed + 4))).bfloat16()
+    hh = int(math.sqrt(max(S - s_txt, 1)))
+    ids = torch.zeros(S, 3)
+    n_img = S - s_txt
+    ids[s_txt:, 1] = torch.arange(n_img) // max(hh, 1)
+    ids[s_txt:, 2] = torch.arange(n_img) % max(hh, 1)
+    cos, sin = oflux.rope_tables(ids)
+    # ---- oracle
+    q, k, v = [t.view(B, S, H, 128).transpose(1, 2) for t in qkv.split(D, dim=-1)]
+    qn = torch.cat([oflux.rms_norm(q[:, :, :s_txt], cwq), oflux.rms_norm(q[:, :, s_txt:], wq)], dim=2)
+    kn = torch.cat([oflux.rms_norm(k[:, :, :s_txt], cwk), oflux.rms_norm(k[:, :, s_txt:], wk)], dim=2)
+    qr, kr = oflux.apply_rope(qn, cos, sin), oflux.apply_rope(kn, cos, sin)
+    scale = 1 / math.sqrt(128)
+    ref = ops_ref.attention_ref_f64(qr, kr, v, scale)
+    # ---- HIP
+    qd = qkv.to(gpu).clone()
+    s_pad = (S + 63) // 64 * 64
+    vt = torch.full((B, H, 128, s_pad), float("nan"), dtype=torch.bfloat16, device=gpu)
+    ops.qk_norm_rope_vt(qd, vt, cwq.to(gpu), cwk.to(gpu), wq.to(gpu), wk.to(gpu), cos.to(gpu), sin.to(gpu), B, S, H, 3 * D, s_txt)
+    got_q = qd.cpu()[..., :D].view(B, S, H, 128).transpose(1, 2)
+    got_k = qd.cpu()[..., D:2 * D].view(B, S, H, 128).transpose(1, 2)
+    assert _rel(got_q, qr) < 1e-2 and _rel(got_k, kr) < 1e-2
+    assert torch.equal(qd.cpu()[..., 2 * D:], qkv[..., 2 * D:]), "v must be untouched"
+    out = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
+    ops.attention(qd, qd.view(-1)[D:], vt, out, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
+    o = out.cpu()
+    assert torch.isfinite(o.float()).all()
+    # reference evaluated on the kernel's own (bf16) q/k so only the attention is compared
+    ref2 = ops_ref.attention_ref_f64(got_q, got_k, v, scale)
+    assert _rel(o, ref2) < 1.5e-2
+    assert _rel(o, ref) < 3e-2
+
+
+@pytest.mark.parametrize("B,S,H,s_txt", [(1, 64, 1, 0), (2, 200, 2, 24), (1, 333, 3, 77), (1, 1241 + 256, 2, 1241)])
+def test_attention(gpu, B, S, H, s_txt):
+    _attn_case(gpu, B, S, H, s_txt, seed=11)
+
+
+def test_attention_spike(gpu):
+    _attn_case(gpu, 1, 300, 1, 10, seed=5, spike=True)
+
+
+# ------------------------------------------------------------------ top-k
+@pytest.mark.parametrize("N,Q,k", [(1000, 16, 100), (37, 3, 37), (5000, 1, 100), (20000, 20, 7), (4097, 2, 2048)])
+def test_topk_bit_exact(gpu, N, Q, k):
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(N + Q)
+    corpus = rng.standard_normal((N, 512)).astype(np.float32)
+    corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
+    qs = rng.standard_normal((Q, 512)).astype(np.float32)
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu), k)
+    Dr, Ir = oret.cosine_topk(corpus, qs, k)
+    assert np.array_equal(I.cpu().numpy(), Ir)
+    assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+
+
+def test_topk_ties_and_padding(gpu):
+    """duplicated rows give exact ties -> lower index first; k > N pads with (-FLT_MAX, -1)."""
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((50, 512)).astype(np.float32)
+    corpus = np.concatenate([base, base, base[::-1]], axis=0)  # every row appears 3 times
+    qs = base[:5].copy()
+    D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu), 150)
+    Dr, Ir = oret.cosine_topk(corpus, qs, 150)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+    assert (I.cpu().numpy()[:, 0] == np.arange(5)).all()
+    D2, I2 = ops.cosine_topk(torch.from_numpy(corpus[:10]).to(gpu), torch.from_numpy(qs).to(gpu), 16)
+    D2r, I2r = oret.cosine_topk(corpus[:10], qs, 16)
+    assert np.array_equal(I2.cpu().numpy(), I2r) and np.array_equal(D2.cpu().numpy(), D2r)
+    assert (I2.cpu().numpy()[:, 10:] == -1).all()
+
+
+def test_l2_normalize(gpu):
+    from domain_rag_amd import ops
+    x = torch.randn(33, 512)
+    y = ops.l2_normalize_(x.to(gpu).clone()).cpu()
+    assert torch.allclose(y, x / x.norm(dim=-1, keepdim=True), atol=1e-6)
