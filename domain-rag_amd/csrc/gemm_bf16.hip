@@ -73,14 +73,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
 
   // ---- staging addresses: wave w stages 8-row chunks {4w..4w+3} of both tiles ----
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.w_bytes, 0x00020000);
+  // W descriptor is based at this tile's first row, so stacked weights of any size work
+  const int wrows = min(BN, p.N - n0);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0,
+                                                                 (unsigned)((long long)wrows * p.K * 2), 0x00020000);
   unsigned voffA[4], voffW[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (w * 4 + i) * 8 + (l >> 3);           // row within tile
     const int slot = (l & 7) ^ ((row >> 1) & 7);           // logical 16-B slot this lane fetches
     int ra = min(m0 + row, p.M - 1);                       // clamp: rows past the edge are never stored
-    int rw = min(n0 + row, p.N - 1);
+    int rw = min(row, wrows - 1);
     voffA[i] = (unsigned)((p.am.off(ra) + slot * 8) * 2);
     voffW[i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
   }
@@ -206,9 +209,9 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   // byte span of A / W for the buffer descriptors (raw buffers address with 32-bit offsets)
   const long long a_rows_b = (long long)((a->M - 1) / k.am.rpb);
   const long long a_span = (a_rows_b * k.am.bs + (long long)(k.am.rpb - 1) * k.am.ld + a->K) * 2;
-  const long long w_span = (long long)a->N * a->K * 2;
-  DRAG_CHECK(a_span < (1ll << 31) && w_span < (1ll << 31), "drag_gemm_bf16: operand span must be < 2 GiB");
-  k.a_bytes = (unsigned)a_span; k.w_bytes = (unsigned)w_span;
+  DRAG_CHECK(a_span < (1ll << 31), "drag_gemm_bf16: A span must be < 2 GiB");
+  DRAG_CHECK((long long)BN * a->K * 2 < (1ll << 31), "drag_gemm_bf16: K too large");
+  k.a_bytes = (unsigned)a_span; k.w_bytes = 0;
   k.tiles_m = (a->M + BM - 1) / BM; k.tiles_n = (a->N + BN - 1) / BN;
   const int grid = k.tiles_m * k.tiles_n;
   hipLaunchKernelGGL(gemm_bf16_t128, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);

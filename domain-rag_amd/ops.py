@@ -16,6 +16,27 @@ from ._lib import GemmArgs, check
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2, 3, 4
 
 
+class GemmRecorder:
+    """Per-launch timing of the GEMM kernel with events on the launch stream (bench.py's roofline)."""
+
+    def __init__(self):
+        self.events = []
+
+    def totals(self):
+        torch.cuda.synchronize()
+        flops = sum(f for _, _, f in self.events)
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.events)
+        return flops, ms, len(self.events)
+
+
+_recorder: GemmRecorder | None = None
+
+
+def set_recorder(rec: GemmRecorder | None) -> None:
+    global _recorder
+    _recorder = rec
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -65,6 +86,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, b
     args.lda, args.a_rows_per_batch, args.a_batch_stride = lda, a_rows_per_batch, a_batch_stride
     args.ldc, args.c_rows_per_batch, args.c_batch_stride = ldc, c_rows_per_batch, c_batch_stride
     args.ldg, args.act, args.act_n0, args.out_f32 = ldg, act, act_n0, int(out_f32)
+    if _recorder is not None:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+        check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
+        e_ev.record()
+        _recorder.events.append((s_ev, e_ev, 2.0 * M * N * K))
+        return out
     check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
     return out
 

@@ -43,7 +43,7 @@ const char* drag_last_error(void);
  *   epilogue:  v = acc + bias[n];  v = act(v) for n >= act_n0;
  *              gate != NULL:  C = resid + gate[r / c_rows_per_batch, n] * v   (bf16-rounded like torch)
  *              else resid != NULL: C = resid + v
- *   Requires K % 64 == 0, N % 4 == 0, lda % 8 == 0, ldc % 4 == 0, operand spans < 2 GiB.
+ *   Requires K % 64 == 0, N % 4 == 0, lda % 8 == 0, ldc % 4 == 0, A span < 2 GiB.
  */
 typedef struct drag_gemm_args {
   const void* A;
