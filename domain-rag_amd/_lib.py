@@ -22,6 +22,12 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class ConvArgs(ctypes.Structure):
+    """mirror of ``drag_conv_args``"""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("bias", c_void_p), ("resid", c_void_p)] + \
+               [(n, c_int) for n in ("B", "Ho", "Wo", "Hp", "Wp", "Cin", "Cout", "ldy", "stride", "oy", "ox", "act")]
+
+
 # name -> (restype, argtypes); every symbol include/domainrag_hip.h declares
 SIGNATURES = {
     "drag_version": (c_int, []),
@@ -39,6 +45,18 @@ SIGNATURES = {
     "drag_cosine_topk_workspace_bytes": (c_int64, [c_int64, c_int]),
     "drag_cosine_topk_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "drag_l2_normalize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+    "drag_conv3x3_bf16": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
+    "drag_groupnorm_workspace_bytes": (c_int64, [c_int] * 4),
+    "drag_groupnorm_silu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_float, c_void_p, c_void_p]),
+    "drag_pad_copy_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "drag_softmax_rows_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "drag_unpack_latents_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_float, c_void_p]),
+    "drag_sample_pack_latents_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_float, c_float, c_void_p]),
+    "drag_image_preprocess_u8": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "drag_image_postprocess_u8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "drag_mask_pack_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "drag_flow_euler_rows_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "drag_scale_noise_rows_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
 }
 
 _lib = None

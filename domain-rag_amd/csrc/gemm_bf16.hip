@@ -35,6 +35,21 @@ struct RowMap {
   }
 };
 
+// conv mode (implicit GEMM, 3x3): A is a zero-haloed NHWC activation [B, Hp, Wp, Cin]; logical row
+// m = (b, y, x) of the [B*Ho*Wo, 9*Cin] im2col matrix starts at pixel (y*stride + oy, x*stride + ox)
+// and K-tile kt = (tap, channel chunk) adds ((tap/3)*Wp + tap%3)*Cin + chunk*64.
+struct ConvMap {
+  int Ho, Wo, Hp, Wp, Cin, stride, oy, ox;
+  __device__ __forceinline__ long long off(int m) const {
+    const int hw = Ho * Wo;
+    const int b = m / hw;
+    const int r = m - b * hw;
+    const int y = r / Wo;
+    const int x = r - y * Wo;
+    return (((long long)b * Hp + y * stride + oy) * Wp + x * stride + ox) * Cin;
+  }
+};
+
 struct GemmKArgs {
   const bf16_t* A;
   const bf16_t* W;
@@ -44,6 +59,7 @@ struct GemmKArgs {
   const bf16_t* resid;  // same row addressing as C, or null
   int M, N, K;
   RowMap am, cm;
+  ConvMap cv;
   int ldg;
   int act;
   int act_n0;     // activation applies to columns >= act_n0
@@ -52,6 +68,7 @@ struct GemmKArgs {
   int tiles_m, tiles_n;
 };
 
+template <int MODE>  // 0: batched rows, 1: conv3x3 implicit GEMM
 __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
   const int w = wave_id();
@@ -72,7 +89,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging addresses: wave w stages 8-row chunks {4w..4w+3} of both tiles ----
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  // descriptors are based at the tile's first row (addresses grow with the row index), so operands
+  // of any size work with 32-bit in-tile offsets; rows are clamped, so no access leaves the tensor
+  const long long a0 = MODE == 0 ? p.am.off(m0) : p.cv.off(m0);
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a0), 0, 0x7ffffff0u, 0x00020000);
   // W descriptor is based at this tile's first row, so stacked weights of any size work
   const int wrows = min(BN, p.N - n0);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0,
@@ -84,17 +104,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
     const int slot = (l & 7) ^ ((row >> 1) & 7);           // logical 16-B slot this lane fetches
     int ra = min(m0 + row, p.M - 1);                       // clamp: rows past the edge are never stored
     int rw = min(row, wrows - 1);
-    voffA[i] = (unsigned)((p.am.off(ra) + slot * 8) * 2);
+    voffA[i] = (unsigned)(((MODE == 0 ? p.am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
     voffW[i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
   }
 
+  const int cchunks = MODE == 1 ? p.cv.Cin / BK : 1;
   auto stage = [&](int buf, int kt) {
     const int soff = kt * (BK * 2);
+    int soffA = soff;
+    if (MODE == 1) {
+      const int tap = kt / cchunks, cc = kt - tap * cchunks;
+      const int r = tap / 3, sx = tap - r * 3;
+      soffA = ((r * p.cv.Wp + sx) * p.cv.Cin + cc * BK) * 2;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       DRAG_LDS char* dA = (DRAG_LDS char*)smem + buf * TILE_BYTES + (w * 4 + i) * 1024;
       DRAG_LDS char* dB = (DRAG_LDS char*)smem + (2 + buf) * TILE_BYTES + (w * 4 + i) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)dA, 16, voffA[i], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)dA, 16, voffA[i], soffA, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)dB, 16, voffW[i], soff, 0, 0);
     }
   };
@@ -189,6 +216,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
 
 }  // namespace
 
+static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, const void* bias, const void* gate,
+                       const void* resid, int M, int N, int K, int ldc, int c_rpb, long long c_bs, int ldg, int act,
+                       int act_n0, int out_f32) {
+  k.A = (const bf16_t*)A; k.W = (const bf16_t*)W; k.C = C;
+  k.bias = (const bf16_t*)bias; k.gate = (const bf16_t*)gate; k.resid = (const bf16_t*)resid;
+  k.M = M; k.N = N; k.K = K;
+  k.cm.rpb = c_rpb > 0 ? c_rpb : M; k.cm.bs = c_bs; k.cm.ld = ldc;
+  k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
+  k.a_bytes = 0; k.w_bytes = 0;
+  k.tiles_m = (M + BM - 1) / BM; k.tiles_n = (N + BN - 1) / BN;
+  return k.tiles_m * k.tiles_n;
+}
+
 extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   DRAG_CHECK(a != nullptr, "drag_gemm_bf16: null args");
   DRAG_CHECK(a->A && a->W && a->C, "drag_gemm_bf16: null operand pointer");
@@ -198,23 +238,39 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   DRAG_CHECK(a->lda % 8 == 0 && a->ldc % 4 == 0, "drag_gemm_bf16: lda %% 8 and ldc %% 4 required");
   DRAG_CHECK(!(a->gate && !a->resid), "drag_gemm_bf16: gate needs resid");
   GemmKArgs k;
-  k.A = (const bf16_t*)a->A; k.W = (const bf16_t*)a->W; k.C = a->C;
-  k.bias = (const bf16_t*)a->bias; k.gate = (const bf16_t*)a->gate; k.resid = (const bf16_t*)a->resid;
-  k.M = a->M; k.N = a->N; k.K = a->K;
+  const int grid = fill_common(k, a->A, a->W, a->C, a->bias, a->gate, a->resid, a->M, a->N, a->K, a->ldc,
+                               a->c_rows_per_batch, a->c_batch_stride, a->ldg, a->act, a->act_n0, a->out_f32);
   k.am.rpb = a->a_rows_per_batch > 0 ? a->a_rows_per_batch : a->M;
   k.am.bs = a->a_batch_stride; k.am.ld = a->lda;
-  k.cm.rpb = a->c_rows_per_batch > 0 ? a->c_rows_per_batch : a->M;
-  k.cm.bs = a->c_batch_stride; k.cm.ld = a->ldc;
-  k.ldg = a->ldg; k.act = a->act; k.act_n0 = a->act_n0; k.out_f32 = a->out_f32;
-  // byte span of A / W for the buffer descriptors (raw buffers address with 32-bit offsets)
-  const long long a_rows_b = (long long)((a->M - 1) / k.am.rpb);
-  const long long a_span = (a_rows_b * k.am.bs + (long long)(k.am.rpb - 1) * k.am.ld + a->K) * 2;
-  DRAG_CHECK(a_span < (1ll << 31), "drag_gemm_bf16: A span must be < 2 GiB");
-  DRAG_CHECK((long long)BN * a->K * 2 < (1ll << 31), "drag_gemm_bf16: K too large");
-  k.a_bytes = (unsigned)a_span; k.w_bytes = 0;
-  k.tiles_m = (a->M + BM - 1) / BM; k.tiles_n = (a->N + BN - 1) / BN;
-  const int grid = k.tiles_m * k.tiles_n;
-  hipLaunchKernelGGL(gemm_bf16_t128, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+  k.cv = ConvMap{1, 1, 1, 1, 64, 1, 0, 0};
+  // in-tile offsets are 32-bit and must grow with the row index
+  DRAG_CHECK(k.am.rpb >= a->M || k.am.bs >= (long long)(k.am.rpb - 1) * k.am.ld,
+             "drag_gemm_bf16: a_batch_stride must not be smaller than one batch of rows");
+  DRAG_CHECK(((long long)BM * a->lda + a->K) * 2 < (1ll << 30) && (long long)BN * a->K * 2 < (1ll << 31) &&
+                 (k.am.rpb >= a->M || (k.am.bs - (long long)(k.am.rpb - 1) * k.am.ld) * 2 < (1ll << 30)),
+             "drag_gemm_bf16: tile span too large for 32-bit offsets");
+  hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
+  DRAG_CHECK(a != nullptr && a->x && a->w && a->y, "drag_conv3x3_bf16: null pointer");
+  DRAG_CHECK(a->B > 0 && a->Ho > 0 && a->Wo > 0 && a->Hp > 0 && a->Wp > 0, "drag_conv3x3_bf16: bad shape");
+  DRAG_CHECK(a->Cin % BK == 0, "drag_conv3x3_bf16: Cin must be a multiple of 64 (zero-pad channels)");
+  DRAG_CHECK(a->Cout % 4 == 0 && a->ldy % 4 == 0, "drag_conv3x3_bf16: Cout and ldy must be multiples of 4");
+  DRAG_CHECK(a->stride == 1 || a->stride == 2, "drag_conv3x3_bf16: stride 1 or 2");
+  DRAG_CHECK((a->Ho - 1) * a->stride + a->oy + 2 <= a->Hp - 1 && (a->Wo - 1) * a->stride + a->ox + 2 <= a->Wp - 1,
+             "drag_conv3x3_bf16: taps leave the padded input");
+  GemmKArgs k;
+  const long long M = (long long)a->B * a->Ho * a->Wo;
+  DRAG_CHECK(M < (1ll << 31), "drag_conv3x3_bf16: too many output pixels");
+  const int grid = fill_common(k, a->x, a->w, a->y, a->bias, nullptr, a->resid, (int)M, a->Cout, 9 * a->Cin, a->ldy, 0, 0,
+                               0, a->act, 0, 0);
+  k.am.rpb = (int)M; k.am.bs = 0; k.am.ld = a->Cin;
+  k.cv = ConvMap{a->Ho, a->Wo, a->Hp, a->Wp, a->Cin, a->stride, a->oy, a->ox};
+  DRAG_CHECK(((long long)(BM * a->stride + 3 * a->Wp * 2) * a->Cin) * 2 < (1ll << 30), "drag_conv3x3_bf16: tile span too large");
+  hipLaunchKernelGGL(gemm_bf16_t128<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -200,3 +200,100 @@ def l2_normalize_(x: torch.Tensor) -> torch.Tensor:
     _need(x, torch.float32, "x")
     check(lib.drag_l2_normalize_f32(_p(x), x.shape[0], x.shape[1], _stream()), "drag_l2_normalize_f32")
     return x
+
+
+# ------------------------------------------------------------------ VAE-side ops
+def conv3x3(x_pad: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, B: int, Ho: int, Wo: int, Hp: int, Wp: int,
+            Cin: int, Cout: int, bias=None, resid=None, ldy: int | None = None, stride: int = 1, oy: int = 0, ox: int = 0,
+            act: int = ACT_NONE) -> torch.Tensor:
+    """3x3 conv over a zero-haloed NHWC input as an implicit GEMM (w is [Cout, 3, 3, Cin])."""
+    lib = _lib.load()
+    _need(x_pad, torch.bfloat16, "conv.x")
+    _need(w, torch.bfloat16, "conv.w")
+    a = _lib.ConvArgs()
+    a.x, a.w, a.y = x_pad.data_ptr(), w.data_ptr(), y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.resid = resid.data_ptr() if resid is not None else None
+    a.B, a.Ho, a.Wo, a.Hp, a.Wp, a.Cin, a.Cout = B, Ho, Wo, Hp, Wp, Cin, Cout
+    a.ldy, a.stride, a.oy, a.ox, a.act = ldy if ldy is not None else Cout, stride, oy, ox, act
+    if _recorder is not None:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+        check(lib.drag_conv3x3_bf16(ctypes.byref(a), _stream()), "drag_conv3x3_bf16")
+        e_ev.record()
+        _recorder.events.append((s_ev, e_ev, 2.0 * B * Ho * Wo * Cout * 9 * Cin))
+        return y
+    check(lib.drag_conv3x3_bf16(ctypes.byref(a), _stream()), "drag_conv3x3_bf16")
+    return y
+
+
+_gn_ws: dict = {}
+
+
+def groupnorm_silu(x, y, gamma, beta, B, H, W, C, *, out_pad: int, silu: bool, eps: float = 1e-6):
+    lib = _lib.load()
+    _need(x, torch.bfloat16, "gn.x")
+    nbytes = lib.drag_groupnorm_workspace_bytes(B, H, W, C)
+    key = (x.device, nbytes)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        ws = _gn_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib.drag_groupnorm_silu_bf16(_p(x), _p(y), _p(gamma), _p(beta), B, H, W, C, 32, out_pad, int(silu), eps,
+                                       _p(ws), _stream()), "drag_groupnorm_silu_bf16")
+    return y
+
+
+def pad_copy(x, y, B, H, W, C, upsample: int = 1):
+    lib = _lib.load()
+    check(lib.drag_pad_copy_bf16(_p(x), _p(y), B, H, W, C, upsample, _stream()), "drag_pad_copy_bf16")
+    return y
+
+
+def softmax_rows(x: torch.Tensor, y: torch.Tensor, rows: int, cols: int, scale: float):
+    lib = _lib.load()
+    _need(x, torch.float32, "softmax.x")
+    check(lib.drag_softmax_rows_f32_bf16(_p(x), _p(y), rows, cols, scale, _stream()), "drag_softmax_rows_f32_bf16")
+    return y
+
+
+def unpack_latents(tokens, y, B, h, w, ld, C, scaling, shift):
+    lib = _lib.load()
+    check(lib.drag_unpack_latents_bf16(_p(tokens), _p(y), B, h, w, ld, C, scaling, shift, _stream()), "drag_unpack_latents_bf16")
+    return y
+
+
+def sample_pack_latents(moments, noise, tokens, B, H, W, ldm, ld, scaling, shift):
+    lib = _lib.load()
+    check(lib.drag_sample_pack_latents_bf16(_p(moments), _p(noise), _p(tokens), B, H, W, ldm, ld, scaling, shift, _stream()),
+          "drag_sample_pack_latents_bf16")
+    return tokens
+
+
+def image_preprocess(img_u8, mask_u8, y, B, H, W, C):
+    lib = _lib.load()
+    _need(img_u8, torch.uint8, "img")
+    check(lib.drag_image_preprocess_u8(_p(img_u8), _p(mask_u8), _p(y), B, H, W, C, _stream()), "drag_image_preprocess_u8")
+    return y
+
+
+def image_postprocess(x, out_u8, npix, ld):
+    lib = _lib.load()
+    check(lib.drag_image_postprocess_u8(_p(x), _p(out_u8), npix, ld, _stream()), "drag_image_postprocess_u8")
+    return out_u8
+
+
+def mask_pack(mask_u8, tokens, B, H, W, ld):
+    lib = _lib.load()
+    _need(mask_u8, torch.uint8, "mask")
+    check(lib.drag_mask_pack_u8(_p(mask_u8), _p(tokens), B, H, W, ld, _stream()), "drag_mask_pack_u8")
+    return tokens
+
+
+def flow_euler_rows(x, v, rows, cols, ldx, ldv, dt):
+    lib = _lib.load()
+    check(lib.drag_flow_euler_rows_bf16(_p(x), _p(v), rows, cols, ldx, ldv, dt, _stream()), "drag_flow_euler_rows_bf16")
+
+
+def scale_noise_rows(x, noise, rows, cols, ldx, ldn, sigma):
+    lib = _lib.load()
+    check(lib.drag_scale_noise_rows_bf16(_p(x), _p(noise), rows, cols, ldx, ldn, sigma, _stream()), "drag_scale_noise_rows_bf16")

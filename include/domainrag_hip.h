@@ -64,6 +64,27 @@ typedef struct drag_gemm_args {
 int drag_gemm_bf16(const drag_gemm_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * drag_conv3x3_bf16 — 3x3 convolution as an implicit GEMM on the same MFMA main loop.
+ * Replaces torch.nn.Conv2d(k=3) inside AutoencoderKL.encode/decode (Flux VAE; diffusers 0.33.1,
+ * un-vendored; reached at the start/end of pipe(...) / pipe_fill(...):
+ * batch_generate_flux_kshot.py:467-474, outpainting_updown_sampling_redux.py:1246-1257).
+ *   x: NHWC bf16 with a zero halo, [B, Hp, Wp, Cin], Cin % 64 == 0 (zero-pad channels);
+ *   w: bf16 [Cout, 3, 3, Cin] (KRSC);  y: rows m = (b, yo, xo) of ldy elements (NHWC, no halo);
+ *   output pixel (yo, xo) reads input pixels (yo*stride + oy + r, xo*stride + ox + s), r,s in 0..2
+ *   (pad=1 stride=1: halo 1, oy = ox = 0;  diffusers' Downsample2D pad (0,1,0,1) stride 2: oy = ox = 1).
+ *   epilogue: y = act(conv + bias) or resid + (conv + bias)   (resid addressed like y).
+ */
+typedef struct drag_conv_args {
+  const void* x;
+  const void* w;
+  void* y;
+  const void* bias;
+  const void* resid;
+  int32_t B, Ho, Wo, Hp, Wp, Cin, Cout, ldy, stride, oy, ox, act;
+} drag_conv_args;
+int drag_conv3x3_bf16(const drag_conv_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * drag_qk_norm_rope_vt_bf16 — per-head RMSNorm(128) on q,k + interleaved-pair RoPE, in place,
  * and V -> V^T repack for the attention kernel.  Replaces FluxAttnProcessor2_0's norm_q/norm_k/
  * norm_added_q/norm_added_k + apply_rotary_emb (diffusers 0.33.1, un-vendored; call sites as above).
@@ -126,6 +147,42 @@ int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, i
                          void* stream);
 /* L2-normalise rows in place (image_embedding / image_embedding.norm(dim=-1), retrieval/...:172) */
 int drag_l2_normalize_f32(float* x, int64_t rows, int32_t d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Flux VAE helpers (AutoencoderKL.encode/decode, VaeImageProcessor, FluxFillPipeline.prepare_mask_latents,
+ * FluxPipeline._pack_latents/_unpack_latents — diffusers 0.33.1, un-vendored; reached from
+ * batch_generate_flux_kshot.py:467-474 and outpainting_updown_sampling_redux.py:1246-1257).
+ * Activations are NHWC bf16; "haloed" buffers are [B, H+2, W+2, C] with a zero border that kernels never write.
+ */
+/* GroupNorm(groups=32) (+ SiLU) over NHWC [B,H,W,C] -> y, optionally into a haloed buffer (out_pad=1). */
+int64_t drag_groupnorm_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C);
+int drag_groupnorm_silu_bf16(const void* x, void* y, const void* gamma, const void* beta, int32_t B,
+                             int32_t H, int32_t W, int32_t C, int32_t groups, int32_t out_pad,
+                             int32_t silu, float eps, void* workspace, void* stream);
+/* copy NHWC [B,H,W,C] into the interior of a haloed [B, up*H+2, up*W+2, C] buffer, nearest-upsampling by `upsample` (1|2) */
+int drag_pad_copy_bf16(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t upsample,
+                       void* stream);
+/* y = softmax(x * scale) per row, f32 in, bf16 out (VAE mid-block attention, softmax upcast) */
+int drag_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols, float scale, void* stream);
+/* packed tokens [B, h*w, ld] (64 features) -> haloed NHWC latents [B, 2h+2, 2w+2, C]: tok / scaling + shift */
+int drag_unpack_latents_bf16(const void* tokens, void* y, int32_t B, int32_t h, int32_t w, int32_t ld, int32_t C,
+                             float scaling, float shift, void* stream);
+/* encoder moments NHWC [B,H,W,ldm] (mean|logvar) (+ noise NCHW [B,16,H,W], may be NULL = mode) ->
+ * packed tokens [B,(H/2)(W/2), ld]: ((mean + std*noise) - shift) * scaling */
+int drag_sample_pack_latents_bf16(const void* moments, const void* noise, void* tokens, int32_t B, int32_t H,
+                                  int32_t W, int32_t ldm, int32_t ld, float scaling, float shift, void* stream);
+/* uint8 RGB [B,H,W,3] (+ uint8 mask [B,H,W], may be NULL) -> haloed NHWC bf16: (2*u8/255-1) * (1-binarised mask) */
+int drag_image_preprocess_u8(const void* img, const void* mask, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                             void* stream);
+/* rows [npix, ld] bf16 (3 real channels) -> uint8 RGB [npix,3]: ((x/2+0.5).clamp(0,1)*255).round() */
+int drag_image_postprocess_u8(const void* x, void* out, int64_t npix, int32_t ld, void* stream);
+/* uint8 mask [B,H,W] -> 256 mask features per token (8x8 pixel-unshuffle then 2x2 pack), tokens [B,(H/16)(W/16), ld] */
+int drag_mask_pack_u8(const void* mask, void* tokens, int32_t B, int32_t H, int32_t W, int32_t ld, void* stream);
+/* strided forms on token rows: x[r, :cols] += dt * v[r, :cols];  x = sigma*noise + (1-sigma)*x (scale_noise) */
+int drag_flow_euler_rows_bf16(void* x, const void* v, int64_t rows, int32_t cols, int32_t ldx, int32_t ldv, float dt,
+                              void* stream);
+int drag_scale_noise_rows_bf16(void* x, const void* noise, int64_t rows, int32_t cols, int32_t ldx, int32_t ldn,
+                               float sigma, void* stream);
 
 #ifdef __cplusplus
 }
