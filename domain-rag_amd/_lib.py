@@ -45,6 +45,8 @@ SIGNATURES = {
     "drag_cosine_topk_workspace_bytes": (c_int64, [c_int64, c_int]),
     "drag_cosine_topk_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "drag_l2_normalize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+    "drag_patchify_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
+    "drag_scale_sum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "drag_conv3x3_bf16": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
     "drag_groupnorm_workspace_bytes": (c_int64, [c_int] * 4),
     "drag_groupnorm_silu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_float, c_void_p, c_void_p]),

@@ -39,6 +39,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(PrepArgs p) {
   // ---- q and k: 16 lanes per row, 8 elements per lane ----
   const int sub = tid & 15;        // which 8-element group of the 128
   const int rloc = tid >> 4;       // 0..15
+  const bool do_norm = p.wq_txt != nullptr, do_rope = p.cosT != nullptr;
+  if (do_norm || do_rope)
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     for (int it = 0; it < 4; ++it) {
@@ -61,16 +63,25 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(PrepArgs p) {
       ss += __shfl_xor(ss, 2, 64);
       ss += __shfl_xor(ss, 1, 64);
       const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
-      const bf16_t* wsel = which == 0 ? (sc < p.s_txt ? p.wq_txt : p.wq_img) : (sc < p.s_txt ? p.wk_txt : p.wk_img);
-      const u32x4_t wr = *(const u32x4_t*)(wsel + sub * 8);
-      const f32x4_t c4 = *(const f32x4_t*)(p.cosT + (long long)sc * 64 + sub * 4);
-      const f32x4_t s4 = *(const f32x4_t*)(p.sinT + (long long)sc * 64 + sub * 4);
+      u32x4_t wr = (u32x4_t){0u, 0u, 0u, 0u};
+      if (do_norm) {
+        const bf16_t* wsel = which == 0 ? (sc < p.s_txt ? p.wq_txt : p.wq_img) : (sc < p.s_txt ? p.wk_txt : p.wk_img);
+        wr = *(const u32x4_t*)(wsel + sub * 8);
+      }
+      f32x4_t c4 = (f32x4_t){1.f, 1.f, 1.f, 1.f}, s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (do_rope) {
+        c4 = *(const f32x4_t*)(p.cosT + (long long)sc * 64 + sub * 4);
+        s4 = *(const f32x4_t*)(p.sinT + (long long)sc * 64 + sub * 4);
+      }
       u32x4_t o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // diffusers RMSNorm: (x * rsqrt(var+eps)).to(bf16) * weight(bf16) -> bf16
-        const float a0 = rbf(rbf(x[2 * j] * rs) * bf2f((bf16_t)(wr[j] & 0xffff)));
-        const float a1 = rbf(rbf(x[2 * j + 1] * rs) * bf2f((bf16_t)(wr[j] >> 16)));
+        float a0 = x[2 * j], a1 = x[2 * j + 1];
+        if (do_norm) {
+          a0 = rbf(rbf(a0 * rs) * bf2f((bf16_t)(wr[j] & 0xffff)));
+          a1 = rbf(rbf(a1 * rs) * bf2f((bf16_t)(wr[j] >> 16)));
+        }
         // apply_rotary_emb (use_real, unbind_dim=-1): out = x*cos + rot(x)*sin in fp32
         const float r0 = a0 * c4[j] - a1 * s4[j];
         const float r1 = a1 * c4[j] + a0 * s4[j];
@@ -284,8 +295,10 @@ extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt
                                          const void* wq_img, const void* wk_img, const float* rope_cos,
                                          const float* rope_sin, int32_t B, int32_t S, int32_t H, int32_t ld,
                                          int32_t s_txt, float eps, void* stream) {
-  DRAG_CHECK(qkv && vt && wq_txt && wk_txt && wq_img && wk_img && rope_cos && rope_sin,
-             "drag_qk_norm_rope_vt_bf16: null pointer");
+  DRAG_CHECK(qkv && vt, "drag_qk_norm_rope_vt_bf16: null pointer");
+  DRAG_CHECK((wq_txt && wk_txt && wq_img && wk_img) || (!wq_txt && !wk_txt && !wq_img && !wk_img),
+             "drag_qk_norm_rope_vt_bf16: norm weights are all-or-none");
+  DRAG_CHECK((rope_cos == nullptr) == (rope_sin == nullptr), "drag_qk_norm_rope_vt_bf16: cos/sin come in pairs");
   DRAG_CHECK(B > 0 && S > 0 && H > 0 && ld >= 3 * H * 128 && ld % 8 == 0, "drag_qk_norm_rope_vt_bf16: bad shape");
   PrepArgs p;
   p.qkv = (bf16_t*)qkv; p.vt = (bf16_t*)vt;

@@ -170,6 +170,42 @@ __global__ void timestep_embedding_kernel(const float* t, bf16_t* out, int B, in
   out[(long long)b * dim + half + j] = f2bf(sinf(a));
 }
 
+// uint8 RGB [B, H, W, 3] -> normalised patch rows [B*(H/P)*(W/P), ldo] bf16, k = c*P*P + py*P + px
+// (the flattening of a Conv2d(3, D, P, stride=P) weight), columns >= 3*P*P zero-filled.
+struct PatchArgs { const uint8_t* img; bf16_t* out; int B, H, W, P, ldo; float mean[3], istd[3]; };
+__global__ __launch_bounds__(256) void patchify_kernel(PatchArgs p) {
+  const int gh = p.H / p.P, gw = p.W / p.P;
+  const long long total = (long long)p.B * gh * gw * p.ldo;
+  const int kk = 3 * p.P * p.P;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % p.ldo);
+    const long long row = i / p.ldo;
+    float v = 0.f;
+    if (k < kk) {
+      const int c = k / (p.P * p.P), r = k - c * p.P * p.P;
+      const int py = r / p.P, px = r - py * p.P;
+      const int pw = (int)(row % gw);
+      const long long t = row / gw;
+      const int ph = (int)(t % gh), b = (int)(t / gh);
+      const uint8_t u = p.img[(((long long)b * p.H + ph * p.P + py) * p.W + pw * p.P + px) * 3 + c];
+      v = ((float)u * (1.0f / 255.0f) - p.mean[c]) * p.istd[c];
+    }
+    p.out[i] = f2bf(v);
+  }
+}
+
+// out[g, e] = bf16( sum_n bf16(scale[g*N+n] * x[g, n, e]) )   (Redux: prompt_embeds *= scale; sum(dim=0))
+__global__ __launch_bounds__(256) void scale_sum_kernel(const bf16_t* x, const float* scales, bf16_t* out, int G, int N,
+                                                        long long elems) {
+  const long long total = (long long)G * elems;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long g = i / elems, e = i - g * elems;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += rbf(rbf(scales[g * N + n]) * bf2f(x[(g * N + n) * elems + e]));
+    out[i] = f2bf(acc);
+  }
+}
+
 inline int ew_grid(long long n8) {
   long long g = (n8 + 255) / 256;
   if (g < 1) g = 1;
@@ -246,6 +282,28 @@ extern "C" int drag_timestep_embedding_bf16(const float* t, void* out, int32_t B
   const int n = B * (dim / 2);
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
                      (bf16_t*)out, B, dim);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int drag_patchify_u8(const void* img, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t ldo,
+                                const float* mean3, const float* std3, void* stream) {
+  DRAG_CHECK(img && out && mean3 && std3, "drag_patchify_u8: null pointer");
+  DRAG_CHECK(B > 0 && P > 0 && H % P == 0 && W % P == 0 && ldo >= 3 * P * P, "drag_patchify_u8: bad shape");
+  PatchArgs p;
+  p.img = (const uint8_t*)img; p.out = (bf16_t*)out; p.B = B; p.H = H; p.W = W; p.P = P; p.ldo = ldo;
+  for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.istd[c] = 1.0f / std3[c]; }
+  const long long total = (long long)B * (H / P) * (W / P) * ldo;
+  hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int drag_scale_sum_bf16(const void* x, const float* scales, void* out, int32_t G, int32_t N, int64_t elems,
+                                   void* stream) {
+  DRAG_CHECK(x && scales && out && G > 0 && N > 0 && elems > 0, "drag_scale_sum_bf16: bad args");
+  hipLaunchKernelGGL(scale_sum_kernel, dim3(ew_grid((long long)G * elems)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, scales, (bf16_t*)out, G, N, (long long)elems);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

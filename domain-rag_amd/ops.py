@@ -102,7 +102,8 @@ def qk_norm_rope_vt(qkv: torch.Tensor, vt: torch.Tensor, wq_txt, wk_txt, wq_img,
     lib = _lib.load()
     _need(qkv, torch.bfloat16, "qkv")
     _need(vt, torch.bfloat16, "vt")
-    _need(rope_cos, torch.float32, "rope_cos")
+    if rope_cos is not None:
+        _need(rope_cos, torch.float32, "rope_cos")
     check(lib.drag_qk_norm_rope_vt_bf16(_p(qkv), _p(vt), _p(wq_txt), _p(wk_txt), _p(wq_img), _p(wk_img),
                                         _p(rope_cos), _p(rope_sin), B, S, H, ld, s_txt, eps, _stream()),
           "drag_qk_norm_rope_vt_bf16")
@@ -297,3 +298,21 @@ def flow_euler_rows(x, v, rows, cols, ldx, ldv, dt):
 def scale_noise_rows(x, noise, rows, cols, ldx, ldn, sigma):
     lib = _lib.load()
     check(lib.drag_scale_noise_rows_bf16(_p(x), _p(noise), rows, cols, ldx, ldn, sigma, _stream()), "drag_scale_noise_rows_bf16")
+
+
+# ------------------------------------------------------------------ ViT front ends / Redux combine
+def patchify(img_u8: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, P: int, ldo: int, mean, std):
+    lib = _lib.load()
+    _need(img_u8, torch.uint8, "img")
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    check(lib.drag_patchify_u8(_p(img_u8), _p(out), B, H, W, P, ldo, m, s, _stream()), "drag_patchify_u8")
+    return out
+
+
+def scale_sum(x: torch.Tensor, scales: torch.Tensor, out: torch.Tensor, G: int, N: int, elems: int):
+    lib = _lib.load()
+    _need(x, torch.bfloat16, "x")
+    _need(scales, torch.float32, "scales")
+    check(lib.drag_scale_sum_bf16(_p(x), _p(scales), _p(out), G, N, elems, _stream()), "drag_scale_sum_bf16")
+    return out

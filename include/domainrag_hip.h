@@ -89,8 +89,9 @@ int drag_conv3x3_bf16(const drag_conv_args* args, void* stream);
  * and V -> V^T repack for the attention kernel.  Replaces FluxAttnProcessor2_0's norm_q/norm_k/
  * norm_added_q/norm_added_k + apply_rotary_emb (diffusers 0.33.1, un-vendored; call sites as above).
  *   qkv: [B, S, ld] rows, q at column 0, k at column H*128, v at column 2*H*128.
- *   rows s < s_txt use (wq_txt, wk_txt), rows >= s_txt use (wq_img, wk_img) (bf16 [128] each).
- *   rope_cos / rope_sin: f32 [S, 64].
+ *   rows s < s_txt use (wq_txt, wk_txt), rows >= s_txt use (wq_img, wk_img) (bf16 [128] each);
+ *   all four NULL = no RMSNorm.  rope_cos / rope_sin: f32 [S, 64]; both NULL = no RoPE (ViT encoders:
+ *   only the V^T repack runs).
  *   vt: [B, H, 128, s_pad] bf16, s_pad = ceil(S/64)*64, keys permuted inside each group of 16
  *       (position 8h+j  <->  key 8*(j>>2) + 4h + (j&3)) to match the MFMA accumulator layout; the
  *       pad keys are written as zeros.
@@ -132,6 +133,17 @@ int drag_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream
 /* f32 <-> bf16 casts */
 int drag_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 int drag_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+
+/* uint8 RGB [B,H,W,3] -> normalised patch rows [B*(H/P)*(W/P), ldo] bf16 ((u8/255 - mean)/std), column
+ * k = c*P*P + py*P + px (= flattened Conv2d(3, D, P, stride=P) weight), extra columns zero.  Front end of
+ * clip VisionTransformer.conv1 (retrieval/clip100_resnet_style_all_shots.py:171) and SiglipVisionEmbeddings
+ * (inside pipe_prior_redux, outpainting_updown_sampling_redux.py:1237). mean3/std3 are HOST pointers. */
+int drag_patchify_u8(const void* img, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t ldo,
+                     const float* mean3, const float* std3, void* stream);
+/* out[g] = sum_n scales[g*N+n] * x[g, n]  (bf16 ops as torch: `prompt_embeds *= scale; torch.sum(dim=0)`,
+ * FluxPriorReduxPipeline.__call__; scales is a DEVICE f32 array [G*N]; x [G, N, elems], out [G, elems]) */
+int drag_scale_sum_bf16(const void* x, const float* scales, void* out, int32_t G, int32_t N, int64_t elems,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * drag_cosine_topk_f32 — exact inner-product top-k (faiss.IndexFlatIP.add/search,

@@ -1,0 +1,53 @@
+"""End-to-end Flux-Fill composition (Redux prior -> VAE enc x2 -> DiT steps -> VAE dec) vs the CPU oracle,
+reduced depth/width, identical seeds.  Stated tolerance (BASELINE north_star): pixels within 1e-2 relative."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fill_pipeline_vs_oracle(gpu):
+    from domain_rag_amd import fill_pipeline as fp, redux, vae, vit
+    from domain_rag_amd.flux import FluxTransformerHIP
+    from domain_rag_amd.flux_params import FluxConfig, init_params
+    from oracle import fill as ofill, flux as oflux, redux as ored, vit as ovit
+
+    B, res, steps = 2, 64, 4
+    cfg = FluxConfig(in_channels=384, num_layers=1, num_single_layers=2, num_attention_heads=2, joint_attention_dim=256,
+                     pooled_projection_dim=64)
+    tp = init_params(cfg, seed=0)
+    vcfg = vae.VaeConfig(layers_per_block=1)
+    vp = vae.init_params(vcfg, seed=1)
+    vitcfg = vit.VitConfig(image_size=56, patch_size=14, hidden=192, heads=2, layers=2, intermediate=304)
+    vitp = vit.init_generic_params(vitcfg, 2)
+    rp = redux.init_redux_params(192, 256, seed=3)
+    g = torch.Generator().manual_seed(4)
+    image = torch.randint(0, 256, (B, res, res, 3), generator=g, dtype=torch.uint8)
+    mask = torch.full((B, res, res), 255, dtype=torch.uint8); mask[:, 20:41, 16:50] = 0
+    bg = torch.randint(0, 256, (B, 56, 56, 3), generator=g, dtype=torch.uint8)
+    t5 = torch.randn(24, 256, generator=g).bfloat16(); pooled = torch.randn(64, generator=g).bfloat16()
+    en = torch.randn(B, 16, res // 8, res // 8, generator=g).bfloat16()
+    mn = torch.randn(B, 16, res // 8, res // 8, generator=g).bfloat16()
+    nt = torch.randn(B, (res // 16) ** 2, 64, generator=g).bfloat16()
+
+    prior = redux.ReduxPriorHIP(vitcfg, vitp, rp, gpu)
+    fill = fp.FluxFillHIP(FluxTransformerHIP(cfg, tp, gpu), vae.FluxVaeHIP(vcfg, vp, gpu))
+    for strength in (1.0, 0.5):
+        pe, pp = prior(bg.to(gpu), t5.to(gpu), pooled.to(gpu), [1.2], [1.0], group=1)
+        out = fill(image.to(gpu), mask.to(gpu), pe, pp, guidance_scale=30.0, num_inference_steps=steps, strength=strength,
+                   enc_noise=en.to(gpu), masked_enc_noise=mn.to(gpu), noise_tokens=nt.to(gpu)).cpu()
+        # ---- oracle, fp32 yardstick and bf16 (reference dtype) runs
+        res_or = {}
+        for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
+            lat = ovit.siglip_last_hidden_state(vitp, 56, 14, 192, 2, 2, 304, ovit.normalize_u8(bg, vitcfg.mean, vitcfg.std), dt)
+            pes, pps = zip(*[ored.redux_prior(lat[i:i + 1], cast(rp), t5.to(dt), pooled.to(dt), [1.2], [1.0]) for i in range(B)])
+            ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+            u8, img = ofill.fill_pipeline(cast(tp), ocfg, cast(vp), dict(block_out=vcfg.block_out_channels, layers=1), image, mask,
+                                          torch.cat(pes), torch.cat(pps), 30.0, steps, strength, en, mn, nt, dtype=dt)
+            res_or[name] = (u8, img.float())
+        ref_u8, ref_img = res_or["f32"]
+        e_or = (res_or["bf16"][1] - ref_img).abs().max().item()      # bf16 oracle vs fp32 oracle, full scale = 1
+        e = (out.float() / 255.0 - ref_img.permute(0, 2, 3, 1)).abs().max().item()
+        assert out.shape == (B, res, res, 3) and out.dtype == torch.uint8
+        assert e < max(1e-2 + 0.5 / 255, 2.5 * e_or), (strength, e, e_or)
