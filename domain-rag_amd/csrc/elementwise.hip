@@ -289,7 +289,8 @@ extern "C" int drag_timestep_embedding_bf16(const float* t, void* out, int32_t B
 extern "C" int drag_patchify_u8(const void* img, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t ldo,
                                 const float* mean3, const float* std3, void* stream) {
   DRAG_CHECK(img && out && mean3 && std3, "drag_patchify_u8: null pointer");
-  DRAG_CHECK(B > 0 && P > 0 && H % P == 0 && W % P == 0 && ldo >= 3 * P * P, "drag_patchify_u8: bad shape");
+  // a VALID (unpadded) strided conv: trailing pixels that do not fill a patch are dropped (SigLIP 384/14 -> 27)
+  DRAG_CHECK(B > 0 && P > 0 && H >= P && W >= P && ldo >= 3 * P * P, "drag_patchify_u8: bad shape");
   PatchArgs p;
   p.img = (const uint8_t*)img; p.out = (bf16_t*)out; p.B = B; p.H = H; p.W = W; p.P = P; p.ldo = ldo;
   for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.istd[c] = 1.0f / std3[c]; }
