@@ -316,3 +316,21 @@ def scale_sum(x: torch.Tensor, scales: torch.Tensor, out: torch.Tensor, G: int, 
     _need(scales, torch.float32, "scales")
     check(lib.drag_scale_sum_bf16(_p(x), _p(scales), _p(out), G, N, elems, _stream()), "drag_scale_sum_bf16")
     return out
+
+
+def resnet_stem_style(img_f32: torch.Tensor, conv_w, bn_scale, bn_shift, eps: float = 1e-5) -> torch.Tensor:
+    """img fp32 [B,3,H,W] in [0,1] -> fp32 [B,128] (channel mean | std) of the ResNet50 stem output"""
+    lib = _lib.load()
+    _need(img_f32, torch.float32, "img")
+    B, _, H, W = img_f32.shape
+    out = torch.empty((B, 128), dtype=torch.float32, device=img_f32.device)
+    check(lib.drag_resnet_stem_style_f32(_p(img_f32), _p(conv_w), _p(bn_scale), _p(bn_shift), _p(out), B, H, W, eps,
+                                         _stream()), "drag_resnet_stem_style_f32")
+    return out
+
+
+def patchify_f32(img: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, P: int, ldo: int):
+    lib = _lib.load()
+    _need(img, torch.float32, "img")
+    check(lib.drag_patchify_f32_nchw(_p(img), _p(out), B, H, W, P, ldo, _stream()), "drag_patchify_f32_nchw")
+    return out

@@ -1,0 +1,297 @@
+"""Stage-1 retrieval on the HIP path: CLIP ViT-B/32 embedding, exact inner-product top-k over a
+corpus kept resident in HBM, ResNet50-stem style re-rank.  Objects mirror what
+``retrieval/clip100_resnet_style_all_shots.py`` calls so its call sites work unchanged:
+
+* ``load_clip("ViT-B/32", device) -> (model, preprocess)``; ``model.encode_image(x)``   (ref :206-211,:171)
+* ``IndexFlatIP(d)``, ``.add(x)``, ``.search(q, k) -> (D, I)``                            (ref :425-434)
+* ``StemStyle`` = ``ResNetEncoder`` + ``calc_mean_std``                                  (ref :51-74,:180-203)
+* ``clip_first_stage_retrieval`` / ``resnet_second_stage_rerank``                        (ref :396-497)
+
+Differences that are deliberate: the index is built once, not per query; corpus
+embedding is batched instead of batch-1 with a host sync per image; ``CUDA_VISIBLE_DEVICES`` is
+honoured.  Multi-GPU: each rank embeds a contiguous shard of the sorted path list and ONE
+all-gather (RCCL over xGMI with backend "nccl") makes the whole corpus resident on every GPU, in
+the global row order, so top-k indices equal the single-GPU result bit-for-bit.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .vit import VitConfig, VitHIP, init_generic_params, openai_clip_to_generic
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+# ------------------------------------------------------------------ host helpers (reference semantics)
+def clean_image_path(path):
+    """ref :77-86 — strip the stray ``pipeline/`` prefix, then map ../../datasets/coco -> ./coco"""
+    if isinstance(path, str):
+        if "../../pipeline/datasets" in path:
+            return path.replace("../../pipeline/datasets", "../../datasets")
+        if "../../datasets/coco" in path:
+            return path.replace("../../datasets/coco", "./coco")
+    return path
+
+
+def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
+    """contiguous shards, the first n % world ranks take one extra (split_samples_for_gpus rule,
+    outpainting_updown_sampling_redux.py:157-177)"""
+    base, rem = divmod(n, max(world, 1))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def clip_preprocess(pil_image, size: int = 224) -> torch.Tensor:
+    """openai clip ``_transform``: Resize(size, bicubic) -> CenterCrop(size) -> RGB -> ToTensor -> Normalize.
+    Host-side (PIL), exactly where the reference does it."""
+    from PIL import Image
+    img = pil_image.convert("RGB")
+    w, h = img.size
+    s = size / min(w, h)
+    nw, nh = (size, max(size, int(round(h * s)))) if w <= h else (max(size, int(round(w * s))), size)
+    img = img.resize((nw, nh), Image.BICUBIC)
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    img = img.crop((left, top, left + size, top + size))
+    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).float().div_(255.0)
+    x = (x - torch.tensor(CLIP_MEAN)) / torch.tensor(CLIP_STD)
+    return x.permute(2, 0, 1).contiguous()
+
+
+# ------------------------------------------------------------------ CLIP
+class ClipImageModel:
+    """``model`` half of ``clip.load``; only the image tower is on Domain-RAG's path."""
+
+    def __init__(self, vit: VitHIP):
+        self.visual = vit
+        self.device = vit.dev
+
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        """float [B,3,224,224] (``preprocess`` output, any device) or uint8 [B,224,224,3] -> fp32 [B,512] on device"""
+        return self.visual(image.to(self.device))
+
+    def embed_normalized(self, image: torch.Tensor) -> torch.Tensor:
+        """encode_image followed by ``x / x.norm(dim=-1, keepdim=True)`` (ref :171-172)"""
+        return ops.l2_normalize_(self.encode_image(image).clone())
+
+
+def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None = None, seed: int = 0):
+    """(model, preprocess).  ``weights``: an openai-CLIP state_dict (or a path to one saved with torch.save);
+    None -> seeded synthetic weights of the ViT-B/32 architecture (no checkpoints offline)."""
+    if name != "ViT-B/32":
+        raise ValueError("Domain-RAG uses CLIP ViT-B/32 only")
+    cfg = VitConfig.clip_vit_b32()
+    if isinstance(weights, str):
+        weights = torch.load(weights, map_location="cpu")
+    if weights is not None:
+        g = openai_clip_to_generic(weights, cfg)
+    else:
+        g = init_generic_params(cfg, seed, device=device if str(device) != "cpu" else "cpu")
+    return ClipImageModel(VitHIP(cfg, g, device)), clip_preprocess
+
+
+# ------------------------------------------------------------------ exact inner-product index
+class IndexFlatIP:
+    """faiss.IndexFlatIP look-alike with the corpus resident in HBM.  Scores follow the order pinned in
+    oracle/topk.c; ties resolve to the lower index."""
+
+    def __init__(self, d: int, device="cuda"):
+        self.d, self.device = d, torch.device(device)
+        self._chunks: list[torch.Tensor] = []
+        self._corpus: torch.Tensor | None = None
+
+    @property
+    def ntotal(self) -> int:
+        return sum(c.shape[0] for c in self._chunks) if self._corpus is None else self._corpus.shape[0]
+
+    def add(self, x) -> None:
+        t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x.float()
+        if t.dim() != 2 or t.shape[1] != self.d:
+            raise ValueError(f"expected [n, {self.d}]")
+        if self._corpus is not None:
+            self._chunks, self._corpus = [self._corpus], None
+        self._chunks.append(t.to(self.device).contiguous())
+
+    def _resident(self) -> torch.Tensor:
+        if self._corpus is None:
+            self._corpus = self._chunks[0] if len(self._chunks) == 1 else torch.cat(self._chunks, 0).contiguous()
+            self._chunks = []
+        return self._corpus
+
+    def search_device(self, q: torch.Tensor, k: int):
+        return ops.cosine_topk(self._resident(), q.to(self.device).float().contiguous(), k)
+
+    def search(self, q, k: int):
+        """(D float32 [Q,k] descending, I int64 [Q,k]) as numpy, like faiss"""
+        qt = torch.as_tensor(np.ascontiguousarray(q, dtype=np.float32))
+        D, I = self.search_device(qt, k)
+        return D.cpu().numpy(), I.cpu().numpy()
+
+
+# ------------------------------------------------------------------ ResNet stem style
+class StemStyle:
+    """ResNet50 stem (conv1+bn1+relu+maxpool, eval) + channel mean / unbiased std -> 128-d style vector."""
+
+    def __init__(self, state: dict | None = None, device="cuda", seed: int = 0):
+        dev = torch.device(device)
+        if state is None:   # seeded synthetic stem (torchvision IMAGENET1K_V1 weights are not available offline)
+            g = torch.Generator().manual_seed(seed)
+            state = {"conv1.weight": torch.randn(64, 3, 7, 7, generator=g) * math.sqrt(2.0 / 147),
+                     "bn1.weight": 1 + 0.1 * torch.randn(64, generator=g), "bn1.bias": 0.1 * torch.randn(64, generator=g),
+                     "bn1.running_mean": 0.1 * torch.randn(64, generator=g), "bn1.running_var": 1 + 0.1 * torch.rand(64, generator=g)}
+        self.state = {k: v.float() for k, v in state.items() if k.split(".")[0] in ("conv1", "bn1")}
+        scale = self.state["bn1.weight"] / torch.sqrt(self.state["bn1.running_var"] + 1e-5)
+        shift = self.state["bn1.bias"] - self.state["bn1.running_mean"] * scale
+        self.w = self.state["conv1.weight"].contiguous().to(dev)
+        self.scale, self.shift = scale.contiguous().to(dev), shift.contiguous().to(dev)
+        self.device = dev
+
+    def __call__(self, img: torch.Tensor) -> torch.Tensor:
+        """fp32 [B,3,H,W] in [0,1] -> fp32 [B,128] = cat(mean, std)   (ref :197-200)"""
+        return ops.resnet_stem_style(img.to(self.device).float().contiguous(), self.w, self.scale, self.shift, 1e-5)
+
+    def features_from_path(self, image_path: str):
+        """compute_resnet_features (ref :180-203): imread -> RGB -> resize 256x256 (bilinear) -> /255"""
+        image_path = clean_image_path(image_path)
+        try:
+            try:
+                import cv2
+                img = cv2.imread(image_path)
+                if img is None:
+                    print(f"警告：无法读取图像 {image_path}")
+                    return None
+                img = cv2.resize(cv2.cvtColor(img, cv2.COLOR_BGR2RGB), (256, 256))
+            except ImportError:   # no OpenCV in this image: PIL bilinear (resize kernels differ slightly from cv2)
+                from PIL import Image
+                img = np.asarray(Image.open(image_path).convert("RGB").resize((256, 256), Image.BILINEAR))
+            x = torch.from_numpy(np.ascontiguousarray(img)).float().permute(2, 0, 1).unsqueeze(0) / 255.0
+            return self(x)[0].cpu().numpy()
+        except Exception as e:  # reference behaviour: log and skip
+            print(f"计算ResNet特征时出错: {e}, 图像: {image_path}")
+            return None
+
+
+# ------------------------------------------------------------------ two-stage retrieval (reference call shapes)
+_index_cache: dict = {}
+
+
+def _index_for(dataset_features: dict, device) -> tuple[IndexFlatIP, list, list]:
+    """build the resident index ONCE per corpus (the reference rebuilds it for every query, :419-430)"""
+    key = tuple((name, id(f), len(f)) for name, f in dataset_features.items() if f is not None and len(f) > 0)
+    hit = _index_cache.get(key)
+    if hit is None:
+        feats = [np.asarray(f, dtype=np.float32) for _, f in dataset_features.items() if f is not None and len(f) > 0]
+        idx = IndexFlatIP(feats[0].shape[1], device)
+        idx.add(np.vstack(feats))
+        _index_cache.clear()
+        _index_cache[key] = hit = idx
+    return hit
+
+
+def clip_first_stage_retrieval(query_feature, dataset_features: dict, dataset_paths: dict, top_k: int = 100, device="cuda"):
+    """ref :396-451 — list of {similarity, image_path, source_dataset, index}, descending inner product"""
+    all_paths, all_sources = [], []
+    for name, feats in dataset_features.items():
+        if feats is not None and len(feats) > 0:
+            all_paths.extend(dataset_paths[name])
+            all_sources.extend([name] * len(dataset_paths[name]))
+    if not all_paths:
+        print("错误：没有可用的数据集特征")
+        return []
+    index = _index_for(dataset_features, device)
+    D, I = index.search(np.asarray([query_feature], dtype=np.float32), min(top_k, index.ntotal))
+    return [{"similarity": float(D[0][i]), "image_path": all_paths[idx], "source_dataset": all_sources[idx], "index": int(idx)}
+            for i, idx in enumerate(I[0]) if 0 <= idx < len(all_paths)]
+
+
+def resnet_second_stage_rerank(query_image_path, first_stage_results, stem: StemStyle, style_cache: dict | None = None):
+    """ref :454-497 — L2 distance between style vectors, stable ascending sort, similarity = 1/(1+d), rank = i+1.
+    Candidates whose image cannot be read are dropped; ``style_cache`` (path -> vector) avoids re-reading candidates."""
+    query_image_path = clean_image_path(query_image_path)
+    qf = stem.features_from_path(query_image_path)
+    if qf is None:
+        print(f"警告：无法计算查询图像的ResNet特征: {query_image_path}")
+        return first_stage_results
+    rer = []
+    for r in first_stage_results:
+        path = clean_image_path(r["image_path"])
+        f = style_cache.get(path) if style_cache is not None else None
+        if f is None:
+            f = stem.features_from_path(path)
+            if style_cache is not None and f is not None:
+                style_cache[path] = f
+        if f is not None:
+            rer.append({"clip_similarity": r["similarity"], "resnet_distance": float(np.linalg.norm(qf - f)),
+                        "image_path": path, "source_dataset": r.get("source_dataset", "unknown")})
+    rer.sort(key=lambda x: x["resnet_distance"])          # list.sort is stable, like the reference
+    return [{"rank": i + 1, "similarity": float(1.0 / (1.0 + r["resnet_distance"])), "image_path": r["image_path"],
+             "source_dataset": r["source_dataset"]} for i, r in enumerate(rer)]
+
+
+# ------------------------------------------------------------------ corpus embedding (+ all-gather)
+def embed_images(model: ClipImageModel, tensors: torch.Tensor, batch: int = 256) -> torch.Tensor:
+    """L2-normalised fp32 embeddings [n,512] on device for a stack of preprocessed images"""
+    outs = []
+    for i in range(0, tensors.shape[0], batch):
+        outs.append(model.embed_normalized(tensors[i:i + batch]))
+    return torch.cat(outs, 0) if outs else torch.empty((0, 512), device=model.device)
+
+
+def allgather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Concatenate per-rank row shards (split by ``shard_bounds``) into the global [n_total, d] matrix on every
+    rank with ONE all_gather of equal-sized (padded) shards.  Works with RCCL ("nccl", GPU tensors) and gloo."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    d = local.shape[1]
+    cap = shard_bounds(n_total, world, 0)[1]                      # largest shard
+    s, e = shard_bounds(n_total, world, rank)
+    assert local.shape[0] == e - s, "local shard does not follow shard_bounds()"
+    send = torch.zeros((cap, d), dtype=local.dtype, device=local.device)
+    send[: e - s] = local
+    recv = torch.empty((world, cap, d), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send, group=group) if hasattr(dist, "all_gather_into_tensor") and local.is_cuda \
+        else dist.all_gather(list(recv.unbind(0)), send, group=group)
+    parts = [recv[r, : shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0]] for r in range(world)]
+    return torch.cat(parts, 0)
+
+
+def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list[str], batch: int = 256):
+    """compute_coco_clip_features (ref :236-298), batched and rank-sharded.  Returns (features float32 [n,512]
+    numpy in path order, valid_paths).  Unreadable images are skipped like the reference (:290-292)."""
+    import torch.distributed as dist
+    from PIL import Image
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    s, e = shard_bounds(len(image_paths), world, rank)
+    feats = torch.zeros((e - s, 512), dtype=torch.float32, device=model.device)
+    ok = torch.zeros((e - s, 1), dtype=torch.float32, device=model.device)
+    buf, idxs = [], []
+
+    def flush():
+        if buf:
+            emb = model.embed_normalized(torch.stack(buf))
+            ii = torch.tensor(idxs, device=model.device)
+            feats[ii] = emb
+            ok[ii] = 1.0
+            buf.clear(); idxs.clear()
+
+    for j, p in enumerate(image_paths[s:e]):
+        try:
+            buf.append(preprocess(Image.open(clean_image_path(p)).convert("RGB")))
+            idxs.append(j)
+        except Exception as ex:
+            print(f"处理图像 {p} 时出错: {ex}")
+        if len(buf) == batch:
+            flush()
+    flush()
+    allf = allgather_rows(torch.cat([feats, ok], 1), len(image_paths))
+    keep = allf[:, 512] > 0.5
+    valid = [p for p, k in zip(image_paths, keep.cpu().tolist()) if k]
+    return allf[keep][:, :512].cpu().numpy(), valid

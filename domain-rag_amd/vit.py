@@ -189,7 +189,14 @@ class VitHIP:
         ws = self._workspace(B)
         x, nrm, qkv, vt, att, hid = ws["x"], ws["nrm"], ws["qkv"], ws["vt"], ws["att"], ws["hid"]
         S = cfg.image_size
-        ops.patchify(img_u8, ws["patches"], B, S, S, cfg.patch_size, self.Kp, cfg.mean, cfg.std)
+        if img_u8.dtype == torch.uint8:
+            if tuple(img_u8.shape[1:]) != (S, S, 3):
+                raise ValueError(f"expected uint8 [B,{S},{S},3]")
+            ops.patchify(img_u8.contiguous(), ws["patches"], B, S, S, cfg.patch_size, self.Kp, cfg.mean, cfg.std)
+        else:   # already normalised float NCHW (e.g. clip `preprocess` output)
+            if tuple(img_u8.shape[1:]) != (3, S, S):
+                raise ValueError(f"expected float [B,3,{S},{S}]")
+            ops.patchify_f32(img_u8.float().contiguous(), ws["patches"], B, S, S, cfg.patch_size, self.Kp)
         if c0:
             x.copy_(ws["tmpl"])               # device memcpy: row 0 of every image = cls + pos[0]
         ops.gemm(ws["patches"], self.w_patch, out=x.view(-1)[c0 * D:], bias=self.b_patch, M=B * nP, lda=self.Kp,

@@ -1,0 +1,76 @@
+"""Stage-1 retrieval objects on the HIP path: CLIP encode_image, resident IndexFlatIP, stem style, two-stage flow."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stem_style_vs_oracle(gpu):
+    from domain_rag_amd.retrieval import StemStyle
+    from oracle import stem as ostem
+    st = StemStyle(device=gpu, seed=3)
+    x = torch.rand(3, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    got = st(x).cpu()
+    ref = ostem.style_vector(x, st.state)
+    assert torch.allclose(got, ref, rtol=2e-4, atol=2e-5), (got - ref).abs().max()
+    # the verified reference identity: arange(96).reshape(2,3,4,4) -> mean 7.5/23.5/39.5, std 4.7610
+    m, s = ostem.calc_mean_std(torch.arange(96.0).reshape(2, 3, 4, 4))
+    assert torch.allclose(m[0], torch.tensor([7.5, 23.5, 39.5])) and abs(s[0, 0].item() - 4.7610) < 1e-3
+    x2 = torch.rand(1, 3, 96, 64, generator=torch.Generator().manual_seed(1))
+    assert torch.allclose(st(x2).cpu(), ostem.style_vector(x2, st.state), rtol=2e-4, atol=2e-5)
+
+
+def test_clip_full_size_and_index(gpu):
+    """real ViT-B/32 shape: float-preprocess path == uint8 path; embeddings vs transformers oracle; top-k on them"""
+    from domain_rag_amd import retrieval as R
+    from domain_rag_amd.vit import VitConfig, init_generic_params, VitHIP
+    from oracle import retrieval as oret, vit as ov
+    cfg = VitConfig.clip_vit_b32()
+    g = init_generic_params(cfg, 5)
+    model = R.ClipImageModel(VitHIP(cfg, g, gpu))
+    img = (torch.rand(6, 224, 224, 3, generator=torch.Generator().manual_seed(2)) * 255).to(torch.uint8)
+    px = ov.normalize_u8(img, cfg.mean, cfg.std)
+    e_u8 = model.encode_image(img).cpu()
+    e_f = model.encode_image(px).cpu()
+    assert torch.allclose(e_u8, e_f, atol=2e-2 * e_u8.abs().max().item())
+    ref = ov.clip_image_embeds(g, 224, 32, 768, 12, 12, 3072, 512, px, torch.float32)
+    rel = ((e_u8 - ref).abs().max() / ref.abs().max()).item()
+    assert rel < 3e-2, rel
+    emb = model.embed_normalized(img).cpu()
+    assert torch.allclose(emb.norm(dim=-1), torch.ones(6), atol=1e-5)
+    refn = ref / ref.norm(dim=-1, keepdim=True)
+    assert (emb * refn).sum(-1).min().item() > 0.999      # cosine between HIP and oracle embeddings
+    # resident index: add in two chunks, search == oracle on the same features, bit-exact
+    rng = np.random.default_rng(0)
+    feats = rng.standard_normal((3000, 512)).astype(np.float32)
+    feats /= np.linalg.norm(feats, axis=1, keepdims=True)
+    idx = R.IndexFlatIP(512, gpu)
+    idx.add(feats[:1000]); idx.add(feats[1000:])
+    assert idx.ntotal == 3000
+    D, I = idx.search(feats[:3] + 0.01, 100)
+    Dr, Ir = oret.cosine_topk(feats, feats[:3] + 0.01, 100)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_two_stage_flow_on_files(gpu, tmp_path):
+    from PIL import Image
+    from domain_rag_amd import retrieval as R
+    rng = np.random.default_rng(1)
+    paths = []
+    for i in range(12):
+        p = tmp_path / f"img{i:02d}.jpg"
+        Image.fromarray(rng.integers(0, 256, (80, 100, 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+    model, pre = R.load_clip("ViT-B/32", gpu, seed=1)
+    feats, valid = R.compute_corpus_features(model, pre, paths + [str(tmp_path / "missing.jpg")], batch=5)
+    assert valid == paths and feats.shape == (12, 512) and feats.dtype == np.float32
+    q = feats[4]
+    first = R.clip_first_stage_retrieval(q, {"coco": feats}, {"coco": valid}, top_k=100, device=gpu)
+    assert len(first) == 12 and first[0]["index"] == 4 and first[0]["source_dataset"] == "coco"
+    assert all(first[i]["similarity"] >= first[i + 1]["similarity"] for i in range(11))
+    stem = R.StemStyle(device=gpu)
+    final = R.resnet_second_stage_rerank(paths[4], first, stem, style_cache={})
+    assert [r["rank"] for r in final] == list(range(1, 13))
+    assert final[0]["image_path"] == paths[4] and abs(final[0]["similarity"] - 1.0) < 1e-6
+    assert set(final[0]) == {"rank", "similarity", "image_path", "source_dataset"}

@@ -1,0 +1,95 @@
+"""Host logic (resolution policy, masks, sharding, manifests, path cleaning) pinned against goldens captured from
+the IMPORTED reference (tests/golden/host_logic.json <- tests/golden/make_host_goldens.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_logic.json")))
+
+
+def test_resolution_policy():
+    from PIL import Image
+    from domain_rag_amd import hostlogic as H
+    for c in GOLD["process_image_resolution"]:
+        if c.get("error"):
+            with pytest.raises(ValueError):
+                H.resolution_plan(c["w"], c["h"], c["min"], 2800)
+            continue
+        nw, nh, up, down, wu, wd = H.resolution_plan(c["w"], c["h"], c["min"], 2800)
+        assert [nw, nh] == c["out"] and up == c["up"] and down == c["down"] and wu == c["wu"] and wd == c["wd"], c
+        img, up2, down2, wu2, wd2 = H.process_image_resolution(Image.new("RGB", (c["w"], c["h"])), c["min"], 2800)
+        assert list(img.size) == c["out"] and (up2, down2, wu2, wd2) == (up, down, wu, wd)
+    for c in GOLD["downscale_image"]:
+        assert list(H.downscale_image(Image.new("RGB", (c["w"], c["h"])), c["s"]).size) == c["out"]
+    # SURVEY-verified identities
+    assert H.resolution_plan(500, 375)[:2] == (1365, 1024) and H.resolution_plan(4000, 3000)[:2] == (2800, 2100)
+
+
+def test_outpaint_mask_bitmaps():
+    from PIL import Image
+    from domain_rag_amd import hostlogic as H
+    for c in GOLD["generate_outpaint_mask"]:
+        a = H.outpaint_mask_array(c["W"], c["H"], c["bboxes"])
+        assert a.shape == (c["H"], c["W"]) and int((a == 255).sum()) == c["white"], c
+        assert hashlib.sha256(a.tobytes()).hexdigest() == c["sha256"], c
+        m, bbs = H.generate_outpaint_mask(Image.new("RGB", (c["W"], c["H"])), c["bboxes"])
+        assert m.mode == c["mode"] and np.array_equal(np.asarray(m), a) and bbs == c["bboxes"]
+    a = H.outpaint_mask_array(64, 48, [[10, 10, 20, 15]])       # inclusive rectangle: 21 x 16 px kept
+    assert abs((a == 255).mean() - 0.890625) < 1e-12
+
+
+def test_sharding_and_manifests():
+    from domain_rag_amd import hostlogic as H
+    from domain_rag_amd.retrieval import shard_bounds
+    for c in GOLD["split_samples_for_gpus"]:
+        chunks = H.split_samples_for_gpus(list(range(c["n"])), c["g"])
+        assert [len(x) for x in chunks] == c["sizes"] and [x[0] if x else None for x in chunks] == c["first"]
+        if c["g"] > 1:   # the rank-local form used by the data-parallel drivers agrees with it
+            assert [list(range(*shard_bounds(c["n"], c["g"], r))) for r in range(c["g"])] == chunks
+    assert H.split_samples_for_gpus(list(range(10)), 4) == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    gj = GOLD["generate_formatted_result_json"]
+    out = H.formatted_result_json("DS", gj["logs"], gj["shot"], process_id="golden")
+    out.pop("timestamp")
+    assert out == gj["out"]
+    mg = GOLD["merge_gpu_results"]
+    assert H.merge_gpu_results("DS", mg["in"], 1) == mg["out"]
+    assert H.create_gpu_process_id("7", 3) == GOLD["create_gpu_process_id"]
+
+
+def test_tables_and_paths():
+    from domain_rag_amd import hostlogic as H
+    from domain_rag_amd.retrieval import clean_image_path
+    t = GOLD["tables"]
+    assert H.STRENGTH == t["strength"] and H.GUIDANCE_SCALE == t["guidance"] and H.IMAGE_PROMPT_SCALE == t["image_prompt_scale"]
+    assert H.UPSCALE_DIMENSION == t["upscale"] and H.REDUX_PROMPT == t["redux_prompt"]
+    assert (H.DEFAULT_STRENGTH, H.DEFAULT_GUIDANCE, H.MIN_DIMENSION, H.MAX_DIMENSION) == (
+        t["default_strength"], t["default_guidance"], t["min_dim"], t["max_dim"])
+    for c in GOLD["clean_image_path"]:
+        assert clean_image_path(c["in"]) == c["out"]
+
+
+def test_bbox_helpers():
+    from domain_rag_amd import hostlogic as H
+    assert H.scale_bboxes([[10, 20, 30, 40]], 2.7306666, 1.0, True, False) == [[27, 54, 81, 109]]
+    assert H.scale_bboxes([[10, 20, 30, 40]], 1.0, 0.7, False, True) == [[7, 14, 21, 28]]
+    assert H.scale_bboxes([[1.5, 2, 3, 4]], 1.0, 1.0, False, False) == [[1.5, 2, 3, 4]]
+    ann = {"images": [{"id": 7, "file_name": "abc_001.jpg"}, {"id": "8", "file_name": "zzz.png"}],
+           "annotations": [{"image_id": "7", "bbox": [1, 2, 3, 4], "category_id": 2}, {"image_id": 7, "bbox": [5, 6, 7, 8], "category_id": 9},
+                           {"image_id": 8, "bbox": [0, 0, 1, 1], "category_id": 2}],
+           "categories": [{"id": 2, "name": "beetle"}]}
+    info, boxes, cats = H.lookup_sample_annotations(ann, "abc_001")
+    assert info["id"] == 7 and boxes == [[1, 2, 3, 4], [5, 6, 7, 8]] and cats == ["beetle", "unknown"]
+    assert H.lookup_sample_annotations(ann, "abc")[0]["id"] == 7          # substring fallback
+    assert H.lookup_sample_annotations(ann, "nope") is None
+    assert H.crop_box([-3, 5.9, 1000, "2"], 100, 50) == (0, 5, 100, 7)
+
+
+def test_oracle_stem_identity():
+    """calc_mean_std of arange(96).reshape(2,3,4,4) — the value the reference itself produces"""
+    import torch
+    from oracle import stem
+    m, s = stem.calc_mean_std(torch.arange(96.0).reshape(2, 3, 4, 4))
+    assert np.allclose(m.flatten().numpy(), GOLD["calc_mean_std"]["mean"]) and np.allclose(s.flatten().numpy(), GOLD["calc_mean_std"]["std"])
