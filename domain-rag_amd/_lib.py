@@ -53,7 +53,7 @@ SIGNATURES = {
     "drag_groupnorm_workspace_bytes": (c_int64, [c_int] * 4),
     "drag_groupnorm_silu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_float, c_void_p, c_void_p]),
     "drag_pad_copy_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
-    "drag_softmax_rows_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "drag_softmax_rows_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "drag_unpack_latents_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_float, c_void_p]),
     "drag_sample_pack_latents_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_float, c_float, c_void_p]),
     "drag_image_preprocess_u8": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),

@@ -1,0 +1,232 @@
+"""Stage 1 — drop-in for ``retrieval/clip100_resnet_style_all_shots.py`` (flags :966-998, outputs :866-895,:1088-1097).
+
+    python -m domain_rag_amd.cli.stage1_retrieval --datasets ArTaxOr --shots 1 5 [--coco-dir ./coco] ...
+
+Same flags, cache files and JSON schemas; differences are the deliberate ones of SURVEY §9 (the environment's
+CUDA_VISIBLE_DEVICES is honoured, --clip-top-k is live, the index is built once, corpus embedding is batched and — under
+torch.distributed.run — sharded across ranks with one all-gather).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import retrieval as R
+
+RESULTS_DIR = "./retrieval_results"
+LAMAINPAINT_DIR = "../lamainpaint"
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="CLIP+ResNet图像检索 - 多shot版本 (MI355X)")
+    p.add_argument("--datasets", type=str, nargs="+", default=["ArTaxOr", "DIOR", "FISH", "NEU-DET", "UODD", "clipart1k"])
+    p.add_argument("--shots", type=int, nargs="+", default=[1, 5, 10])
+    p.add_argument("--coco-dir", type=str, default="./coco")
+    p.add_argument("--mini-imagenet-dir", type=str, default="./miniimagenet")
+    p.add_argument("--dataset-source", type=str, choices=["coco", "mini-imagenet", "both"], default="coco")
+    p.add_argument("--clip-top-k", type=int, default=100)
+    p.add_argument("--output-dir", type=str, default=None)
+    p.add_argument("--gpu-id", type=int, default=0)
+    p.add_argument("--pretrained-coco-features", type=str, default="./coco_embeddings_global.pt")
+    p.add_argument("--pretrained-coco-paths", type=str, default=None)
+    p.add_argument("--pretrained-mini-imagenet-features", type=str, default=None)
+    p.add_argument("--pretrained-mini-imagenet-paths", type=str, default=None)
+    p.add_argument("--global-features", action="store_true")
+    p.add_argument("--force-recompute", action="store_true")
+    p.add_argument("--lamainpaint-dir", type=str, default=None)
+    p.add_argument("--force-recompute-inpainted", action="store_true")
+    # additions (not in the reference)
+    p.add_argument("--clip-weights", type=str, default=None, help="openai CLIP ViT-B/32 state_dict (.pt); default: synthetic")
+    p.add_argument("--resnet-weights", type=str, default=None, help="torchvision resnet50 state_dict (.pt); default: synthetic")
+    p.add_argument("--embed-batch", type=int, default=256)
+    return p
+
+
+def list_corpus_images(root: str, subdirs) -> list[str]:
+    """ref :242-258: first existing sub-directory, then **/*.jpg, jpeg, png.  Sorted for a deterministic global row
+    order (the reference takes filesystem order; sorting is required for the sharded embedding)."""
+    base = None
+    for s in subdirs:
+        if os.path.isdir(os.path.join(root, s)):
+            base = os.path.join(root, s)
+            break
+    if base is None:
+        base = root if os.path.isdir(root) else None
+    if base is None:
+        return []
+    out = []
+    for ext in ("jpg", "jpeg", "png"):
+        out += sorted(str(p) for p in Path(base).glob(f"**/*.{ext}"))
+    return out
+
+
+def load_feature_file(feat_path, paths_path, device):
+    """ref :536-610: .pt dict {embeddings|features, image_paths|paths} or .npy + json list"""
+    if feat_path.endswith(".pt"):
+        d = torch.load(feat_path, map_location="cpu", weights_only=False)
+        feats = d.get("embeddings", d.get("features"))
+        paths = d.get("image_paths", d.get("paths"))
+        if feats is None or paths is None:
+            return None, None
+        feats = feats.float().cpu().numpy() if torch.is_tensor(feats) else np.asarray(feats, dtype=np.float32)
+        return feats, [R.clean_image_path(p) for p in paths]
+    if feat_path.endswith(".npy") and paths_path and os.path.exists(paths_path):
+        with open(paths_path) as f:
+            return np.load(feat_path), [R.clean_image_path(p) for p in json.load(f)]
+    return None, None
+
+
+def load_or_compute_features(args, tag, root, subdirs, pre_feats, pre_paths, model, preprocess, results_dir, rank0=True):
+    """ref :500-655 cache resolution order, then compute + save ``<tag>_clip_features.npy`` / ``<tag>_image_paths.json``"""
+    cache_f = os.path.join(results_dir, f"{tag}_clip_features.npy")
+    cache_p = os.path.join(results_dir, f"{tag}_image_paths.json")
+    if not args.force_recompute:
+        if pre_feats and os.path.exists(pre_feats):
+            f, p = load_feature_file(pre_feats, pre_paths, model.device)
+            if f is not None:
+                print(f"成功加载 {len(f)} 个预提取特征: {pre_feats}")
+                return f, p
+        if os.path.exists(cache_f) and os.path.exists(cache_p):
+            with open(cache_p) as fh:
+                print(f"从缓存加载特征: {cache_f}")
+                return np.load(cache_f), [R.clean_image_path(p) for p in json.load(fh)]
+    paths = list_corpus_images(root, ("images", "train2017", "val2017", "train"))
+    if not paths:
+        print(f"错误：找不到图像: {root}")
+        return None, None
+    feats, valid = R.compute_corpus_features(model, preprocess, paths, batch=args.embed_batch)
+    if rank0 and len(feats):
+        np.save(cache_f, feats)
+        with open(cache_p, "w") as fh:
+            json.dump(valid, fh)
+    return feats, valid
+
+
+def get_inpainted_images(lama_dir, dataset, shot):
+    """ref :89-158: ``<lama>/<ds>/<k>_shot/*.jpg``; category = sample id unless category_mapping.json says otherwise.
+    Accepts LaMa's ``safe`` spelling (``-`` -> ``_``) as well."""
+    shot_dir = os.path.join(lama_dir, dataset, f"{shot}_shot")
+    if not os.path.isdir(shot_dir):
+        alt = os.path.join(lama_dir, dataset.replace("-", "_"), f"{shot}_shot")
+        shot_dir = alt if os.path.isdir(alt) else shot_dir
+    files = sorted(glob.glob(os.path.join(shot_dir, "*.jpg")))
+    mapping = {}
+    mp = os.path.join(shot_dir, "category_mapping.json")
+    if os.path.exists(mp):
+        try:
+            with open(mp) as f:
+                mapping = json.load(f)
+        except Exception as e:
+            print(f"加载类别映射文件时出错: {e}")
+    s2i = {os.path.splitext(os.path.basename(p))[0]: p for p in files}
+    return s2i, {s: mapping.get(s, s) for s in s2i}
+
+
+def retrieve_dataset(args, dataset, shot, model, preprocess, stem, feats, paths, results_dir, lama_dir, style_cache):
+    """ref :773-898"""
+    from PIL import Image
+    s2i, s2c = get_inpainted_images(lama_dir, dataset, shot)
+    if not s2i:
+        return None
+    cat2s: dict = {}
+    for s, c in s2c.items():
+        cat2s.setdefault(c, []).append(s)
+    # query embeddings in one batch; also the cache files of the reference (:794-822)
+    ids = list(s2i)
+    tens, ok_ids = [], []
+    for s in ids:
+        try:
+            tens.append(preprocess(Image.open(R.clean_image_path(s2i[s])).convert("RGB")))
+            ok_ids.append(s)
+        except Exception as e:
+            print(f"提取CLIP特征时出错: {e}, 图像: {s2i[s]}")
+    qf = R.embed_images(model, torch.stack(tens), args.embed_batch).cpu().numpy() if tens else np.zeros((0, 512), np.float32)
+    np.save(os.path.join(results_dir, f"{dataset}_{shot}_shot_inpainted_clip_features.npy"), qf)
+    with open(os.path.join(results_dir, f"{dataset}_{shot}_shot_inpainted_image_paths.json"), "w") as f:
+        json.dump([s2i[s] for s in ok_ids], f)
+    qmap = {s: qf[i] for i, s in enumerate(ok_ids)}
+    all_results: dict = {}
+    for cat, samples in cat2s.items():
+        cat_res = []
+        for s in samples:
+            if s not in qmap:
+                continue
+            first = R.clip_first_stage_retrieval(qmap[s], feats, paths, top_k=args.clip_top_k, device=model.device)
+            if not first:
+                continue
+            final = R.resnet_second_stage_rerank(s2i[s], first, stem, style_cache)
+            if not final:
+                continue
+            with open(os.path.join(results_dir, f"{dataset}_{shot}_shot_{cat}_{s}_retrieval_results.json"), "w", encoding="utf-8") as f:
+                json.dump(final, f, indent=2, ensure_ascii=False)
+            cat_res.append({"sample_id": s, "image_path": s2i[s], "category": cat, "similar_images": final})
+        if cat_res:
+            all_results.setdefault(cat, []).extend(cat_res)
+    with open(os.path.join(results_dir, f"{dataset}_{shot}_shot_retrieval_results.json"), "w", encoding="utf-8") as f:
+        json.dump(all_results, f, indent=2, ensure_ascii=False)
+    return all_results
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    results_dir = args.output_dir or RESULTS_DIR
+    lama_dir = args.lamainpaint_dir or LAMAINPAINT_DIR
+    os.makedirs(results_dir, exist_ok=True)
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(args.gpu_id)))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=device)
+    rank = dist.get_rank() if world > 1 else 0
+    print(f"使用设备: {device}")
+    model, preprocess = R.load_clip("ViT-B/32", device, weights=args.clip_weights)
+    stem = R.StemStyle(torch.load(args.resnet_weights, map_location="cpu") if args.resnet_weights else None, device)
+    feats, paths = {}, {}
+    if args.dataset_source in ("coco", "both"):
+        f, p = load_or_compute_features(args, "coco", args.coco_dir, None, args.pretrained_coco_features, args.pretrained_coco_paths,
+                                        model, preprocess, results_dir, rank == 0)
+        if f is not None and len(f):
+            feats["coco"], paths["coco"] = f, p
+    if args.dataset_source in ("mini-imagenet", "both"):
+        f, p = load_or_compute_features(args, "mini_imagenet", args.mini_imagenet_dir, None, args.pretrained_mini_imagenet_features,
+                                        args.pretrained_mini_imagenet_paths, model, preprocess, results_dir, rank == 0)
+        if f is not None and len(f):
+            feats["mini-imagenet"], paths["mini-imagenet"] = f, p
+    if not feats:
+        print("错误：没有可用的数据集特征，无法进行检索")
+        return 1
+    all_shots: dict = {}
+    style_cache: dict = {}
+    if rank == 0:   # queries are few; the corpus embedding above is the sharded part
+        for ds in args.datasets:
+            all_shots[ds] = {}
+            for shot in args.shots:
+                print(f"\n====== 处理数据集: {ds}, {shot}_shot ======")
+                res = retrieve_dataset(args, ds, shot, model, preprocess, stem, feats, paths, results_dir, lama_dir, style_cache)
+                if res:
+                    all_shots[ds][f"{shot}_shot"] = res
+                else:
+                    print(f"跳过数据集 {ds} 的 {shot}_shot")
+        if any(all_shots.values()):
+            out = os.path.join(results_dir, "all_shots_retrieval_results.json")
+            with open(out, "w", encoding="utf-8") as f:
+                json.dump(all_shots, f, indent=2, ensure_ascii=False)
+            print(f"所有数据集和所有shot的检索结果已合并保存到 {out}")
+        else:
+            print("没有成功检索任何数据集")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,212 @@
+"""Stage 2 — drop-in for ``batch_generate_flux_kshot.py`` (flags :33-45; outputs :798-802,:477-519).
+
+    python -m domain_rag_amd.cli.stage2_generate --dataset ArTaxOr --shots 1 --retrieval_results_dir ./retrieval/retrieval_results
+
+For every k-shot sample: ranks 1..5 of ``all_shots_retrieval_results.json`` -> Redux prior over [retrieved, target]
+with scales [0.8, 1.0] -> FLUX.1-dev 1024x1024, 50 steps, guidance 2.5, seed 0 -> ``generated_image_rank{r}.png`` plus
+the side files stage 3 and humans read.  Under torch.distributed.run the (sample, rank) units are sharded with the
+reference's contiguous rule; no collective is needed.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import shutil
+from datetime import datetime
+
+import torch
+
+from ..engine import Engine, generator_noise, pack_noise
+from ..retrieval import shard_bounds
+
+COCO_IMAGE_SCALE, TARGET_IMAGE_SCALE, COCO_TEXT_SCALE, TARGET_TEXT_SCALE = 0.8, 1.0, 1.0, 1.0
+PROMPT = ""
+GUIDANCE, STEPS, SIZE, SEED = 2.5, 50, 1024, 0
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="批量生成Flux k-shot图像 (MI355X)")
+    p.add_argument("--dataset", type=str, default=None)
+    p.add_argument("--shots", nargs="+", type=int, default=None)
+    p.add_argument("--output_dir", type=str, default="result")
+    p.add_argument("--database", type=str, default="coco", choices=["coco", "miniimagenet", "neudet"])
+    p.add_argument("--retrieval_results_dir", type=str, default="./retrieval/retrieval_results")
+    p.add_argument("--dataset_group", type=str, default=None, choices=["dataset1", "dataset2", "dataset3", "dataset4"])
+    # additions
+    p.add_argument("--lamainpaint_dir", type=str, default="./lamainpaint")
+    p.add_argument("--model_root", type=str, default="./model")
+    p.add_argument("--coco_dir", type=str, default="./retrieval/coco")
+    p.add_argument("--synthetic-weights", action="store_true")
+    p.add_argument("--tiny", action="store_true", help="test hook: tiny architectures, small images")
+    p.add_argument("--num_inference_steps", type=int, default=STEPS)
+    p.add_argument("--size", type=int, default=SIZE)
+    p.add_argument("--fallback-seed", type=int, default=None, help="seed the random-COCO fallback (reference: unseeded)")
+    return p
+
+
+DATASET_GROUPS = {"dataset1": ["ArTaxOr", "clipart1k"], "dataset2": ["DIOR", "FISH"], "dataset3": ["NEU-DET", "UODD"],
+                  "dataset4": ["NWPU_VHR_10", "Camouflage"]}
+
+
+def resolve_path(path: str, roots) -> str | None:
+    """get_correct_image_path (:1332-1406) in spirit: try the path as written, then relative to the known roots"""
+    if os.path.exists(path):
+        return path
+    for r in roots:
+        for cand in (os.path.join(r, path), os.path.join(r, os.path.basename(path)),
+                     os.path.join(r, *path.replace("\\", "/").split("/")[-2:])):
+            if os.path.exists(cand):
+                return cand
+    return None
+
+
+def top5_from_json(results: dict, dataset: str, shot: int, sample: str, coco_dir: str, rng: random.Random):
+    """get_top5_similar_images_from_json (:1105-1330): results[ds]["<k>_shot"][sample] -> first entry ->
+    similar_images with rank <= 5, sorted by rank -> [(similarity, path, rank)].  Missing sample: 5 random corpus
+    images with similarities 1.0, 0.9, ... (NEU-DET raises instead)."""
+    node = results.get(dataset, {})
+    node = node.get(f"{shot}_shot", node)
+    entry = node.get(sample)
+    if entry is None:
+        for k in node:                       # sample-name variants (with / without extension, case)
+            if os.path.splitext(k)[0].lower() == sample.lower():
+                entry = node[k]
+                break
+    if entry is None:
+        if dataset == "NEU-DET":
+            raise ValueError(f"无法在NEU-DET数据集中找到样本 {sample} 或其类别")
+        print(f"将为样本 {sample} 使用随机COCO图像")
+        pool = []
+        for root, _, files in os.walk(coco_dir):
+            pool += [os.path.join(root, f) for f in files if f.lower().endswith((".jpg", ".jpeg", ".png"))]
+        pool.sort()
+        return [(1.0 - i * 0.1, p, i + 1) for i, p in enumerate(rng.sample(pool, min(5, len(pool))))]
+    if isinstance(entry, list):
+        entry = entry[0] if entry else {}
+    sims = [s for s in entry.get("similar_images", []) if int(s.get("rank", 99)) <= 5]
+    sims.sort(key=lambda s: s["rank"])
+    return [(float(s.get("similarity", 0.0)), s["image_path"], int(s["rank"])) for s in sims]
+
+
+def generate_one(engine: Engine, ref_path, target_path, out_path, rank, similarity, args, database):
+    """generate_image (:439-524)"""
+    from PIL import Image
+    try:
+        ref_img, tgt_img = Image.open(ref_path).convert("RGB"), Image.open(target_path).convert("RGB")
+        w, h = tgt_img.size
+        w, h = max((w // 16) * 16, 64), max((h // 16) * 16, 64)        # computed and recorded, not used (:447-456,:470-471)
+        pe, pp = engine.prior_embeds([ref_img, tgt_img], PROMPT, [COCO_IMAGE_SCALE, TARGET_IMAGE_SCALE],
+                                     [COCO_TEXT_SCALE, TARGET_TEXT_SCALE])
+        noise = pack_noise(generator_noise(SEED, 1, args.size, args.size, 1)[0])
+        img = engine.pipe(pe, pp, height=args.size, width=args.size, guidance_scale=GUIDANCE,
+                          num_inference_steps=args.num_inference_steps, noise_tokens=noise)
+        os.makedirs(os.path.dirname(out_path), exist_ok=True)
+        Image.fromarray(img[0].cpu().numpy()).save(out_path)
+        d = os.path.dirname(out_path)
+        pf = os.path.join(d, "params.txt")
+        if not os.path.exists(pf):
+            with open(pf, "w") as f:
+                f.write(f"数据库类型: {database}\n参考图像权重: {COCO_IMAGE_SCALE}\n目标图像权重: {TARGET_IMAGE_SCALE}\n"
+                        f"参考文本权重: {COCO_TEXT_SCALE}\n目标文本权重: {TARGET_TEXT_SCALE}\n提示词: {PROMPT}\n指导比例: {GUIDANCE}\n"
+                        f"推理步数: {args.num_inference_steps}\n生成图像尺寸: {w}x{h}\n原始图像尺寸: {tgt_img.size[0]}x{tgt_img.size[1]}\n")
+        rs = f"rank{rank}" if rank is not None else ""
+        ss = f"_sim{similarity:.4f}" if similarity is not None else ""
+        with open(os.path.join(d, f"ref_info{rs}{ss}.txt"), "w") as f:
+            f.write(f"数据库类型: {database}\n参考图像: {ref_path}\n目标图像: {target_path}\n生成图像尺寸: {w}x{h}\n"
+                    f"原始图像尺寸: {tgt_img.size[0]}x{tgt_img.size[1]}\n")
+            if rank is not None:
+                f.write(f"排名: {rank}\n")
+            if similarity is not None:
+                f.write(f"相似度: {similarity}\n")
+        tgt_out = os.path.join(d, "target_input.png")
+        if not os.path.exists(tgt_out):
+            shutil.copy(target_path, tgt_out)
+        shutil.copy(ref_path, os.path.join(d, f"ref_input{rs}.jpg"))
+        return True
+    except Exception as e:   # reference convention: log, continue
+        print(f"生成图像时出错: {str(e)}")
+        return False
+
+
+def process_dataset(engine, results, dataset, shot, args, rank, world):
+    """process_kshot_dataset_with_retrieval (:766-1058)"""
+    shot_dir = os.path.join(args.lamainpaint_dir, dataset, f"{shot}_shot")
+    if not os.path.isdir(shot_dir):
+        alt = os.path.join(args.lamainpaint_dir, dataset.replace("-", "_"), f"{shot}_shot")
+        if not os.path.isdir(alt):
+            print(f"错误：找不到k-shot目录 {shot_dir}")
+            return 0, 0
+        shot_dir = alt
+    names = sorted(os.path.splitext(f)[0] for f in os.listdir(shot_dir) if f.endswith(".jpg"))
+    if not names:
+        print(f"跳过数据集 {dataset} {shot}-shot，因为找不到样本")
+        return 0, 0
+    result_dir = f"{args.output_dir}/{dataset}_{shot}shot_retrieval"
+    ts = os.environ.get("DRAG_TIMESTAMP") or datetime.now().strftime("%Y%m%d_%H%M%S")
+    base = os.path.join(result_dir, f"results_coco_{COCO_IMAGE_SCALE}_target_{TARGET_IMAGE_SCALE}_cocotext_{COCO_TEXT_SCALE}"
+                                    f"_targettext_{TARGET_TEXT_SCALE}_{ts}")
+    os.makedirs(base, exist_ok=True)
+    if rank == 0:
+        with open(os.path.join(base, "batch_params.txt"), "w") as f:
+            f.write(f"数据集: {dataset} ({shot}-shot，使用检索结果)\nCOCO图像权重: {COCO_IMAGE_SCALE}\n目标图像权重: {TARGET_IMAGE_SCALE}\n"
+                    f"COCO文本权重: {COCO_TEXT_SCALE}\n目标文本权重: {TARGET_TEXT_SCALE}\n提示词: {PROMPT}\n指导比例: {GUIDANCE}\n"
+                    f"推理步数: {args.num_inference_steps}\n处理样本数: {len(names)}\n")
+    rng = random.Random(args.fallback_seed)
+    s, e = shard_bounds(len(names), world, rank)
+    ok = bad = 0
+    for name in names[s:e]:
+        target = os.path.join(shot_dir, name + ".jpg")
+        sdir = os.path.join(base, name)
+        os.makedirs(sdir, exist_ok=True)
+        try:
+            top = top5_from_json(results, dataset, shot, name, args.coco_dir, rng)
+        except ValueError as ex:
+            with open(os.path.join(sdir, "error.txt"), "w") as f:
+                f.write(str(ex))
+            bad += 1
+            continue
+        for sim, path, r in top:
+            real = resolve_path(path, [args.coco_dir, os.path.dirname(args.retrieval_results_dir), "."])
+            if real is None:
+                print(f"警告：找不到参考图像 {path}")
+                bad += 1
+                continue
+            if generate_one(engine, real, target, os.path.join(sdir, f"generated_image_rank{r}.png"), r, sim, args, args.database):
+                ok += 1
+            else:
+                bad += 1
+    return ok, bad
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if args.tiny and args.size == SIZE:
+        args.size = 64
+    rf = os.path.join(args.retrieval_results_dir, "all_shots_retrieval_results.json")
+    if not os.path.exists(rf):
+        print(f"错误：找不到检索结果文件 {rf}")
+        return 1
+    with open(rf, encoding="utf-8") as f:
+        results = json.load(f)
+    engine = Engine("dev", args.model_root, synthetic=args.synthetic_weights, tiny=args.tiny, device=torch.device("cuda", local))
+    datasets = [args.dataset] if args.dataset else (DATASET_GROUPS[args.dataset_group] if args.dataset_group else list(results))
+    tot_ok = tot_bad = 0
+    for ds in datasets:
+        shots = args.shots or sorted(int(k.split("_")[0]) for k in results.get(ds, {}) if k.endswith("_shot"))
+        for shot in shots:
+            ok, bad = process_dataset(engine, results, ds, shot, args, rank, world)
+            tot_ok += ok
+            tot_bad += bad
+            print(f"数据集 {ds} {shot}-shot: 成功 {ok}, 失败 {bad}")
+    print(f"处理完成: 成功生成 {tot_ok} 张图像, 失败 {tot_bad}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -140,11 +140,12 @@ __global__ __launch_bounds__(256) void pad_copy_kernel(PadCopyArgs p) {
 }
 
 // ------------------------------------------------------------------ row softmax (f32 -> bf16)
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, bf16_t* y, int cols, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, bf16_t* y, int cols, float scale, int ldy) {
   __shared__ float red[8];
   const long long row = blockIdx.x;
   const float* xr = x + row * cols;
-  bf16_t* yr = y + row * cols;
+  bf16_t* yr = y + row * ldy;
+  for (int c = cols + threadIdx.x; c < ldy; c += 256) yr[c] = 0;   // zero the K-padding the next GEMM reads
   const int tid = threadIdx.x;
   float m = -INFINITY;
   for (int c = tid * 4; c < cols; c += 1024) {
@@ -345,9 +346,11 @@ extern "C" int drag_pad_copy_bf16(const void* x, void* y, int32_t B, int32_t H, 
   return 0;
 }
 
-extern "C" int drag_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols, float scale, void* stream) {
-  DRAG_CHECK(x && y && rows > 0 && cols > 0 && cols % 4 == 0, "drag_softmax_rows_f32_bf16: bad args");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, cols, scale);
+extern "C" int drag_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols, int32_t ldy, float scale,
+                                          void* stream) {
+  DRAG_CHECK(x && y && rows > 0 && cols > 0 && cols % 4 == 0 && ldy >= cols && ldy % 4 == 0,
+             "drag_softmax_rows_f32_bf16: bad args");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, cols, scale, ldy);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

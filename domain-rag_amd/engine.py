@@ -1,0 +1,137 @@
+"""Model assembly for the stage CLIs: load the FLUX.1 checkpoints the reference loads
+(``load_model``: batch_generate_flux_kshot.py:117-153, outpainting_updown_sampling_redux.py:500-543) into the
+HIP classes, or build seeded synthetic weights of the same architectures when no checkpoints exist
+(``synthetic=True``; there are none offline).  Models are loaded ONCE per process (the reference reloads them per
+sample at outpainting_…:1185 — a pure slowdown).
+
+Text encoders: the prompt is constant per dataset ("" everywhere except FISH, outpainting_…:85-95), so T5 /
+CLIP-text outputs are cached inputs (``prompt_embeds_cache``), never on the per-image path.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from . import ops, redux as redux_mod, vae as vae_mod, vit as vit_mod
+from .fill_pipeline import FluxFillHIP
+from .flux import FluxTransformerHIP, latent_image_ids
+from .flux_params import FluxConfig, init_params, load_safetensors_dir
+from .scheduler import flow_sigmas
+
+TINY = dict(flux=dict(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=256, pooled_projection_dim=64),
+            vae=dict(layers_per_block=1), vit=dict(image_size=56, patch_size=14, hidden=192, heads=2, layers=1, intermediate=304),
+            t5_tokens=16)
+
+
+def pack_noise(noise_nchw: torch.Tensor) -> torch.Tensor:
+    """FluxPipeline._pack_latents on a host noise tensor [B,16,h,w] -> [B,(h/2)(w/2),64] (layout only)"""
+    B, C, H, W = noise_nchw.shape
+    return noise_nchw.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 2) * (W // 2), C * 4).contiguous()
+
+
+def generator_noise(seed: int, B: int, H: int, W: int, n_draws: int):
+    """the draws diffusers takes from ``torch.Generator("cpu").manual_seed(seed)``: bf16 [B,16,H/8,W/8] each, in order"""
+    g = torch.Generator("cpu").manual_seed(int(seed))
+    return [torch.randn((B, 16, H // 8, W // 8), generator=g, dtype=torch.bfloat16) for _ in range(n_draws)]
+
+
+def siglip_input(pil_images, size: int) -> torch.Tensor:
+    """SiglipImageProcessor: RGB, resize to (size,size) bicubic (aspect ignored); rescale/normalise happen on device"""
+    from PIL import Image
+    arr = [np.asarray(im.convert("RGB").resize((size, size), Image.BICUBIC), dtype=np.uint8) for im in pil_images]
+    return torch.from_numpy(np.stack(arr))
+
+
+class TextCache:
+    """prompt -> (T5 embeds [Lt, J] bf16, pooled [P] bf16).  Real encodings are read from
+    ``<model_root>/prompt_cache/<sha1>.pt`` (written once by any tool that has the text encoders); synthetic mode
+    derives seeded stand-ins from the prompt hash."""
+
+    def __init__(self, model_root: str, synthetic: bool, Lt: int, J: int, P: int, device):
+        self.root, self.synthetic, self.Lt, self.J, self.P, self.dev = model_root, synthetic, Lt, J, P, device
+        self._mem: dict = {}
+
+    def get(self, prompt: str, prompt_2: str = ""):
+        key = hashlib.sha1(f"{prompt}\x00{prompt_2}".encode()).hexdigest()
+        if key not in self._mem:
+            path = os.path.join(self.root, "prompt_cache", key + ".pt")
+            if os.path.exists(path):
+                d = torch.load(path, map_location="cpu")
+                t5, pooled = d["prompt_embeds"].reshape(-1, self.J), d["pooled_prompt_embeds"].reshape(-1)
+            elif self.synthetic:
+                g = torch.Generator().manual_seed(int(key[:8], 16))
+                t5, pooled = torch.randn(self.Lt, self.J, generator=g), torch.randn(self.P, generator=g)
+            else:
+                raise FileNotFoundError(f"no cached text encoding for prompt {prompt!r}: expected {path} "
+                                        "(dict with prompt_embeds [512,4096], pooled_prompt_embeds [768])")
+            self._mem[key] = (t5.to(self.dev, torch.bfloat16).contiguous(), pooled.to(self.dev, torch.bfloat16).contiguous())
+        return self._mem[key]
+
+
+class FluxTxt2ImgHIP:
+    """``FluxPipeline.__call__(prompt_embeds=…, pooled_prompt_embeds=…, guidance_scale, num_inference_steps, height,
+    width, generator)`` of stage 2 (batch_generate_flux_kshot.py:467-474)."""
+
+    def __init__(self, transformer: FluxTransformerHIP, vae: "vae_mod.FluxVaeHIP"):
+        self.tr, self.vae, self.dev = transformer, vae, transformer.device
+
+    def __call__(self, prompt_embeds, pooled, *, height: int, width: int, guidance_scale: float, num_inference_steps: int,
+                 noise_tokens: torch.Tensor) -> torch.Tensor:
+        B = prompt_embeds.shape[0]
+        h, w = height // 16, width // 16
+        lat = noise_tokens.to(self.dev, torch.bfloat16).clone()
+        sigmas, timesteps = flow_sigmas(num_inference_steps, h * w)
+        img_ids, txt_ids = latent_image_ids(h, w), torch.zeros(prompt_embeds.shape[1], 3)
+        guidance = torch.full((B,), float(guidance_scale)) if self.tr.cfg.guidance_embeds else None
+        for i in range(num_inference_steps):
+            t = torch.full((B,), float(timesteps[i]) / 1000.0)
+            v = self.tr(lat, prompt_embeds, pooled, t, img_ids, txt_ids, guidance)
+            ops.flow_euler_rows(lat, v, B * h * w, 64, 64, 64, float(sigmas[i + 1] - sigmas[i]))
+        return self.vae.decode_tokens(lat, B, h, w, ld=64)
+
+
+class Engine:
+    """Everything stage 2 / stage 3 need, loaded once."""
+
+    def __init__(self, kind: str, model_root: str = "./model", synthetic: bool = False, tiny: bool = False, device="cuda",
+                 seed: int = 0):
+        assert kind in ("dev", "fill")
+        dev = torch.device(device)
+        self.dev, self.kind = dev, kind
+        fkw = dict(TINY["flux"]) if tiny else {}
+        cfg = FluxConfig(in_channels=384 if kind == "fill" else 64, **fkw)
+        vcfg = vae_mod.VaeConfig(**(TINY["vae"] if tiny else {}))
+        vitcfg = vit_mod.VitConfig(**TINY["vit"]) if tiny else vit_mod.VitConfig.siglip_so400m()
+        flux_dir = os.path.join(model_root, "FLUX.1-Fill-dev" if kind == "fill" else "FLUX.1-dev")
+        redux_dir = os.path.join(model_root, "FLUX.1-Redux-dev")
+        if synthetic:
+            tp = init_params(cfg, seed=seed, device=dev)
+            vp = vae_mod.init_params(vcfg, seed=seed + 1, device=dev)
+            vitp = vit_mod.init_generic_params(vitcfg, seed + 2, device=dev)
+            rp = redux_mod.init_redux_params(vitcfg.hidden, cfg.joint_attention_dim, seed=seed + 3, device=dev)
+        else:
+            for d in (flux_dir, redux_dir):
+                if not os.path.isdir(d):
+                    raise FileNotFoundError(f"{d} not found (pass --synthetic-weights to run with seeded random weights)")
+            cfg = FluxConfig.from_json(os.path.join(flux_dir, "transformer", "config.json"))
+            tp = load_safetensors_dir(os.path.join(flux_dir, "transformer"))
+            vp = load_safetensors_dir(os.path.join(flux_dir, "vae"))
+            vitp = vit_mod.siglip_to_generic(load_safetensors_dir(os.path.join(redux_dir, "image_encoder")), vitcfg)
+            rp = load_safetensors_dir(os.path.join(redux_dir, "image_embedder"))
+        tr = FluxTransformerHIP(cfg, tp, dev)
+        vae = vae_mod.FluxVaeHIP(vcfg, vp, dev)
+        del tp, vp
+        self.cfg, self.vit_cfg = cfg, vitcfg
+        self.prior = redux_mod.ReduxPriorHIP(vitcfg, vitp, rp, dev)
+        self.pipe = FluxFillHIP(tr, vae) if kind == "fill" else FluxTxt2ImgHIP(tr, vae)
+        self.text = TextCache(flux_dir, synthetic, TINY["t5_tokens"] if tiny else redux_mod.T5_TOKENS, cfg.joint_attention_dim,
+                              cfg.pooled_projection_dim, dev)
+
+    def prior_embeds(self, pil_images, prompt: str, embeds_scale, pooled_scale):
+        """pipe_prior_redux(images, prompt=…, prompt_2="", prompt_embeds_scale=…, pooled_prompt_embeds_scale=…)"""
+        t5, pooled = self.text.get(prompt, "")
+        imgs = siglip_input(pil_images, self.vit_cfg.image_size).to(self.dev)
+        return self.prior(imgs, t5, pooled, embeds_scale, pooled_scale, group=len(pil_images))

@@ -250,10 +250,11 @@ def pad_copy(x, y, B, H, W, C, upsample: int = 1):
     return y
 
 
-def softmax_rows(x: torch.Tensor, y: torch.Tensor, rows: int, cols: int, scale: float):
+def softmax_rows(x: torch.Tensor, y: torch.Tensor, rows: int, cols: int, scale: float, ldy: int | None = None):
     lib = _lib.load()
     _need(x, torch.float32, "softmax.x")
-    check(lib.drag_softmax_rows_f32_bf16(_p(x), _p(y), rows, cols, scale, _stream()), "drag_softmax_rows_f32_bf16")
+    check(lib.drag_softmax_rows_f32_bf16(_p(x), _p(y), rows, cols, ldy if ldy is not None else cols, scale, _stream()),
+          "drag_softmax_rows_f32_bf16")
     return y
 
 

@@ -168,16 +168,17 @@ class FluxVaeHIP:
         ops.gemm(n.view(-1, C), w[pre + "to_q.weight"], out=q, bias=w[pre + "to_q.bias"])
         ops.gemm(n.view(-1, C), w[pre + "to_k.weight"], out=k, bias=w[pre + "to_k.bias"])
         o = self._buf("attn_o", (B * T, C))
-        vt = self._buf("attn_vt", (C, T))
+        Tp = (T + 63) // 64 * 64                       # K of the P·V GEMM, zero-padded
+        vt = self._buf("attn_vt", (C, Tp), zero=True)
         s = self._buf("attn_s", (T, T), dtype=torch.float32)
-        pbuf = self._buf("attn_p", (T, T))
+        pbuf = self._buf("attn_p", (T, Tp))
         for b in range(B):
             nb = n.view(B, T, C)[b]
             # V^T = Wv · X^T (bias added after P·V: softmax rows sum to one)
-            ops.gemm(w[pre + "to_v.weight"], nb, out=vt)
+            ops.gemm(w[pre + "to_v.weight"], nb, out=vt, M=C, lda=C, ldc=Tp)
             ops.gemm(q.view(B, T, C)[b], k.view(B, T, C)[b], out=s, out_f32=True)
-            ops.softmax_rows(s, pbuf, T, T, 1.0 / math.sqrt(C))
-            ops.gemm(pbuf, vt, out=o.view(B, T, C)[b], bias=w[pre + "to_v.bias"])
+            ops.softmax_rows(s, pbuf, T, T, 1.0 / math.sqrt(C), ldy=Tp)
+            ops.gemm(pbuf, vt, out=o.view(B, T, C)[b], bias=w[pre + "to_v.bias"], M=T, lda=Tp, ldc=C)
         y = self._buf(tag, (B, H, W, C))
         ops.gemm(o, w[pre + "to_out.0.weight"], out=y, bias=w[pre + "to_out.0.bias"], resid=x)
         return y

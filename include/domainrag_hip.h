@@ -183,8 +183,10 @@ int drag_groupnorm_silu_bf16(const void* x, void* y, const void* gamma, const vo
 /* copy NHWC [B,H,W,C] into the interior of a haloed [B, up*H+2, up*W+2, C] buffer, nearest-upsampling by `upsample` (1|2) */
 int drag_pad_copy_bf16(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t upsample,
                        void* stream);
-/* y = softmax(x * scale) per row, f32 in, bf16 out (VAE mid-block attention, softmax upcast) */
-int drag_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols, float scale, void* stream);
+/* y[r, :cols] = softmax(x[r] * scale), y[r, cols:ldy] = 0; f32 in (dense rows of `cols`), bf16 out (row stride ldy)
+ * (VAE mid-block attention, softmax upcast; the zero tail is the K padding of the following P·V GEMM) */
+int drag_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols, int32_t ldy, float scale,
+                               void* stream);
 /* packed tokens [B, h*w, ld] (64 features) -> haloed NHWC latents [B, 2h+2, 2w+2, C]: tok / scaling + shift */
 int drag_unpack_latents_bf16(const void* tokens, void* y, int32_t B, int32_t h, int32_t w, int32_t ld, int32_t C,
                              float scaling, float shift, void* stream);

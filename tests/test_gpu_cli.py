@@ -1,0 +1,87 @@
+"""The three stage CLIs end to end on a synthetic mini-dataset (tiny architectures, seeded synthetic weights):
+file tree + JSON schemas of the reference's stage boundaries."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(mod, args, cwd, env_extra=None):
+    env = dict(os.environ, PYTHONPATH=ROOT, DRAG_TIMESTAMP="20260101_000000", **(env_extra or {}))
+    r = subprocess.run([sys.executable, "-m", mod] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_three_stages_on_mini_dataset(gpu, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    root = tmp_path
+    (root / "retrieval" / "coco" / "train2017").mkdir(parents=True)
+    for i in range(8):
+        Image.fromarray(rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)).save(root / "retrieval" / "coco" / "train2017" / f"{i:06d}.jpg")
+    ds = "ArTaxOr"
+    (root / "lamainpaint" / ds / "1_shot").mkdir(parents=True)
+    (root / "datasets" / ds / "annotations").mkdir(parents=True)
+    (root / "datasets" / ds / "train").mkdir(parents=True)
+    images, anns = [], []
+    for i, name in enumerate(["beetle_01", "moth_02"]):
+        arr = rng.integers(0, 256, (48, 72, 3), dtype=np.uint8)
+        Image.fromarray(arr).save(root / "lamainpaint" / ds / "1_shot" / f"{name}.jpg")
+        Image.fromarray(arr).save(root / "datasets" / ds / "train" / f"{name}.jpg")
+        images.append({"id": i + 1, "file_name": f"{name}.jpg", "width": 72, "height": 48})
+        anns.append({"id": i + 1, "image_id": i + 1, "bbox": [10 + i, 8, 20, 16], "category_id": 1})
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "Coleoptera"}]},
+              open(root / "datasets" / ds / "annotations" / "1_shot.json", "w"))
+
+    # ---- stage 1 (run from ./retrieval like domainrag.sh)
+    _run("domain_rag_amd.cli.stage1_retrieval", ["--datasets", ds, "--shots", "1", "--coco-dir", "./coco", "--clip-top-k", "6",
+                                                 "--pretrained-coco-features", "none.pt"], cwd=root / "retrieval")
+    rr = root / "retrieval" / "retrieval_results"
+    allr = json.load(open(rr / "all_shots_retrieval_results.json"))
+    entry = allr[ds]["1_shot"]["beetle_01"][0]
+    assert entry["sample_id"] == "beetle_01" and entry["category"] == "beetle_01"      # category == sample id
+    sims = entry["similar_images"]
+    assert len(sims) == 6 and [s["rank"] for s in sims] == [1, 2, 3, 4, 5, 6]
+    assert set(sims[0]) == {"rank", "similarity", "image_path", "source_dataset"} and sims[0]["source_dataset"] == "coco"
+    assert np.load(rr / "coco_clip_features.npy").shape == (8, 512) and len(json.load(open(rr / "coco_image_paths.json"))) == 8
+    assert (rr / f"{ds}_1_shot_beetle_01_beetle_01_retrieval_results.json").exists()
+    assert np.load(rr / f"{ds}_1_shot_inpainted_clip_features.npy").shape == (2, 512)
+
+    # ---- stage 2
+    _run("domain_rag_amd.cli.stage2_generate", ["--dataset", ds, "--shots", "1", "--retrieval_results_dir", str(rr), "--output_dir", "result",
+                                                "--coco_dir", "./retrieval/coco", "--synthetic-weights", "--tiny",
+                                                "--num_inference_steps", "2"], cwd=root)
+    base = root / "result" / f"{ds}_1shot_retrieval" / "results_coco_0.8_target_1.0_cocotext_1.0_targettext_1.0_20260101_000000"
+    for r in range(1, 6):
+        im = Image.open(base / "beetle_01" / f"generated_image_rank{r}.png")
+        assert im.size == (64, 64)
+        assert (base / "beetle_01" / f"ref_inputrank{r}.jpg").exists()
+    assert (base / "beetle_01" / "target_input.png").exists() and (base / "beetle_01" / "params.txt").exists() and (base / "batch_params.txt").exists()
+
+    # ---- stage 3
+    out = _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "7", "--dataset", ds, "--shot", "1", "--synthetic-weights", "--tiny",
+                                                       "--num_inference_steps", "2", "--seed", "3"], cwd=root)
+    assert "样本 beetle_01 处理完成" in out and "样本 moth_02 处理完成" in out
+    sd = root / "outpaint_hires" / "process_7" / ds / "1_shot" / "beetle_01"
+    pre = f"{ds}_beetle_01_1shot"
+    for r in range(1, 6):
+        assert Image.open(sd / f"{pre}_final_result_{r}.png").size == (72, 48)      # back at the original resolution
+        hires = Image.open(sd / f"{pre}_hires_result_{r}.png").size
+        assert hires == (96, 64)                                                     # min side 48 -> 64, x16 grid
+        prm = json.load(open(sd / f"{pre}_params_{r}.json"))
+        assert prm["strength"] == 0.9 and prm["guidance_scale"] == 30.0 and prm["was_upscaled"] and prm["num_bbox"] == 1
+        assert prm["processed_bbox_coords_list"] == [[int(c * prm["up_scale_factor"]) for c in [10, 8, 20, 16]]]
+        m = np.asarray(Image.open(sd / f"{pre}_mask_{r}.png"))
+        assert m.shape == (64, 96) and set(np.unique(m)) == {0, 255}
+    res = json.load(open(root / "outpaint_hires" / "process_7" / ds / "1_shot" / "outpaint_results_1shot.json"))
+    assert res["dataset"] == ds and res["shot_number"] == 1 and len(res["samples"]) == 2
+    assert len(res["samples"][0]["outpainted_images"]) == 5 and res["samples"][0]["categories"] == ["Coleoptera"]
+    fin = root / "final_results" / "process_7" / "1_shot" / ds / "1_shot"
+    assert len(list(fin.glob("*_final_result*.png"))) == 10

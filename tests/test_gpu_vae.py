@@ -57,6 +57,10 @@ def test_softmax_padcopy_pack(gpu):
     y = torch.empty((50, 256), dtype=torch.bfloat16, device=gpu)
     ops.softmax_rows(x.to(gpu), y, 50, 256, 0.3)
     assert _rel(y, torch.softmax(x * 0.3, -1)) < 1e-2
+    x2 = torch.randn(7, 100) * 3          # ragged width: zero K-padding up to the row stride
+    y2 = torch.full((7, 128), 9.0, dtype=torch.bfloat16, device=gpu)
+    ops.softmax_rows(x2.to(gpu), y2, 7, 100, 1.0, ldy=128)
+    assert _rel(y2[:, :100], torch.softmax(x2, -1)) < 1e-2 and (y2[:, 100:] == 0).all()
     a = _rand((2, 5, 3, 64), 4)
     up = torch.zeros((2, 12, 8, 64), dtype=torch.bfloat16, device=gpu)
     ops.pad_copy(a.to(gpu), up, 2, 5, 3, 64, upsample=2)
@@ -74,10 +78,11 @@ def test_softmax_padcopy_pack(gpu):
     # torch-CPU rounds the python scalar 0.1159 to bf16 before the add, CUDA/HIP keep it in fp32
     # (gpu_kernel_with_scalars opmath): <= 1 bf16 ulp apart
     got = zp.cpu()[:, 1:-1, 1:-1, :16].permute(0, 3, 1, 2).float()
-    assert ((got - ref.float()).abs() <= ref.float().abs() * 2 ** -7 + 1e-6).all()
+    assert ((got - ref.float()).abs() <= ref.float().abs() * 2 ** -7 + 1e-3).all()
 
 
-@pytest.mark.parametrize("blocks,layers,B,h,w", [((128, 256), 1, 2, 4, 4), ((128, 256, 512, 512), 2, 1, 4, 4)])
+@pytest.mark.parametrize("blocks,layers,B,h,w", [((128, 256), 1, 2, 4, 4), ((128, 256, 512, 512), 2, 1, 4, 4),
+                                                  ((128, 256), 1, 1, 5, 3)])
 def test_vae_decode_encode_vs_oracle(gpu, blocks, layers, B, h, w):
     from domain_rag_amd import vae
     from oracle import vae as ov
