@@ -128,6 +128,7 @@ struct AttnArgs {
   unsigned k_bytes, vt_bytes;
 };
 
+constexpr float DEFER_THR = 8.0f;     // log2 units; 0 = rescale on every increase (classic online softmax)
 constexpr int KT_BYTES = 64 * 256;   // K tile   [64 keys][128 d] bf16
 constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
 
     // ---- S^T = K Q^T ----
     f32x16_t sacc[2];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
         sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // lane holds S[query l&31][key kv0 + 32t + (r&3) + 8(r>>2) + 4hh]
     if (kv0 + 64 > p.S) {
 #pragma unroll
@@ -226,31 +229,38 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
           if (key >= p.S) sacc[t][r] = -INFINITY;
         }
     }
-    // ---- online softmax (exp2 domain) ----
+    // ---- online softmax (exp2 domain), deferred rescale ----
     float mt = sacc[0][0];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp2f((m_run - m_new) * p.c);
-    const float mc = m_new * p.c;
+    // Only move the running max (and rescale O, l) when some row's max grew by more than 2^8 in the
+    // exp2 domain; otherwise P = exp2(s - m_old) is bounded by 2^8, which fp32 accumulation and the
+    // bf16 P operand (relative precision is scale-free) absorb.  The previous tile's P·V is complete
+    // at this point, so everything still at the old scale (O, l) is rescaled exactly once.
+    if (!__all((mt - m_run) * p.c <= DEFER_THR)) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    const float mc = m_run * p.c;
     float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(sacc[t][r] * p.c - mc);
+        const float e = __builtin_amdgcn_exp2f(sacc[t][r] * p.c - mc);
         sacc[t][r] = e;
         ps += e;
       }
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    l_run += ps;
     // ---- P -> bf16 B-operand fragments: k-step s uses regs 8(s&1)..+8 of tile s>>1 ----
     bf16x8_t pf[4];
 #pragma unroll
@@ -262,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
       pf[s] = __builtin_bit_cast(bf16x8_t, pk);
     }
     // ---- O^T += V^T P^T ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -269,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
         const bf16x8_t vf = *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[dt], 0, 0, 0);
       }
+    __builtin_amdgcn_s_setprio(0);
   }
 
   // ---- epilogue: lane holds O[query l&31][d = 32dt + 8(r>>2) + 4hh + (r&3)] ----
