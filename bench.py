@@ -116,7 +116,7 @@ def main():
                                    f"batch={args.batch} per GPU (BASELINE configs[2])",
                        "stages": job.stages(), "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "weights": "seeded random init of the FLUX.1-Fill-dev architecture"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_t128", "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_t256 (+t128 for small M; all GEMM/conv launches)", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                          "launches_timed": launches, "avg_launch_ms": ms / max(launches, 1),
                          "e2e_mfma_frac": job.flops_per_image() * images / world / dt / 2.5e15},

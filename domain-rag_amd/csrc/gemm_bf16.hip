@@ -18,6 +18,7 @@
 // which lets the text and image streams of Flux live inside one joint [B, S, D] buffer with no
 // concat copies.
 #include "drag_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -67,6 +68,61 @@ struct GemmKArgs {
   unsigned a_bytes, w_bytes;
   int tiles_m, tiles_n;
 };
+
+
+// epilogue for 4 consecutive output columns n..n+3 of one row (bias, activation, gate/residual, store)
+__device__ __forceinline__ void epi4(const GemmKArgs& p, long long coff, int bidx, int n, f32x4_t a) {
+  if (n >= p.N) return;
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  if (p.bias) {
+    const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
+    v[0] += bf2f((bf16_t)(bb[0] & 0xffff)); v[1] += bf2f((bf16_t)(bb[0] >> 16));
+    v[2] += bf2f((bf16_t)(bb[1] & 0xffff)); v[3] += bf2f((bf16_t)(bb[1] >> 16));
+  }
+  if (p.act != DRAG_ACT_NONE && n >= p.act_n0) {
+    // torch: y = linear(x) is a bf16 tensor before the activation reads it
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(rbf(v[r]), p.act);
+  }
+  if (p.gate) {
+    // diffusers computes  x = x + gate * y  with y, gate, x bf16 tensors: y is rounded to
+    // bf16 first, the product is rounded, then the sum is rounded.
+    const u32x2_t gg = *(const u32x2_t*)(p.gate + (long long)bidx * p.ldg + n);
+    const u32x2_t rr = *(const u32x2_t*)(p.resid + coff + n);
+    const float g[4] = {bf2f((bf16_t)(gg[0] & 0xffff)), bf2f((bf16_t)(gg[0] >> 16)),
+                        bf2f((bf16_t)(gg[1] & 0xffff)), bf2f((bf16_t)(gg[1] >> 16))};
+    const float x[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)),
+                        bf2f((bf16_t)(rr[1] & 0xffff)), bf2f((bf16_t)(rr[1] >> 16))};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * rbf(v[r]));
+  } else if (p.resid) {
+    const u32x2_t rr = *(const u32x2_t*)(p.resid + coff + n);
+    v[0] = bf2f((bf16_t)(rr[0] & 0xffff)) + rbf(v[0]); v[1] = bf2f((bf16_t)(rr[0] >> 16)) + rbf(v[1]);
+    v[2] = bf2f((bf16_t)(rr[1] & 0xffff)) + rbf(v[2]); v[3] = bf2f((bf16_t)(rr[1] >> 16)) + rbf(v[3]);
+  }
+  if (p.out_f32) {
+    *(f32x4_t*)((float*)p.C + coff + n) = (f32x4_t){v[0], v[1], v[2], v[3]};
+  } else {
+    u32x2_t o;
+    o[0] = pack2bf(v[0], v[1]);
+    o[1] = pack2bf(v[2], v[3]);
+    *(u32x2_t*)((bf16_t*)p.C + coff + n) = o;
+  }
+}
+
+// tile selection shared by both kernels: XCD-contiguous, grouped along M for L2 reuse of the W panel
+__device__ __forceinline__ void pick_tile(const GemmKArgs& p, int& tm, int& tn) {
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int wg = xcd_remap((int)blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * p.tiles_n;
+  const int gid = wg / in_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int rem = wg - gid * in_group;
+  tm = first_m + rem % gsz;
+  tn = rem / gsz;
+}
 
 template <int MODE>  // 0: batched rows, 1: conv3x3 implicit GEMM
 __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
@@ -172,49 +228,209 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
     const long long coff = p.cm.off(m);
     const int bidx = m / p.cm.rpb;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wc * 64 + ni * 16 + nq;
-      if (n >= p.N) continue;
-      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-      if (p.bias) {
-        const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
-        v[0] += bf2f((bf16_t)(bb[0] & 0xffff)); v[1] += bf2f((bf16_t)(bb[0] >> 16));
-        v[2] += bf2f((bf16_t)(bb[1] & 0xffff)); v[3] += bf2f((bf16_t)(bb[1] >> 16));
-      }
-      if (p.act != DRAG_ACT_NONE && n >= p.act_n0) {
-        // torch: y = linear(x) is a bf16 tensor before the activation reads it
+    for (int ni = 0; ni < 4; ++ni) epi4(p, coff, bidx, n0 + wc * 64 + ni * 16 + nq, acc[mi][ni]);
+  }
+}
+
+
+// --------------------------------------------------------------------------------------------
+// gemm_bf16_t256 — 256x256x64 tile, 8 waves (2 along M x 4 along N), wave tile 128x64 as 8x4
+// v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  LDS: 2 K-tile buffers x {A0,A1,B0,B1}
+// half-tiles of 128 rows x 64 k (16 KiB each) = 128 KiB, one workgroup per CU, 2 waves per SIMD.
+//
+// Schedule (per K-tile t, buffer t&1, four phases; every phase = load segment, barrier, 16 MFMAs,
+// barrier):           ds_read                         LDS-DMA issued (one half-tile = 2 x 1 KiB per wave)
+//   P1   X rows 0-63 (8), W cols 0-31 (4)             tile t+1 : A0
+//   P2   W cols 32-63 (4)                             tile t+1 : A1
+//   P3   X rows 64-127 (8)                            tile t+2 : B0      (B slots of this buffer: last read in P2)
+//   P4   -                                            tile t+2 : B1 ; then s_waitcnt vmcnt(4): tile t+1 complete
+// so ~6 half-tiles (96 KiB) are in flight per CU and the queue is never drained inside the loop.
+// The two wave groups (wr = 0 / 1: one wave of each per SIMD) run staggered by one barrier, so one
+// group's MFMA segment overlaps the other group's ds_read / DMA-issue segment (s_setprio favours the
+// MFMA side).  Hazards: every ds_read is retired (lgkmcnt(0)) BEFORE the phase's first barrier, a
+// slot is restaged >= 1 phase after its last read, and the vmcnt wait that retires tile t+1 sits
+// before P4's FIRST barrier so that it also covers the group that runs one barrier ahead.
+// --------------------------------------------------------------------------------------------
+constexpr int T2_HALF = 128 * BK * 2;          // 16 KiB half-tile
+constexpr int T2_BUF = 4 * T2_HALF;            // A0 A1 B0 B1
+
+// a barrier the compiler may not move memory operations or MFMAs across (the hazard analysis above
+// assumes program order around every barrier)
+#define T2_BARRIER()                      \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * T2_BUF];
+  const int w = wave_id();
+  const int l = lane_id();
+  const int wr = w >> 2, wc = w & 3;
+  int tm, tn;
+  pick_tile(p, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const long long a0 = MODE == 0 ? p.am.off(m0) : p.cv.off(m0);
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a0), 0, 0x7ffffff0u, 0x00020000);
+  const int wrows = min(256, p.N - n0);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0,
+                                                                 (unsigned)((long long)wrows * p.K * 2), 0x00020000);
+  // staging role: in every half-tile (128 rows) this wave moves chunks 2w and 2w+1 (8 rows each)
+  unsigned voffA[2][2], voffW[2][2];   // [half][chunk]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(rbf(v[r]), p.act);
-      }
-      if (p.gate) {
-        // diffusers computes  x = x + gate * y  with y, gate, x bf16 tensors: y is rounded to
-        // bf16 first, the product is rounded, then the sum is rounded.
-        const u32x2_t gg = *(const u32x2_t*)(p.gate + (long long)bidx * p.ldg + n);
-        const u32x2_t rr = *(const u32x2_t*)(p.resid + coff + n);
-        const float g[4] = {bf2f((bf16_t)(gg[0] & 0xffff)), bf2f((bf16_t)(gg[0] >> 16)),
-                            bf2f((bf16_t)(gg[1] & 0xffff)), bf2f((bf16_t)(gg[1] >> 16))};
-        const float x[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)),
-                            bf2f((bf16_t)(rr[1] & 0xffff)), bf2f((bf16_t)(rr[1] >> 16))};
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * rbf(v[r]));
-      } else if (p.resid) {
-        const u32x2_t rr = *(const u32x2_t*)(p.resid + coff + n);
-        v[0] = bf2f((bf16_t)(rr[0] & 0xffff)) + rbf(v[0]); v[1] = bf2f((bf16_t)(rr[0] >> 16)) + rbf(v[1]);
-        v[2] = bf2f((bf16_t)(rr[1] & 0xffff)) + rbf(v[2]); v[3] = bf2f((bf16_t)(rr[1] >> 16)) + rbf(v[3]);
-      }
-      if (p.out_f32) {
-        *(f32x4_t*)((float*)p.C + coff + n) = (f32x4_t){v[0], v[1], v[2], v[3]};
-      } else {
-        u32x2_t o;
-        o[0] = pack2bf(v[0], v[1]);
-        o[1] = pack2bf(v[2], v[3]);
-        *(u32x2_t*)((bf16_t*)p.C + coff + n) = o;
-      }
+    for (int c = 0; c < 2; ++c) {
+      const int row = (w * 2 + c) * 8 + (l >> 3);            // row within the half-tile
+      const int slot = (l & 7) ^ ((row >> 1) & 7);
+      const int ra = min(m0 + h * 128 + row, p.M - 1);
+      const int rw = min(h * 128 + row, wrows - 1);
+      voffA[h][c] = (unsigned)(((MODE == 0 ? p.am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
+      voffW[h][c] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
     }
+  const int cchunks = MODE == 1 ? p.cv.Cin / BK : 1;
+  const int nk = p.K / BK;
+  auto issueA = [&](int kt, int h) {
+    int soff = kt * (BK * 2);
+    if (MODE == 1) {
+      const int tap = kt / cchunks, cc = kt - tap * cchunks;
+      const int r = tap / 3, sx = tap - r * 3;
+      soff = ((r * p.cv.Wp + sx) * p.cv.Cin + cc * BK) * 2;
+    }
+    DRAG_LDS char* d = (DRAG_LDS char*)smem + (kt & 1) * T2_BUF + h * T2_HALF + (w * 2) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)d, 16, voffA[h][0], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + 1024), 16, voffA[h][1], soff, 0, 0);
+  };
+  auto issueB = [&](int kt, int h) {
+    const int soff = kt * (BK * 2);
+    DRAG_LDS char* d = (DRAG_LDS char*)smem + (kt & 1) * T2_BUF + (2 + h) * T2_HALF + (w * 2) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)d, 16, voffW[h][0], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + 1024), 16, voffW[h][1], soff, 0, 0);
+  };
+
+  // fragment read offsets inside this wave's A half (wr) and B half (wc>>1)
+  const int p0 = (l >> 4) ^ ((l & 15) >> 1);
+  const int fx = wr * T2_HALF + (l & 15) * 128;                                   // + mi*2048
+  const int fw = (2 + (wc >> 1)) * T2_HALF + ((wc & 1) * 64 + (l & 15)) * 128;    // + ni*2048
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: tile 0 complete, tile 1's B halves in flight ----
+  issueB(0, 0); issueB(0, 1); issueA(0, 0); issueA(0, 1);
+  if (nk > 1) {
+    issueB(1, 0); issueB(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  T2_BARRIER();
+  if (wr == 1) T2_BARRIER();       // stagger the second wave group by one barrier
+
+  bf16x8_t xf[4][2], w0[2][2], w1[2][2];
+  for (int t = 0; t < nk; ++t) {
+    const char* sb = smem + (t & 1) * T2_BUF;
+    // ================= P1 =================
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) w0[ni][ks] = *(const bf16x8_t*)(sb + fw + ni * 2048 + ((p0 ^ (ks * 4)) << 4));
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + mi * 2048 + ((p0 ^ (ks * 4)) << 4));
+    if (t + 1 < nk) issueA(t + 1, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T2_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[ni][ks], xf[mi][ks], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    T2_BARRIER();
+    // ================= P2 =================
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) w1[ni][ks] = *(const bf16x8_t*)(sb + fw + (2 + ni) * 2048 + ((p0 ^ (ks * 4)) << 4));
+    if (t + 1 < nk) issueA(t + 1, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T2_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ni][ks], xf[mi][ks], acc[mi][2 + ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    T2_BARRIER();
+    // ================= P3 =================
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + (4 + mi) * 2048 + ((p0 ^ (ks * 4)) << 4));
+    if (t + 2 < nk) issueB(t + 2, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T2_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ni][ks], xf[mi][ks], acc[4 + mi][2 + ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    T2_BARRIER();
+    // ================= P4 =================
+    if (t + 2 < nk) {
+      issueB(t + 2, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // tile t+1 has landed; tile t+2's B halves stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    T2_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[ni][ks], xf[mi][ks], acc[4 + mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    T2_BARRIER();
+  }
+  if (wr == 0) T2_BARRIER();       // balance the stagger
+
+  const int nq = (l >> 4) * 4;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wr * 128 + mi * 16 + (l & 15);
+    if (m >= p.M) continue;
+    const long long coff = p.cm.off(m);
+    const int bidx = m / p.cm.rpb;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) epi4(p, coff, bidx, n0 + wc * 64 + ni * 16 + nq, acc[mi][ni]);
   }
 }
 
 }  // namespace
+
+// tile policy: the 256x256 kernel needs enough tiles to fill 256 CUs and rows to amortise its prologue
+static bool use_t256(long long M, int N, int K) { return M >= 2048 && N >= 256 && K >= 256 && getenv("DRAG_GEMM_T128") == nullptr; }
 
 static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, const void* bias, const void* gate,
                        const void* resid, int M, int N, int K, int ldc, int c_rpb, long long c_bs, int ldg, int act,
@@ -249,7 +465,12 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   DRAG_CHECK(((long long)BM * a->lda + a->K) * 2 < (1ll << 30) && (long long)BN * a->K * 2 < (1ll << 31) &&
                  (k.am.rpb >= a->M || (k.am.bs - (long long)(k.am.rpb - 1) * k.am.ld) * 2 < (1ll << 30)),
              "drag_gemm_bf16: tile span too large for 32-bit offsets");
-  hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+  if (use_t256(a->M, a->N, a->K)) {
+    k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
+    hipLaunchKernelGGL(gemm_bf16_t256<0>, dim3(k.tiles_m * k.tiles_n), dim3(512), 0, (hipStream_t)stream, k);
+  } else {
+    hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+  }
   DRAG_LAUNCH_CHECK();
   return 0;
 }
@@ -270,7 +491,11 @@ extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
   k.am.rpb = (int)M; k.am.bs = 0; k.am.ld = a->Cin;
   k.cv = ConvMap{a->Ho, a->Wo, a->Hp, a->Wp, a->Cin, a->stride, a->oy, a->ox};
   DRAG_CHECK(((long long)(BM * a->stride + 3 * a->Wp * 2) * a->Cin) * 2 < (1ll << 30), "drag_conv3x3_bf16: tile span too large");
-  hipLaunchKernelGGL(gemm_bf16_t128<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+  if (use_t256(M, a->Cout, 9 * a->Cin)) {
+    k.tiles_m = (int)((M + 255) / 256); k.tiles_n = (a->Cout + 255) / 256;
+    hipLaunchKernelGGL(gemm_bf16_t256<1>, dim3(k.tiles_m * k.tiles_n), dim3(512), 0, (hipStream_t)stream, k);
+  } else
+    hipLaunchKernelGGL(gemm_bf16_t128<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

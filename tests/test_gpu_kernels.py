@@ -214,3 +214,74 @@ def test_l2_normalize(gpu):
     x = torch.randn(33, 512)
     y = ops.l2_normalize_(x.to(gpu).clone()).cpu()
     assert torch.allclose(y, x / x.norm(dim=-1, keepdim=True), atol=1e-6)
+
+
+# ------------------------------------------------------------------ 256x256 phased GEMM (M >= 2048 selects it)
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 256), (2321, 520, 320), (4096, 1024, 64), (3000, 3072, 1024), (2049, 260, 1536)])
+def test_gemm_t256_shapes(gpu, M, N, K):
+    from domain_rag_amd import ops
+    a, w, b = _randn((M, K), 21), _randn((N, K), 22, 0.05), _randn((N,), 23)
+    out = ops.gemm(a.to(gpu), w.to(gpu), bias=b.to(gpu)).cpu()
+    ref64 = a.double() @ w.double().T + b.double()
+    assert _rel(out, ref64) < 6e-3
+    # row/col-resolved check (a transposed or shifted tile would pass a max-only check on iid data rarely, never this)
+    err = (out.double() - ref64).abs()
+    assert (err.max(dim=1).values < 0.05 * ref64.abs().max()).all() and (err.max(dim=0).values < 0.05 * ref64.abs().max()).all()
+
+
+def test_gemm_t256_identity_and_epilogues(gpu):
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    K = N = 512
+    M = 2560
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0                       # row r selects W column r % K
+    w = (torch.arange(N)[:, None] * 1.0 + torch.arange(K)[None, :] * 0.001).bfloat16()
+    out = ops.gemm(a.bfloat16().to(gpu), w.to(gpu)).cpu()
+    assert torch.equal(out, w.T[torch.arange(M) % K].contiguous())
+    # gated residual inside a joint buffer, batched rows straddling tile boundaries
+    B, St, Si, D, Kk = 2, 100, 1500, 512, 256
+    S = St + Si
+    x, aa = _randn((B, S, D), 7), _randn((B, S, Kk), 8)
+    ww, bb, mod = _randn((D, Kk), 9, 0.1), _randn((D,), 10), _randn((B, 3 * D), 11)
+    xd = x.to(gpu)
+    ops.gemm(aa.to(gpu).view(-1)[St * Kk:], ww.to(gpu), out=xd.view(-1)[St * D:], bias=bb.to(gpu), M=B * Si,
+             a_rows_per_batch=Si, a_batch_stride=S * Kk, lda=Kk, c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D,
+             gate=mod.to(gpu).view(-1)[D:], resid=xd.view(-1)[St * D:], ldg=3 * D, act=1)
+    ref = ops_ref.gemm_ref(aa[:, St:].reshape(-1, Kk), ww, bb, act=1, gate=mod[:, D:2 * D], resid=x[:, St:].reshape(-1, D),
+                           rows_per_batch=Si)
+    got = xd.cpu()
+    assert torch.equal(got[:, :St], x[:, :St]) and _rel(got[:, St:].reshape(-1, D), ref) < 1e-2
+
+
+def test_gemm_t256_race_screen(gpu):
+    """the phased schedule keeps LDS-DMA in flight across barriers: results must be bit-identical run to run and equal
+    to the simple 128x128 kernel's (same k-order per output element -> same fp32 sums)"""
+    import os
+    from domain_rag_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K) in [(8192, 4096, 4096), (42696 // 4, 3072, 15360 // 4)]:
+        a = torch.randn(M, K, generator=g).bfloat16().to(gpu)
+        w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().to(gpu)
+        ref = ops.gemm(a, w).clone()
+        for _ in range(6):
+            assert torch.equal(ops.gemm(a, w), ref)
+        os.environ["DRAG_GEMM_T128"] = "1"
+        try:
+            small = ops.gemm(a, w)
+        finally:
+            del os.environ["DRAG_GEMM_T128"]
+        assert torch.equal(small, ref)
+
+
+def test_conv3x3_t256(gpu):
+    from domain_rag_amd import ops
+    B, H, W, Ci, Co = 2, 40, 40, 128, 256
+    x, w, b = _randn((B, Ci, H, W), 1), _randn((Co, Ci, 3, 3), 2, 0.05), _randn((Co,), 3)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), padding=1)
+    xp = torch.zeros((B, H + 2, W + 2, Ci), dtype=torch.bfloat16)
+    xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    y = torch.empty((B, H, W, Co), dtype=torch.bfloat16, device=gpu)
+    ops.conv3x3(xp.to(gpu), w.permute(0, 2, 3, 1).contiguous().to(gpu), y, B=B, Ho=H, Wo=W, Hp=H + 2, Wp=W + 2, Cin=Ci, Cout=Co,
+                bias=b.to(gpu))
+    assert _rel(y.cpu().permute(0, 3, 1, 2), ref) < 8e-3
