@@ -39,15 +39,20 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // --- activations (fp32 math; match torch's definitions) ---
+// sigmoid(z) = 1 / (1 + 2^(-z*log2 e)) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each; saturates correctly:
+// z -> -inf gives rcp(inf) = 0, z -> +inf gives rcp(1) = 1)
+__device__ __forceinline__ float fast_sigmoid(float z) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
 __device__ __forceinline__ float act_gelu_tanh(float x) {
-  // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))
+  // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715x^3); 0.5*(1+tanh u) = sigmoid(2u)
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  const float u2 = 2.0f * k0 * x * (1.0f + k1 * x * x);
+  return x * fast_sigmoid(u2);
 }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
-__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_silu(float x) { return x * fast_sigmoid(x); }
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * fast_sigmoid(1.702f * x); }
 
 
 __device__ __forceinline__ float apply_act(float x, int act) {

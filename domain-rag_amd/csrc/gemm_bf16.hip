@@ -70,43 +70,118 @@ struct GemmKArgs {
 };
 
 
-// epilogue for 4 consecutive output columns n..n+3 of one row (bias, activation, gate/residual, store)
-__device__ __forceinline__ void epi4(const GemmKArgs& p, long long coff, int bidx, int n, f32x4_t a) {
+// per-column epilogue operands of one 4-wide column group, loaded once per tile column (not once per row)
+struct ColOps {
+  float b[4];      // bias
+  float g[4];      // gate (valid when the tile lies inside one batch)
+};
+__device__ __forceinline__ void load_colops(const GemmKArgs& p, int n, int bidx, bool gate_uniform, ColOps& c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { c.b[r] = 0.f; c.g[r] = 0.f; }
   if (n >= p.N) return;
-  float v[4] = {a[0], a[1], a[2], a[3]};
   if (p.bias) {
     const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
-    v[0] += bf2f((bf16_t)(bb[0] & 0xffff)); v[1] += bf2f((bf16_t)(bb[0] >> 16));
-    v[2] += bf2f((bf16_t)(bb[1] & 0xffff)); v[3] += bf2f((bf16_t)(bb[1] >> 16));
+    c.b[0] = bf2f((bf16_t)(bb[0] & 0xffff)); c.b[1] = bf2f((bf16_t)(bb[0] >> 16));
+    c.b[2] = bf2f((bf16_t)(bb[1] & 0xffff)); c.b[3] = bf2f((bf16_t)(bb[1] >> 16));
   }
-  if (p.act != DRAG_ACT_NONE && n >= p.act_n0) {
-    // torch: y = linear(x) is a bf16 tensor before the activation reads it
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = apply_act(rbf(v[r]), p.act);
-  }
-  if (p.gate) {
-    // diffusers computes  x = x + gate * y  with y, gate, x bf16 tensors: y is rounded to
-    // bf16 first, the product is rounded, then the sum is rounded.
+  if (p.gate && gate_uniform) {
     const u32x2_t gg = *(const u32x2_t*)(p.gate + (long long)bidx * p.ldg + n);
-    const u32x2_t rr = *(const u32x2_t*)(p.resid + coff + n);
-    const float g[4] = {bf2f((bf16_t)(gg[0] & 0xffff)), bf2f((bf16_t)(gg[0] >> 16)),
-                        bf2f((bf16_t)(gg[1] & 0xffff)), bf2f((bf16_t)(gg[1] >> 16))};
-    const float x[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)),
-                        bf2f((bf16_t)(rr[1] & 0xffff)), bf2f((bf16_t)(rr[1] >> 16))};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * rbf(v[r]));
-  } else if (p.resid) {
-    const u32x2_t rr = *(const u32x2_t*)(p.resid + coff + n);
-    v[0] = bf2f((bf16_t)(rr[0] & 0xffff)) + rbf(v[0]); v[1] = bf2f((bf16_t)(rr[0] >> 16)) + rbf(v[1]);
-    v[2] = bf2f((bf16_t)(rr[1] & 0xffff)) + rbf(v[2]); v[3] = bf2f((bf16_t)(rr[1] >> 16)) + rbf(v[3]);
+    c.g[0] = bf2f((bf16_t)(gg[0] & 0xffff)); c.g[1] = bf2f((bf16_t)(gg[0] >> 16));
+    c.g[2] = bf2f((bf16_t)(gg[1] & 0xffff)); c.g[3] = bf2f((bf16_t)(gg[1] >> 16));
   }
-  if (p.out_f32) {
-    *(f32x4_t*)((float*)p.C + coff + n) = (f32x4_t){v[0], v[1], v[2], v[3]};
+}
+
+// The fused activations are all  y = x * sigmoid(x * (c0 + c1 x^2)):  GELU-tanh (c0, c1) = (2k, 2k*0.044715),
+// SiLU (1, 0), QuickGELU (1.702, 0) -> one branch-free body, tiny code (the epilogue is inlined 32x per lane;
+// a switch over libm-style bodies there blew the instruction cache and cost >25 % on K = 3072 GEMMs).
+struct ActCoef { float c0, c1; };
+__device__ __forceinline__ ActCoef act_coef(int act) {
+  switch (act) {
+    case DRAG_ACT_GELU_TANH: return {2.0f * 0.7978845608028654f, 2.0f * 0.7978845608028654f * 0.044715f};
+    case DRAG_ACT_SILU: return {1.0f, 0.0f};
+    case DRAG_ACT_QUICK_GELU: return {1.702f, 0.0f};
+    default: return {0.0f, 0.0f};
+  }
+}
+
+// epilogue of one accumulator row-group: NI groups of 4 consecutive columns of ONE output row.
+// CHECK = false is the interior-tile fast path (no bounds tests, residual loads issued up front).
+template <int NI, bool CHECK>
+__device__ __forceinline__ void epi_row(const GemmKArgs& p, long long coff, int bidx, int nbase, const f32x4_t* a,
+                                        const ColOps* c, bool gate_uniform, ActCoef ac) {
+  u32x2_t rr[NI];
+  if (p.resid) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = nbase + ni * 16;
+      rr[ni] = (u32x2_t){0u, 0u};
+      if (!CHECK || n < p.N) rr[ni] = *(const u32x2_t*)(p.resid + coff + n);
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = nbase + ni * 16;
+    if (CHECK && n >= p.N) continue;
+    float v[4] = {a[ni][0] + c[ni].b[0], a[ni][1] + c[ni].b[1], a[ni][2] + c[ni].b[2], a[ni][3] + c[ni].b[3]};
+    if (p.act != DRAG_ACT_NONE && n >= p.act_n0) {
+      // torch: y = linear(x) is a bf16 tensor before the activation reads it
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = rbf(v[r]);
+        v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
+      }
+    }
+    if (p.gate) {
+      // diffusers computes  x = x + gate * y  with y, gate, x bf16 tensors: y is rounded to
+      // bf16 first, the product is rounded, then the sum is rounded.
+      float g[4] = {c[ni].g[0], c[ni].g[1], c[ni].g[2], c[ni].g[3]};
+      if (!gate_uniform) {
+        const u32x2_t gg = *(const u32x2_t*)(p.gate + (long long)bidx * p.ldg + n);
+        g[0] = bf2f((bf16_t)(gg[0] & 0xffff)); g[1] = bf2f((bf16_t)(gg[0] >> 16));
+        g[2] = bf2f((bf16_t)(gg[1] & 0xffff)); g[3] = bf2f((bf16_t)(gg[1] >> 16));
+      }
+      const float x[4] = {bf2f((bf16_t)(rr[ni][0] & 0xffff)), bf2f((bf16_t)(rr[ni][0] >> 16)),
+                          bf2f((bf16_t)(rr[ni][1] & 0xffff)), bf2f((bf16_t)(rr[ni][1] >> 16))};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * rbf(v[r]));
+    } else if (p.resid) {
+      v[0] = bf2f((bf16_t)(rr[ni][0] & 0xffff)) + rbf(v[0]); v[1] = bf2f((bf16_t)(rr[ni][0] >> 16)) + rbf(v[1]);
+      v[2] = bf2f((bf16_t)(rr[ni][1] & 0xffff)) + rbf(v[2]); v[3] = bf2f((bf16_t)(rr[ni][1] >> 16)) + rbf(v[3]);
+    }
+    if (p.out_f32) {
+      *(f32x4_t*)((float*)p.C + coff + n) = (f32x4_t){v[0], v[1], v[2], v[3]};
+    } else {
+      u32x2_t o;
+      o[0] = pack2bf(v[0], v[1]);
+      o[1] = pack2bf(v[2], v[3]);
+      *(u32x2_t*)((bf16_t*)p.C + coff + n) = o;
+    }
+  }
+}
+
+// whole-wave epilogue: MI row groups x 4 column groups; rows m = mrow0 + 16*mi, columns nbase + 16*ni
+template <int MI, int TM>
+__device__ __forceinline__ void wave_epilogue(const GemmKArgs& p, int m0, int mrow0, int n0, int nbase, f32x4_t (*acc)[4]) {
+  const int b_first = m0 / p.cm.rpb;
+  const bool gate_uniform = b_first == (min(m0 + TM, p.M) - 1) / p.cm.rpb;     // whole tile inside one batch
+  const ActCoef ac = act_coef(p.act);
+  ColOps co[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) load_colops(p, nbase + ni * 16, b_first, gate_uniform, co[ni]);
+  const bool interior = m0 + TM <= p.M && n0 + TM <= p.N;
+  if (interior) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = mrow0 + mi * 16;
+      epi_row<4, false>(p, p.cm.off(m), m / p.cm.rpb, nbase, acc[mi], co, gate_uniform, ac);
+    }
   } else {
-    u32x2_t o;
-    o[0] = pack2bf(v[0], v[1]);
-    o[1] = pack2bf(v[2], v[3]);
-    *(u32x2_t*)((bf16_t*)p.C + coff + n) = o;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = mrow0 + mi * 16;
+      if (m >= p.M) continue;
+      epi_row<4, true>(p, p.cm.off(m), m / p.cm.rpb, nbase, acc[mi], co, gate_uniform, ac);
+    }
   }
 }
 
@@ -220,16 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
   }
 
   // ---- epilogue: lane holds C[m = .. + (l&15)][n = .. + (l>>4)*4 + 0..3] ----
-  const int nq = (l >> 4) * 4;
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wr * 64 + mi * 16 + (l & 15);
-    if (m >= p.M) continue;
-    const long long coff = p.cm.off(m);
-    const int bidx = m / p.cm.rpb;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) epi4(p, coff, bidx, n0 + wc * 64 + ni * 16 + nq, acc[mi][ni]);
-  }
+  wave_epilogue<4, BM>(p, m0, m0 + wr * 64 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
 }
 
 
@@ -238,24 +304,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
 // v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  LDS: 2 K-tile buffers x {A0,A1,B0,B1}
 // half-tiles of 128 rows x 64 k (16 KiB each) = 128 KiB, one workgroup per CU, 2 waves per SIMD.
 //
-// Schedule (per K-tile t, buffer t&1, four phases; every phase = load segment, barrier, 16 MFMAs,
-// barrier):           ds_read                         LDS-DMA issued (one half-tile = 2 x 1 KiB per wave)
-//   P1   X rows 0-63 (8), W cols 0-31 (4)             tile t+1 : A0
-//   P2   W cols 32-63 (4)                             tile t+1 : A1
-//   P3   X rows 64-127 (8)                            tile t+2 : B0      (B slots of this buffer: last read in P2)
-//   P4   -                                            tile t+2 : B1 ; then s_waitcnt vmcnt(4): tile t+1 complete
-// so ~6 half-tiles (96 KiB) are in flight per CU and the queue is never drained inside the loop.
-// The two wave groups (wr = 0 / 1: one wave of each per SIMD) run staggered by one barrier, so one
-// group's MFMA segment overlaps the other group's ds_read / DMA-issue segment (s_setprio favours the
-// MFMA side).  Hazards: every ds_read is retired (lgkmcnt(0)) BEFORE the phase's first barrier, a
-// slot is restaged >= 1 phase after its last read, and the vmcnt wait that retires tile t+1 sits
-// before P4's FIRST barrier so that it also covers the group that runs one barrier ahead.
+// Per K-tile t (buffer t&1) four phases, each = load segment | barrier | 16 MFMAs | barrier:
+//   P1  reads X rows 0-63 (8 x b128) + W cols 0-31 (4)      quadrant (0,0)
+//   P2  reads W cols 32-63 (4)                              quadrant (0,1)
+//   P3  reads X rows 64-127 (8)                             quadrant (1,1)
+//   P4  reads nothing                                       quadrant (1,0)
+// A wave never needs a whole K-tile at once, so the LDS-DMA stream is cut into four 16-KiB PIECES ordered by
+// need-time instead of by operand:
+//   alpha = A rows 0-63 of both halves (P1)     beta  = W rows {0-31, 64-95} of both halves (P1)
+//   gamma = W rows {32-63, 96-127}     (P2)     delta = A rows 64-127 of both halves        (P3)
+// One piece (2 x 1 KiB per wave) is issued per phase into the slot whose last reader finished one or two
+// phases earlier:   P1: delta(t+1)   P2: alpha(t+2)   P3: beta(t+2)   P4: gamma(t+2)
+// so every piece is in flight for ~6 phases (1.5 K-tiles) before its first reader, ~6 pieces (96 KiB) are in
+// flight per CU, and the queue is never drained: each phase that precedes a first read waits with the COUNTED
+// s_waitcnt vmcnt(10) (five younger pieces stay in flight).
+// The two wave groups (wr = 0 / 1: one wave of each per SIMD) run staggered by one barrier, so one group's MFMA
+// segment overlaps the other's ds_read / DMA-issue segment (s_setprio favours the MFMA side).
+// Hazard rules this schedule satisfies: (RAW) data read in the load segment of phase p is waited for (vmcnt) by
+// EVERY wave in the load segment of phase p-1, i.e. before a barrier that the staggered group has passed before
+// it reads; (WAR) every ds_read is retired (lgkmcnt(0)) before its phase's first barrier and a slot is restaged
+// >= 1 phase after its last read; the compiler may not move anything across a barrier (sched_barrier).
 // --------------------------------------------------------------------------------------------
 constexpr int T2_HALF = 128 * BK * 2;          // 16 KiB half-tile
 constexpr int T2_BUF = 4 * T2_HALF;            // A0 A1 B0 B1
 
-// a barrier the compiler may not move memory operations or MFMAs across (the hazard analysis above
-// assumes program order around every barrier)
 #define T2_BARRIER()                      \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -278,37 +350,51 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
   const int wrows = min(256, p.N - n0);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0,
                                                                  (unsigned)((long long)wrows * p.K * 2), 0x00020000);
-  // staging role: in every half-tile (128 rows) this wave moves chunks 2w and 2w+1 (8 rows each)
-  unsigned voffA[2][2], voffW[2][2];   // [half][chunk]
+  // ---- staging role: every piece has 16 chunks of 8 rows; this wave moves chunks c = 2w, 2w+1 of each piece.
+  // chunk c -> operand half (c>>3) and an 8-row group inside it:
+  //   alpha: rows 8*(c&7)              delta: rows 64 + 8*(c&7)
+  //   beta : sub=c&7: rows 8*sub (sub<4) | 64 + 8*(sub-4)      gamma: rows 32 + 8*sub | 96 + 8*(sub-4)
+  unsigned vo[4][2];          // [piece: 0 alpha, 1 beta, 2 gamma, 3 delta][chunk] global byte offset (per lane)
+  int lo[4][2];               // LDS byte offset of the chunk inside a K-tile buffer (wave-uniform)
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int pc = 0; pc < 4; ++pc)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int row = (w * 2 + c) * 8 + (l >> 3);            // row within the half-tile
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const int c = w * 2 + c2, half = c >> 3, sub = c & 7;
+      int row0;                                            // first row of the chunk inside its half
+      if (pc == 0) row0 = 8 * sub;
+      else if (pc == 3) row0 = 64 + 8 * sub;
+      else if (pc == 1) row0 = sub < 4 ? 8 * sub : 64 + 8 * (sub - 4);
+      else row0 = sub < 4 ? 32 + 8 * sub : 96 + 8 * (sub - 4);
+      const int row = row0 + (l >> 3);                     // this lane's row inside the half
       const int slot = (l & 7) ^ ((row >> 1) & 7);
-      const int ra = min(m0 + h * 128 + row, p.M - 1);
-      const int rw = min(h * 128 + row, wrows - 1);
-      voffA[h][c] = (unsigned)(((MODE == 0 ? p.am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
-      voffW[h][c] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
+      const bool isA = pc == 0 || pc == 3;
+      if (isA) {
+        const int ra = min(m0 + half * 128 + row, p.M - 1);
+        vo[pc][c2] = (unsigned)(((MODE == 0 ? p.am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
+      } else {
+        const int rw = min(half * 128 + row, wrows - 1);
+        vo[pc][c2] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
+      }
+      lo[pc][c2] = ((isA ? 0 : 2) + half) * T2_HALF + row0 * 128;
     }
   const int cchunks = MODE == 1 ? p.cv.Cin / BK : 1;
   const int nk = p.K / BK;
-  auto issueA = [&](int kt, int h) {
+  auto issue = [&](int pc, int kt) {
     int soff = kt * (BK * 2);
-    if (MODE == 1) {
+    if (MODE == 1 && (pc == 0 || pc == 3)) {
       const int tap = kt / cchunks, cc = kt - tap * cchunks;
       const int r = tap / 3, sx = tap - r * 3;
       soff = ((r * p.cv.Wp + sx) * p.cv.Cin + cc * BK) * 2;
     }
-    DRAG_LDS char* d = (DRAG_LDS char*)smem + (kt & 1) * T2_BUF + h * T2_HALF + (w * 2) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)d, 16, voffA[h][0], soff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + 1024), 16, voffA[h][1], soff, 0, 0);
-  };
-  auto issueB = [&](int kt, int h) {
-    const int soff = kt * (BK * 2);
-    DRAG_LDS char* d = (DRAG_LDS char*)smem + (kt & 1) * T2_BUF + (2 + h) * T2_HALF + (w * 2) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)d, 16, voffW[h][0], soff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + 1024), 16, voffW[h][1], soff, 0, 0);
+    DRAG_LDS char* d = (DRAG_LDS char*)smem + (kt & 1) * T2_BUF;
+    if (pc == 0 || pc == 3) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + lo[pc][0]), 16, vo[pc][0], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + lo[pc][1]), 16, vo[pc][1], soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + lo[pc][0]), 16, vo[pc][0], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + lo[pc][1]), 16, vo[pc][1], soff, 0, 0);
+    }
   };
 
   // fragment read offsets inside this wave's A half (wr) and B half (wc>>1)
@@ -322,21 +408,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: tile 0 complete, tile 1's B halves in flight ----
-  issueB(0, 0); issueB(0, 1); issueA(0, 0); issueA(0, 1);
+  // ---- prologue: the stream up to gamma(1); alpha(0), beta(0) must have landed before P1(0) reads ----
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
   if (nk > 1) {
-    issueB(1, 0); issueB(1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    issue(0, 1); issue(1, 1); issue(2, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   T2_BARRIER();
-  if (wr == 1) T2_BARRIER();       // stagger the second wave group by one barrier
+  if (wr == 1) T2_BARRIER();                       // stagger the second wave group by one barrier
 
   bf16x8_t xf[4][2], w0[2][2], w1[2][2];
+#define T2_MMA(wsel, mh, nh) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
+      acc[4 * (mh) + mi][2 * (nh) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsel[ni][ks], xf[mi][ks], \
+                                                                                  acc[4 * (mh) + mi][2 * (nh) + ni], 0, 0, 0)
+  // counted wait: five younger pieces (10 loads) stay in flight; near the end of K the stream is shorter -> drain
+#define T2_WAIT(full) do { if (full) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); \
+                           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+
   for (int t = 0; t < nk; ++t) {
     const char* sb = smem + (t & 1) * T2_BUF;
-    // ================= P1 =================
+    // ================= P1: quadrant (0,0) =================
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -345,86 +439,53 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + mi * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 1 < nk) issueA(t + 1, 0);
+    if (t + 1 < nk) issue(3, t + 1);                 // delta(t+1)
+    T2_WAIT(t + 1 < nk);                              // gamma(t) landed (read in P2)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     T2_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[ni][ks], xf[mi][ks], acc[mi][ni], 0, 0, 0);
+    T2_MMA(w0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     T2_BARRIER();
-    // ================= P2 =================
+    // ================= P2: quadrant (0,1) =================
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) w1[ni][ks] = *(const bf16x8_t*)(sb + fw + (2 + ni) * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 1 < nk) issueA(t + 1, 1);
+    if (t + 2 < nk) issue(0, t + 2);                 // alpha(t+2): A rows 0-63 of this buffer were last read in P1
+    T2_WAIT(t + 2 < nk);                              // delta(t) landed (read in P3)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     T2_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ni][ks], xf[mi][ks], acc[mi][2 + ni], 0, 0, 0);
+    T2_MMA(w1, 0, 1);
     __builtin_amdgcn_s_setprio(0);
     T2_BARRIER();
-    // ================= P3 =================
+    // ================= P3: quadrant (1,1) =================
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + (4 + mi) * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 2 < nk) issueB(t + 2, 0);
+    if (t + 2 < nk) issue(1, t + 2);                 // beta(t+2): its W rows were last read in P1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     T2_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ni][ks], xf[mi][ks], acc[4 + mi][2 + ni], 0, 0, 0);
+    T2_MMA(w1, 1, 1);
     __builtin_amdgcn_s_setprio(0);
     T2_BARRIER();
-    // ================= P4 =================
-    if (t + 2 < nk) {
-      issueB(t + 2, 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // tile t+1 has landed; tile t+2's B halves stay in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // ================= P4: quadrant (1,0); no reads =================
+    if (t + 2 < nk) issue(2, t + 2);                 // gamma(t+2): its W rows were last read in P2
+    T2_WAIT(t + 2 < nk);                              // alpha(t+1), beta(t+1) landed (read in P1 of the next tile)
     T2_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[ni][ks], xf[mi][ks], acc[4 + mi][ni], 0, 0, 0);
+    T2_MMA(w0, 1, 0);
     __builtin_amdgcn_s_setprio(0);
     T2_BARRIER();
   }
-  if (wr == 0) T2_BARRIER();       // balance the stagger
+#undef T2_MMA
+#undef T2_WAIT
+  if (wr == 0) T2_BARRIER();                       // balance the stagger
 
-  const int nq = (l >> 4) * 4;
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = m0 + wr * 128 + mi * 16 + (l & 15);
-    if (m >= p.M) continue;
-    const long long coff = p.cm.off(m);
-    const int bidx = m / p.cm.rpb;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) epi4(p, coff, bidx, n0 + wc * 64 + ni * 16 + nq, acc[mi][ni]);
-  }
+  wave_epilogue<8, 256>(p, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
 }
 
 }  // namespace
@@ -453,6 +514,8 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   DRAG_CHECK(a->N % 4 == 0, "drag_gemm_bf16: N must be a multiple of 4");
   DRAG_CHECK(a->lda % 8 == 0 && a->ldc % 4 == 0, "drag_gemm_bf16: lda %% 8 and ldc %% 4 required");
   DRAG_CHECK(!(a->gate && !a->resid), "drag_gemm_bf16: gate needs resid");
+  DRAG_CHECK(a->act == DRAG_ACT_NONE || a->act == DRAG_ACT_GELU_TANH || a->act == DRAG_ACT_SILU || a->act == DRAG_ACT_QUICK_GELU,
+             "drag_gemm_bf16: fused activation must be none, gelu-tanh, silu or quick-gelu (erf GELU: use drag_act_bf16)");
   GemmKArgs k;
   const int grid = fill_common(k, a->A, a->W, a->C, a->bias, a->gate, a->resid, a->M, a->N, a->K, a->ldc,
                                a->c_rows_per_batch, a->c_batch_stride, a->ldg, a->act, a->act_n0, a->out_f32);
@@ -481,6 +544,8 @@ extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
   DRAG_CHECK(a->Cin % BK == 0, "drag_conv3x3_bf16: Cin must be a multiple of 64 (zero-pad channels)");
   DRAG_CHECK(a->Cout % 4 == 0 && a->ldy % 4 == 0, "drag_conv3x3_bf16: Cout and ldy must be multiples of 4");
   DRAG_CHECK(a->stride == 1 || a->stride == 2, "drag_conv3x3_bf16: stride 1 or 2");
+  DRAG_CHECK(a->act == DRAG_ACT_NONE || a->act == DRAG_ACT_GELU_TANH || a->act == DRAG_ACT_SILU || a->act == DRAG_ACT_QUICK_GELU,
+             "drag_conv3x3_bf16: fused activation must be none, gelu-tanh, silu or quick-gelu");
   DRAG_CHECK((a->Ho - 1) * a->stride + a->oy + 2 <= a->Hp - 1 && (a->Wo - 1) * a->stride + a->ox + 2 <= a->Wp - 1,
              "drag_conv3x3_bf16: taps leave the padded input");
   GemmKArgs k;

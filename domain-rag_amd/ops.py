@@ -21,12 +21,22 @@ class GemmRecorder:
 
     def __init__(self):
         self.events = []
+        self.shapes = []
 
     def totals(self):
         torch.cuda.synchronize()
         flops = sum(f for _, _, f in self.events)
         ms = sum(s.elapsed_time(e) for s, e, _ in self.events)
         return flops, ms, len(self.events)
+
+    def by_shape(self):
+        """{(M, N, K): (launches, total_ms, TFLOP/s)} sorted by total time"""
+        torch.cuda.synchronize()
+        agg: dict = {}
+        for (s, e, f), shp in zip(self.events, self.shapes):
+            a = agg.setdefault(shp, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f
+        return sorted(((k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0) for k, v in agg.items()), key=lambda r: -r[2])
 
 
 _recorder: GemmRecorder | None = None
@@ -92,6 +102,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, b
         check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
         e_ev.record()
         _recorder.events.append((s_ev, e_ev, 2.0 * M * N * K))
+        _recorder.shapes.append((M, N, K))
         return out
     check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
     return out
@@ -223,6 +234,7 @@ def conv3x3(x_pad: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, B: int, Ho
         check(lib.drag_conv3x3_bf16(ctypes.byref(a), _stream()), "drag_conv3x3_bf16")
         e_ev.record()
         _recorder.events.append((s_ev, e_ev, 2.0 * B * Ho * Wo * Cout * 9 * Cin))
+        _recorder.shapes.append((B * Ho * Wo, Cout, 9 * Cin))
         return y
     check(lib.drag_conv3x3_bf16(ctypes.byref(a), _stream()), "drag_conv3x3_bf16")
     return y

@@ -40,7 +40,7 @@ const char* drag_last_error(void);
  * retrieval/clip100_resnet_style_all_shots.py:171.
  *   logical row r of A lives at A + (r / a_rows_per_batch) * a_batch_stride + (r % a_rows_per_batch) * lda
  *   (elements); same for C / resid with the c_* fields; *_rows_per_batch <= 0 means "one batch".
- *   epilogue:  v = acc + bias[n];  v = act(v) for n >= act_n0;
+ *   epilogue:  v = acc + bias[n];  v = act(v) for n >= act_n0  (act: NONE, GELU_TANH, SILU or QUICK_GELU);
  *              gate != NULL:  C = resid + gate[r / c_rows_per_batch, n] * v   (bf16-rounded like torch)
  *              else resid != NULL: C = resid + v
  *   Requires K % 64 == 0, N % 4 == 0, lda % 8 == 0, ldc % 4 == 0, A span < 2 GiB.

@@ -11,17 +11,13 @@ def bench(fn, iters=10, warm=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (32768, 3072, 3072), (42696, 9216, 3072), (42696, 12288, 3072),
-          (42696, 3072, 15360), (32768, 3072, 12288), (9928, 9216, 3072), (9928, 3072, 12288)]
-for (M, N, K) in shapes:
+for (M, N, K) in [(8192, 8192, 8192), (42696, 9216, 3072), (42696, 3072, 15360)]:
     A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    res = []
-    for env in ({}, {"DRAG_GEMM_T128": "1"}):
-        for k in ("DRAG_GEMM_V", "DRAG_GEMM_T128"): os.environ.pop(k, None)
-        os.environ.update(env)
+    out = []
+    for abl in ("0", "1", "2", "3", "4"):
+        os.environ["DRAG_GEMM_ABL"] = abl
         ms = min(bench(lambda: ops.gemm(A, W, out=C)) for _ in range(3))
-        res.append(2 * M * N * K / ms / 1e9)
-    for k in ("DRAG_GEMM_V", "DRAG_GEMM_T128"): os.environ.pop(k, None)
-    print(f"gemm {M}x{N}x{K}: t256 {res[0]:.0f} | t128 {res[1]:.0f} TF/s", flush=True)
-    del A, W, C
+        out.append(f"abl{abl} {2*M*N*K/ms/1e9:.0f}")
+    os.environ.pop("DRAG_GEMM_ABL")
+    print(f"gemm {M}x{N}x{K}: " + " | ".join(out) + "   (0 real, 1 no-DMA, 2 no-ds_read, 3 neither, 4 DMA without waits)", flush=True)

@@ -41,7 +41,15 @@ def test_gemm_identity_asymmetric(gpu):
     assert torch.equal(out, w.T.contiguous())
 
 
-@pytest.mark.parametrize("act", [1, 2, 3, 4])
+def test_gemm_rejects_erf_gelu(gpu):
+    from domain_rag_amd import ops
+    with pytest.raises(RuntimeError, match="fused activation"):
+        ops.gemm(_randn((64, 64), 1).to(gpu), _randn((64, 64), 2).to(gpu), act=ops.ACT_GELU_ERF)
+    x = _randn((3, 1001), 5)
+    assert _rel(ops.act(x.to(gpu), ops.ACT_GELU_ERF).cpu(), torch.nn.functional.gelu(x)) < 1e-2
+
+
+@pytest.mark.parametrize("act", [1, 2, 3])
 def test_gemm_act(gpu, act):
     from domain_rag_amd import ops
     from oracle import ops_ref
