@@ -166,15 +166,21 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
     const int vslot = (l & 7) ^ ((vrow >> 1) & 7);
     voff[i] = (unsigned)(((long long)vrow * p.s_pad + vslot * 8) * 2);
   }
-  auto stage = [&](int buf, int kv0) {
+  auto stage_k = [&](int buf, int kv0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = w * 4 + i;
       const int kr = min(kv0 + krow[i], p.S - 1);
       const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
       DRAG_LDS char* dK = (DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024;
-      DRAG_LDS char* dV = (DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)dK, 16, ko, 0, 0, 0);
+    }
+  };
+  auto stage_v = [&](int buf, int kv0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = w * 4 + i;
+      DRAG_LDS char* dV = (DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, voff[i], kv0 * 2, 0, 0);
     }
   };
@@ -194,47 +200,56 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int nkv = p.s_pad / 64;
-  stage(0, 0);
-  for (int it = 0; it < nkv; ++it) {
-    const int buf = it & 1;
-    const int kv0 = it * 64;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 1 < nkv) stage(buf ^ 1, kv0 + 64);
+  // S^T tile = K Q^T for the K tile in buffer `buf` (lane: query l&31, keys 32t + (r&3) + 8(r>>2) + 4hh)
+  auto qk = [&](int buf, f32x16_t (&sa)[2]) {
     const char* sK = smem + buf * KT_BYTES;
-    const char* sV = smem + 2 * KT_BYTES + buf * VT_BYTES;
-
-    // ---- S^T = K Q^T ----
-    f32x16_t sacc[2];
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) sa[t][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const bf16x8_t kf = *(const bf16x8_t*)(sK + krd + t * (32 * 256) + (((2 * ks + hh) ^ kx) << 4));
-        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t], 0, 0, 0);
+        sa[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa[t], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
-    // lane holds S[query l&31][key kv0 + 32t + (r&3) + 8(r>>2) + 4hh]
-    if (kv0 + 64 > p.S) {
+  };
+
+  // Software pipeline: while the VALU works on the softmax of tile j, the matrix pipe already computes
+  // S(j+1) = K(j+1) Q^T (independent of it), then O += P(j) V(j).  K therefore runs one tile ahead of V:
+  // iteration j needs K(j+1) and V(j) in LDS and stages K(j+2), V(j+1).
+  const int nkv = p.s_pad / 64;
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (nkv > 1) stage_k(1, 64);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16_t scur[2], snext[2];
+  qk(0, scur);
+  for (int it = 0; it < nkv; ++it) {
+    const int kv0 = it * 64;
+    // K(it+1), V(it) landed (issued one iteration ago); every wave is done with K(it) and V(it-1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 2 < nkv) stage_k(it & 1, kv0 + 128);
+    if (it + 1 < nkv) stage_v((it + 1) & 1, kv0 + 64);
+    const char* sV = smem + 2 * KT_BYTES + (it & 1) * VT_BYTES;
+
+    if (kv0 + 64 > p.S) {     // ragged last tile: keys >= S do not exist
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= p.S) sacc[t][r] = -INFINITY;
+          if (key >= p.S) scur[t][r] = -INFINITY;
         }
     }
     // ---- online softmax (exp2 domain), deferred rescale ----
-    float mt = sacc[0][0];
+    float mt = scur[0][0];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, scur[t][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     // Only move the running max (and rescale O, l) when some row's max grew by more than 2^8 in the
     // exp2 domain; otherwise P = exp2(s - m_old) is bounded by 2^8, which fp32 accumulation and the
@@ -250,14 +265,16 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
+    // ---- matrix pipe: S(it+1); VALU: P(it) = exp2(S(it) - m)  (independent -> the scheduler interleaves them)
+    if (it + 1 < nkv) qk((it + 1) & 1, snext);
     const float mc = m_run * p.c;
     float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sacc[t][r] * p.c - mc);
-        sacc[t][r] = e;
+        const float e = __builtin_amdgcn_exp2f(scur[t][r] * p.c - mc);
+        scur[t][r] = e;
         ps += e;
       }
     l_run += ps;
@@ -268,11 +285,10 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
       u32x4_t pk;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        pk[j] = pack2bf(sacc[s >> 1][8 * (s & 1) + 2 * j], sacc[s >> 1][8 * (s & 1) + 2 * j + 1]);
+        pk[j] = pack2bf(scur[s >> 1][8 * (s & 1) + 2 * j], scur[s >> 1][8 * (s & 1) + 2 * j + 1]);
       pf[s] = __builtin_bit_cast(bf16x8_t, pk);
     }
     // ---- O^T += V^T P^T ----
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -280,7 +296,8 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
         const bf16x8_t vf = *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[dt], 0, 0, 0);
       }
-    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) scur[t] = snext[t];
   }
 
   // ---- epilogue: lane holds O[query l&31][d = 32dt + 8(r>>2) + 4hh + (r&3)] ----
