@@ -106,6 +106,16 @@ def main():
 
     if rank == 0:
         flops, ms, launches = rec.totals()
+        # HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+        # command (profiles/r01_pmc_traffic.json <- scripts/rocpd_pmc.py; FETCH_SIZE doubled per the gfx950 guide)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            key = next(k for k in pm if "gemm_bf16_t256ILi0" in k)
+            traffic = pm[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = 2500.0
         out = {
@@ -117,7 +127,9 @@ def main():
                        "stages": job.stages(), "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "weights": "seeded random init of the FLUX.1-Fill-dev architecture"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_t256 (+t128 for small M; all GEMM/conv launches)", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": "bytes/launch of gemm_bf16_t256<0> from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                         "(profiles/r01_pmc_traffic.json); includes Infinity-Cache hits",
                          "launches_timed": launches, "avg_launch_ms": ms / max(launches, 1),
                          "e2e_mfma_frac": job.flops_per_image() * images / world / dt / 2.5e15},
         }
