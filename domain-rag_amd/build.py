@@ -80,6 +80,13 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+        # a shared object with an unresolved symbol links fine and only fails at dlopen: check now
+        import ctypes
+        try:
+            ctypes.CDLL(LIB)
+        except OSError as e:
+            os.remove(LIB)
+            raise RuntimeError(f"libdomainrag_hip.so does not load: {e}") from e
         if verbose:
             print(f"[domain-rag_amd] built {LIB}", file=sys.stderr)
     return LIB

@@ -14,6 +14,7 @@
 // groups of 16 so that a plain 16-byte read yields exactly the keys a lane's P registers hold
 // (no transposes, no cross-lane traffic in the loop).
 #include "drag_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -132,12 +133,21 @@ constexpr float DEFER_THR = 8.0f;     // log2 units; 0 = rescale on every increa
 constexpr int KT_BYTES = 64 * 256;   // K tile   [64 keys][128 d] bf16
 constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 
-__global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
+template <int ABL, int NW>   // ABL: timing ablations only (0 = real); NW: waves per block (4 or 8), 32 queries each
+__global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
   const int w = wave_id(), l = lane_id();
   const int hh = l >> 5;            // half-wave
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  // XCD-aware mapping (speed only): block id -> XCD id%8; all query blocks of one (batch, head) run on ONE XCD so
+  // its K / V^T stream is fetched into a single private L2 instead of all eight.
+  constexpr int QB = NW * 32;          // queries per block
+  constexpr int CPW = 16 / NW;         // 1-KiB DMA chunks per wave per tile (K and V^T tiles have 16 each)
+  const int nqb = (p.S + QB - 1) / QB;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int bh = (loc / nqb) * 8 + xcd;
+  if (bh >= p.B * p.H) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (loc - (loc / nqb) * nqb) * QB + w * 32;
 
   // ---- Q fragments stay in registers: B operand, lane -> query (l&31), k = 16ks + 8hh .. +8 ----
   bf16x8_t qf[8];
@@ -155,11 +165,12 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
   __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.vt_bytes, 0x00020000);
   // K chunk c (1 KiB) = key rows 4c..4c+3; lane: row 4c + (l>>4), physical slot l&15
   // V chunk c (1 KiB) = d rows 8c..8c+7;   lane: row 8c + (l>>3), physical slot l&7
-  int krow[4];
+  int krow[4];                        // (fixed-size: a template-dependent array bound here makes hipcc drop the host stub)
   unsigned kslot[4], voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int c = w * 4 + i;
+    if (i >= CPW) break;
+    const int c = w * CPW + i;
     krow[i] = c * 4 + (l >> 4);
     kslot[i] = (unsigned)(((l & 15) ^ (krow[i] & 15)) * 16);
     const int vrow = c * 8 + (l >> 3);
@@ -169,7 +180,8 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
   auto stage_k = [&](int buf, int kv0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = w * 4 + i;
+      if (i >= CPW) break;
+      const int c = w * CPW + i;
       const int kr = min(kv0 + krow[i], p.S - 1);
       const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
       DRAG_LDS char* dK = (DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024;
@@ -179,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
   auto stage_v = [&](int buf, int kv0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = w * 4 + i;
+      if (i >= CPW) break;
+      const int c = w * CPW + i;
       DRAG_LDS char* dV = (DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, voff[i], kv0 * 2, 0, 0);
     }
@@ -231,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
     // K(it+1), V(it) landed (issued one iteration ago); every wave is done with K(it) and V(it-1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (it + 2 < nkv) stage_k(it & 1, kv0 + 128);
-    if (it + 1 < nkv) stage_v((it + 1) & 1, kv0 + 64);
+    if (ABL != 1 && it + 2 < nkv) stage_k(it & 1, kv0 + 128);
+    if (ABL != 1 && it + 1 < nkv) stage_v((it + 1) & 1, kv0 + 64);
     const char* sV = smem + 2 * KT_BYTES + (it & 1) * VT_BYTES;
 
     if (kv0 + 64 > p.S) {     // ragged last tile: keys >= S do not exist
@@ -265,35 +278,52 @@ __global__ __launch_bounds__(256, 2) void attention_d128_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
-    // ---- matrix pipe: S(it+1); VALU: P(it) = exp2(S(it) - m)  (independent -> the scheduler interleaves them)
-    if (it + 1 < nkv) qk((it + 1) & 1, snext);
+    // ---- matrix pipe: S(it+1) = K(it+1) Q^T   ||   VALU: P(it) = exp2(S(it) - m), row sums, bf16 packing.
+    // The two streams are independent, but hipcc emits 16 back-to-back MFMAs followed by the whole softmax, so the
+    // interleave is written out: 16 steps of {prefetch next K fragment, 1 MFMA, 2 exps + pack}, each fenced with
+    // sched_barrier so the order survives.  An MFMA occupies the matrix pipe for 32 cycles after issue; the ~8 VALU
+    // of the step execute under it.  S(it+1) is computed unconditionally (in the last iteration it reads a stale K
+    // buffer and is discarded).
     const float mc = m_run * p.c;
     float ps = 0.f;
+    u32x4_t pk[4];
+    {
+      const char* sKn = smem + ((it + 1) & 1) * KT_BYTES + krd;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(scur[t][r] * p.c - mc);
-        scur[t][r] = e;
-        ps += e;
+        for (int r = 0; r < 16; ++r) snext[t][r] = 0.f;
+      bf16x8_t kf = *(const bf16x8_t*)(sKn + (((0 + hh) ^ kx) << 4));
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const bf16x8_t kcur = kf;
+        if (g < 15) {
+          const int t1 = (g + 1) >> 3, ks1 = (g + 1) & 7;
+          kf = *(const bf16x8_t*)(sKn + t1 * (32 * 256) + (((2 * ks1 + hh) ^ kx) << 4));
+        }
+        snext[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], snext[g >> 3], 0, 0, 0);
+        float e0, e1;
+        if (ABL == 2) { e0 = scur[g >> 3][(2 * g) & 15]; e1 = scur[g >> 3][((2 * g) & 15) + 1]; }
+        else {
+          e0 = __builtin_amdgcn_exp2f(scur[g >> 3][(2 * g) & 15] * p.c - mc);
+          e1 = __builtin_amdgcn_exp2f(scur[g >> 3][((2 * g) & 15) + 1] * p.c - mc);
+        }
+        ps += e0 + e1;
+        pk[g >> 2][g & 3] = pack2bf(e0, e1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
     l_run += ps;
-    // ---- P -> bf16 B-operand fragments: k-step s uses regs 8(s&1)..+8 of tile s>>1 ----
     bf16x8_t pf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      u32x4_t pk;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        pk[j] = pack2bf(scur[s >> 1][8 * (s & 1) + 2 * j], scur[s >> 1][8 * (s & 1) + 2 * j + 1]);
-      pf[s] = __builtin_bit_cast(bf16x8_t, pk);
-    }
+    for (int s = 0; s < 4; ++s) pf[s] = __builtin_bit_cast(bf16x8_t, pk[s]);
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8_t vf = *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
+        const bf16x8_t vf = ABL == 3 ? qf[(dt * 4 + s) & 7]
+                                     : *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[dt], 0, 0, 0);
       }
 #pragma unroll
@@ -355,7 +385,13 @@ extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt,
   const long long vspan = (long long)128 * p.s_pad * 2;
   DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
-  hipLaunchKernelGGL(attention_d128_kernel, dim3((S + 127) / 128, H, B), dim3(256), 0, (hipStream_t)stream, p);
+  const int groups = (B * H + 7) / 8;
+  const bool w8 = getenv("DRAG_ATTN_W4") == nullptr && S >= 1024;     // 8-wave blocks halve the DMA issue per wave
+  const int QB = w8 ? 256 : 128;
+  const int nqb2 = (S + QB - 1) / QB;
+  const dim3 grid(8 * groups * nqb2);
+  if (w8) hipLaunchKernelGGL((attention_d128_kernel<0, 8>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attention_d128_kernel<0, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -20,6 +20,15 @@ for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 729, 16)]:
     cos = torch.ones(S, 64, device=dev); sin = torch.zeros(S, 64, device=dev)
     o = torch.empty(B, S, D, device=dev, dtype=torch.bfloat16)
     ms_p = bench(lambda: ops.qk_norm_rope_vt(qkv, vt, wq, wq, wq, wq, cos, sin, B, S, H, 3 * D, 1241))
-    ms_a = bench(lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128)))
     fl = 4.0 * S * S * 128 * H * B
-    print(f"attn B={B} S={S} H={H}: prep {ms_p:.3f} ms, attention {ms_a:.3f} ms  {fl/ms_a/1e9:.1f} TF/s", flush=True)
+    res = []
+    for abl in ("0",):
+        os.environ["DRAG_ATTN_ABL"] = abl
+        ms_a = min(bench(lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))) for _ in range(2))
+        res.append(f"abl{abl} {fl/ms_a/1e9:.0f}")
+    os.environ.pop("DRAG_ATTN_ABL")
+    os.environ["DRAG_ATTN_W4"] = "1"
+    ms_a = min(bench(lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))) for _ in range(2))
+    res.append(f"4-wave {fl/ms_a/1e9:.0f}")
+    os.environ.pop("DRAG_ATTN_W4")
+    print(f"attn B={B} S={S} H={H}: prep {ms_p:.3f} ms | " + " | ".join(res) + " TF/s (0 real, 1 no-DMA, 2 no-exp, 3 no V ds_read)", flush=True)
