@@ -39,3 +39,21 @@ def fill_pipeline(tp, tcfg, vp, vae_kw, image_u8, mask_u8, prompt_embeds, pooled
         if taps is not None:
             taps[f"lat.{i}"] = lat.clone()
     return ovae.decode_tokens_to_u8(vp, lat, h, w, **vae_kw)
+
+
+def txt2img_pipeline(tp, tcfg, vp, vae_kw, prompt_embeds, pooled, guidance_scale, num_inference_steps, height, width,
+                     noise_tokens, dtype=torch.bfloat16):
+    """FluxPipeline.__call__(prompt_embeds=..., pooled_prompt_embeds=..., guidance_scale, num_inference_steps, height,
+    width, generator) as stage 2 calls it (batch_generate_flux_kshot.py:467-474); ``noise_tokens`` = packed generator draw."""
+    B = prompt_embeds.shape[0]
+    h, w = height // 16, width // 16
+    sigmas, timesteps = oflux.flow_sigmas(num_inference_steps, h * w)
+    lat = noise_tokens.to(dtype)
+    img_ids, txt_ids = oflux.latent_image_ids(h, w), torch.zeros(prompt_embeds.shape[1], 3)
+    guidance = torch.full((B,), float(guidance_scale)) if tcfg.guidance_embeds else None
+    for i in range(num_inference_steps):
+        t = timesteps[i].expand(B) / 1000.0
+        v = oflux.flux_forward(tp, tcfg, lat, prompt_embeds.to(dtype), pooled.to(dtype), t, img_ids, txt_ids, guidance,
+                               time_dtype=torch.bfloat16)
+        lat = oflux.euler_step(lat, v, sigmas[i], sigmas[i + 1])
+    return ovae.decode_tokens_to_u8(vp, lat, h, w, **vae_kw)

@@ -51,3 +51,44 @@ def test_fill_pipeline_vs_oracle(gpu):
         e = (out.float() / 255.0 - ref_img.permute(0, 2, 3, 1)).abs().max().item()
         assert out.shape == (B, res, res, 3) and out.dtype == torch.uint8
         assert e < max(1e-2 + 0.5 / 255, 2.5 * e_or), (strength, e, e_or)
+
+
+@pytest.mark.parametrize("guidance_embeds,steps", [(True, 3), (False, 4)])
+def test_txt2img_pipeline_vs_oracle(gpu, guidance_embeds, steps):
+    """stage 2 (FLUX.1-dev shape, Redux over TWO images with scales [0.8, 1.0]) and the schnell-shape config
+    (no guidance embedding, 4 steps) — BASELINE configs[1]"""
+    from domain_rag_amd import redux, vae, vit
+    from domain_rag_amd.engine import FluxTxt2ImgHIP, generator_noise, pack_noise
+    from domain_rag_amd.flux import FluxTransformerHIP
+    from domain_rag_amd.flux_params import FluxConfig, init_params
+    from oracle import fill as ofill, flux as oflux, redux as ored, vit as ovit
+    cfg = FluxConfig(in_channels=64, num_layers=2, num_single_layers=1, num_attention_heads=2, joint_attention_dim=256,
+                     pooled_projection_dim=64, guidance_embeds=guidance_embeds)
+    tp = init_params(cfg, seed=5)
+    vcfg = vae.VaeConfig(layers_per_block=1)
+    vp = vae.init_params(vcfg, seed=6)
+    vitcfg = vit.VitConfig(image_size=56, patch_size=14, hidden=192, heads=2, layers=2, intermediate=304)
+    vitp = vit.init_generic_params(vitcfg, 7)
+    rp = redux.init_redux_params(192, 256, seed=8)
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randint(0, 256, (2, 56, 56, 3), generator=g, dtype=torch.uint8)        # [retrieved, target]
+    t5 = torch.randn(24, 256, generator=g).bfloat16(); pooled = torch.randn(64, generator=g).bfloat16()
+    res = 64
+    noise = pack_noise(generator_noise(0, 1, res, res, 1)[0])
+    prior = redux.ReduxPriorHIP(vitcfg, vitp, rp, gpu)
+    pe, pp = prior(imgs.to(gpu), t5.to(gpu), pooled.to(gpu), [0.8, 1.0], [1.0, 1.0], group=2)
+    pipe = FluxTxt2ImgHIP(FluxTransformerHIP(cfg, tp, gpu), vae.FluxVaeHIP(vcfg, vp, gpu))
+    out = pipe(pe, pp, height=res, width=res, guidance_scale=2.5, num_inference_steps=steps, noise_tokens=noise.to(gpu)).cpu()
+    ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    outs = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
+        lat = ovit.siglip_last_hidden_state(vitp, 56, 14, 192, 2, 2, 304, ovit.normalize_u8(imgs, vitcfg.mean, vitcfg.std), dt)
+        r_pe, r_pp = ored.redux_prior(lat, cast(rp), t5.to(dt), pooled.to(dt), [0.8, 1.0], [1.0, 1.0])
+        _, img = ofill.txt2img_pipeline(cast(tp), ocfg, cast(vp), dict(block_out=vcfg.block_out_channels, layers=1), r_pe, r_pp,
+                                        2.5, steps, res, res, noise, dtype=dt)
+        outs[name] = img.float()
+    e_or = (outs["bf16"] - outs["f32"]).abs().max().item()
+    e = (out.float() / 255.0 - outs["f32"].permute(0, 2, 3, 1)).abs().max().item()
+    assert out.shape == (1, res, res, 3)
+    assert e < max(1e-2 + 0.5 / 255, 2.5 * e_or), (e, e_or)
