@@ -138,8 +138,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelArgs p) {
   __shared__ u64 lst[LMAX];
   __shared__ u64 srt[KMAX];
   __shared__ unsigned hist[256];
-  __shared__ unsigned scan[256];
-  __shared__ unsigned sh_need, sh_cnt;
+  __shared__ unsigned sh_need, sh_cnt, sh_done;
   __shared__ u64 sh_prefix;
   const int tid = threadIdx.x;
   const int gblk = blockIdx.x, q = blockIdx.y;
@@ -163,12 +162,16 @@ __global__ __launch_bounds__(1024) void select_kernel(SelArgs p) {
   if (L <= p.k) {
     for (int i = tid; i < p.kpad; i += 1024) srt[i] = i < L ? lst[i] : 0ull;
   } else {
-    // ---- radix select of the k-th largest composite: 8 passes of 8 bits from the top ----
-    if (tid == 0) { sh_need = (unsigned)p.k; sh_prefix = 0ull; }
+    // ---- radix select of the k-th largest composite: up to 8 passes of 8 bits from the top.
+    // Early exit: once the bin that holds the k-th element contains EXACTLY the number of elements still needed,
+    // every element with that prefix is selected and the remaining low bits need not be resolved (with distinct
+    // scores this happens after 2-3 passes; only exact score ties ever reach the index bits).
+    if (tid == 0) { sh_need = (unsigned)p.k; sh_prefix = 0ull; sh_done = 0u; }
     u64 mask = 0ull;
     for (int pass = 7; pass >= 0; --pass) {
       if (tid < 256) hist[tid] = 0u;
       __syncthreads();
+      if (sh_done) break;
       const u64 prefix = sh_prefix;
       const unsigned need = sh_need;
       for (int i = tid; i < L; i += 1024) {
@@ -176,21 +179,26 @@ __global__ __launch_bounds__(1024) void select_kernel(SelArgs p) {
         if ((x & mask) == prefix) atomicAdd(&hist[(unsigned)(x >> (8 * pass)) & 255u], 1u);
       }
       __syncthreads();
-      // inclusive scan from the top bin down: scan[t] = sum_{b >= 255 - t} hist[b]
-      if (tid < 256) scan[tid] = hist[255 - tid];
-      __syncthreads();
-      for (int off = 1; off < 256; off <<= 1) {
-        unsigned v = 0;
-        if (tid < 256 && tid >= off) v = scan[tid - off];
-        __syncthreads();
-        if (tid < 256) scan[tid] += v;
-        __syncthreads();
-      }
-      if (tid < 256) {
-        const unsigned incl = scan[tid], excl = incl - hist[255 - tid];
-        if (excl < need && need <= incl) {
-          sh_need = need - excl;
-          sh_prefix = prefix | ((u64)(255 - tid) << (8 * pass));
+      // wave 0 scans the 256 bins from the top: lane i owns bins 255-4i .. 252-4i
+      if (tid < 64) {
+        unsigned h[4], s4 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * tid - j]; s4 += h[j]; }
+        unsigned incl = s4;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned v = __shfl_up(incl, off, 64);
+          if (tid >= off) incl += v;
+        }
+        unsigned run = incl - s4;                       // elements in bins above this lane's first bin
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (run < need && need <= run + h[j]) {
+            sh_need = need - run;
+            sh_prefix = prefix | ((u64)(255 - 4 * tid - j) << (8 * pass));
+            if (h[j] == need - run) sh_done = 1u;       // the whole bin is selected
+          }
+          run += h[j];
         }
       }
       mask |= (0xffull << (8 * pass));
