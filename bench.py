@@ -119,7 +119,7 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = 2500.0
         out = {
-            "metric": "composited images/sec @1024^2, 30 Flux-Redux steps", "value": value, "unit": "images/s",
+            "metric": f"composited images/sec @{args.res}^2, {args.denoise_steps} Flux-Redux steps", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Flux-Redux outpaint (Fill) {args.res}x{args.res}, {args.denoise_steps} steps, "

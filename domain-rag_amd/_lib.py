@@ -76,6 +76,9 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
             "domain-rag_amd has no CPU / eager fallback.")
+    # torch must initialise ITS HIP runtime first: libdomainrag_hip.so then binds to the already-loaded libamdhip64
+    # instead of pulling a second copy into the process (which cannot see the GPU)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

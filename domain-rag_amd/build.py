@@ -80,13 +80,13 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
-        # a shared object with an unresolved symbol links fine and only fails at dlopen: check now
-        import ctypes
-        try:
-            ctypes.CDLL(LIB)
-        except OSError as e:
+        # a shared object with an unresolved symbol links fine and only fails at dlopen: check now — in a CHILD
+        # process, so that this process does not load the system HIP runtime before torch loads its own copy
+        # (two HIP runtimes in one process = "no ROCm-capable device" on the first launch)
+        r = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB!r})"], capture_output=True, text=True)
+        if r.returncode != 0:
             os.remove(LIB)
-            raise RuntimeError(f"libdomainrag_hip.so does not load: {e}") from e
+            raise RuntimeError(f"libdomainrag_hip.so does not load: {r.stderr.strip().splitlines()[-1] if r.stderr else r.returncode}")
         if verbose:
             print(f"[domain-rag_amd] built {LIB}", file=sys.stderr)
     return LIB
