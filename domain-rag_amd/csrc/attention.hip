@@ -5,7 +5,7 @@
 // apply_rotary_emb and F.scaled_dot_product_attention, reached on every denoise step from
 // batch_generate_flux_kshot.py:467-474 and outpainting_updown_sampling_redux.py:1246-1257.
 //
-// Attention structure: block = 4 waves x 32 queries; KV tile = 64 keys; K tile [64][128] and
+// Attention structure: block = 8 waves x 32 queries (4 waves for short sequences); KV tile = 64 keys; K tile [64][128] and
 // V^T tile [128][64] arrive by LDS-DMA (buffer_load ... lds), double-buffered, one barrier per
 // tile, XOR-swizzled on the source address + on the ds_read_b128.  QK^T is computed swapped
 // (S^T = K Q^T, v_mfma_f32_32x32x16_bf16) so each lane owns ONE query column: the online
@@ -133,7 +133,7 @@ constexpr float DEFER_THR = 8.0f;     // log2 units; 0 = rescale on every increa
 constexpr int KT_BYTES = 64 * 256;   // K tile   [64 keys][128 d] bf16
 constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 
-template <int ABL, int NW>   // ABL: timing ablations only (0 = real); NW: waves per block (4 or 8), 32 queries each
+template <int NW>   // NW: waves per block (4 or 8), 32 queries each
 __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
   const int w = wave_id(), l = lane_id();
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     // K(it+1), V(it) landed (issued one iteration ago); every wave is done with K(it) and V(it-1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (ABL != 1 && it + 2 < nkv) stage_k(it & 1, kv0 + 128);
-    if (ABL != 1 && it + 1 < nkv) stage_v((it + 1) & 1, kv0 + 64);
+    if (it + 2 < nkv) stage_k(it & 1, kv0 + 128);
+    if (it + 1 < nkv) stage_v((it + 1) & 1, kv0 + 64);
     const char* sV = smem + 2 * KT_BYTES + (it & 1) * VT_BYTES;
 
     if (kv0 + 64 > p.S) {     // ragged last tile: keys >= S do not exist
@@ -302,12 +302,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
           kf = *(const bf16x8_t*)(sKn + t1 * (32 * 256) + (((2 * ks1 + hh) ^ kx) << 4));
         }
         snext[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], snext[g >> 3], 0, 0, 0);
-        float e0, e1;
-        if (ABL == 2) { e0 = scur[g >> 3][(2 * g) & 15]; e1 = scur[g >> 3][((2 * g) & 15) + 1]; }
-        else {
-          e0 = __builtin_amdgcn_exp2f(scur[g >> 3][(2 * g) & 15] * p.c - mc);
-          e1 = __builtin_amdgcn_exp2f(scur[g >> 3][((2 * g) & 15) + 1] * p.c - mc);
-        }
+        const float e0 = __builtin_amdgcn_exp2f(scur[g >> 3][(2 * g) & 15] * p.c - mc);
+        const float e1 = __builtin_amdgcn_exp2f(scur[g >> 3][((2 * g) & 15) + 1] * p.c - mc);
         ps += e0 + e1;
         pk[g >> 2][g & 3] = pack2bf(e0, e1);
         __builtin_amdgcn_sched_barrier(0);
@@ -322,8 +318,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8_t vf = ABL == 3 ? qf[(dt * 4 + s) & 7]
-                                     : *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
+        const bf16x8_t vf = *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[dt], 0, 0, 0);
       }
 #pragma unroll
@@ -390,8 +385,8 @@ extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt,
   const int QB = w8 ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
-  if (w8) hipLaunchKernelGGL((attention_d128_kernel<0, 8>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attention_d128_kernel<0, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (w8) hipLaunchKernelGGL((attention_d128_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attention_d128_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

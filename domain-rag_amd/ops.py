@@ -22,12 +22,28 @@ class GemmRecorder:
     def __init__(self):
         self.events = []
         self.shapes = []
+        self.is_conv = []
 
     def totals(self):
         torch.cuda.synchronize()
         flops = sum(f for _, _, f in self.events)
         ms = sum(s.elapsed_time(e) for s, e, _ in self.events)
         return flops, ms, len(self.events)
+
+    @staticmethod
+    def kernel_of(shape, conv=False):
+        """the dispatch rule of drag_gemm_bf16 / drag_conv3x3_bf16 (csrc/gemm_bf16.hip: use_t256)"""
+        M, N, K = shape
+        return ("gemm_bf16_t256" if (M >= 2048 and N >= 256 and K >= 256) else "gemm_bf16_t128") + ("<1>" if conv else "<0>")
+
+    def by_kernel(self):
+        """{kernel name: (launches, total_ms, flops)}"""
+        torch.cuda.synchronize()
+        agg: dict = {}
+        for (s, e, f), shp, cv in zip(self.events, self.shapes, self.is_conv):
+            a = agg.setdefault(self.kernel_of(shp, cv), [0, 0.0, 0.0])
+            a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f
+        return agg
 
     def by_shape(self):
         """{(M, N, K): (launches, total_ms, TFLOP/s)} sorted by total time"""
@@ -103,6 +119,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, b
         e_ev.record()
         _recorder.events.append((s_ev, e_ev, 2.0 * M * N * K))
         _recorder.shapes.append((M, N, K))
+        _recorder.is_conv.append(False)
         return out
     check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
     return out
@@ -235,6 +252,7 @@ def conv3x3(x_pad: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, B: int, Ho
         e_ev.record()
         _recorder.events.append((s_ev, e_ev, 2.0 * B * Ho * Wo * Cout * 9 * Cin))
         _recorder.shapes.append((B * Ho * Wo, Cout, 9 * Cin))
+        _recorder.is_conv.append(True)
         return y
     check(lib.drag_conv3x3_bf16(ctypes.byref(a), _stream()), "drag_conv3x3_bf16")
     return y
