@@ -304,20 +304,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
 // v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  LDS: 2 K-tile buffers x {A0,A1,B0,B1}
 // half-tiles of 128 rows x 64 k (16 KiB each) = 128 KiB, one workgroup per CU, 2 waves per SIMD.
 //
-// Per K-tile t (buffer t&1) four phases, each = load segment | barrier | 16 MFMAs | barrier:
-//   P1  reads X rows 0-63 (8 x b128) + W cols 0-31 (4)      quadrant (0,0)
-//   P2  reads W cols 32-63 (4)                              quadrant (0,1)
-//   P3  reads X rows 64-127 (8)                             quadrant (1,1)
-//   P4  reads nothing                                       quadrant (1,0)
+// Per K-tile t (buffer t&1) TWO phases, each = load segment | barrier | 32 MFMAs | barrier (4 barriers per K-tile):
+//   phase A  reads W cols 0-63 + X rows 0-63 (16 x ds_read_b128)   quadrants (0,0) (0,1)
+//   phase B  reads X rows 64-127 (8)                               quadrants (1,1) (1,0)
 // A wave never needs a whole K-tile at once, so the LDS-DMA stream is cut into four 16-KiB PIECES ordered by
 // need-time instead of by operand:
-//   alpha = A rows 0-63 of both halves (P1)     beta  = W rows {0-31, 64-95} of both halves (P1)
-//   gamma = W rows {32-63, 96-127}     (P2)     delta = A rows 64-127 of both halves        (P3)
-// One piece (2 x 1 KiB per wave) is issued per phase into the slot whose last reader finished one or two
-// phases earlier:   P1: delta(t+1)   P2: alpha(t+2)   P3: beta(t+2)   P4: gamma(t+2)
-// so every piece is in flight for ~6 phases (1.5 K-tiles) before its first reader, ~6 pieces (96 KiB) are in
-// flight per CU, and the queue is never drained: each phase that precedes a first read waits with the COUNTED
-// s_waitcnt vmcnt(10) (five younger pieces stay in flight).
+//   alpha = A rows 0-63 of both halves          beta  = W rows {0-31, 64-95} of both halves       (read in A)
+//   gamma = W rows {32-63, 96-127}   (read in A) delta = A rows 64-127 of both halves             (read in B)
+// and issued into the slot whose last reader finished >= 1 phase earlier:
+//   phase A(t): delta(t+1)   (2 DMA per wave)        phase B(t): alpha, beta, gamma (t+2)   (6 DMA per wave)
+// -> load segments of 16 reads + 2 DMA and 8 reads + 6 DMA, both shorter than the partner group's 32-MFMA segment;
+// every piece is in flight for 2 phases (one K-tile) before the wait that retires it, ~80 KiB are in flight per CU
+// and the queue is never drained: both waits are the COUNTED s_waitcnt vmcnt(8) (four younger pieces stay in flight).
+// (Measured alternatives, same data: four phases of 16 MFMAs with 8 barriers per K-tile -3 %; DMA issue inside the
+//  MFMA segment -10 %; k-step-split fragment reads -3 %; 32x32x16 MFMA -7 %; waiting for reads after the barrier +-0.)
 // The two wave groups (wr = 0 / 1: one wave of each per SIMD) run staggered by one barrier, so one group's MFMA
 // segment overlaps the other's ds_read / DMA-issue segment (s_setprio favours the MFMA side).
 // Hazard rules this schedule satisfies: (RAW) data read in the load segment of phase p is waited for (vmcnt) by
@@ -408,11 +408,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: the stream up to gamma(1); alpha(0), beta(0) must have landed before P1(0) reads ----
+  // ---- TWO phases per K-tile (32 MFMAs each), 4 barriers per K-tile:
+  //   phase A: reads W cols 0-63 + X rows 0-63 (16 x b128), issues delta(t+1),            quadrants (0,0) (0,1)
+  //   phase B: reads X rows 64-127 (8),                     issues alpha,beta,gamma(t+2), quadrants (1,1) (1,0)
+  // (16 reads + 2 DMA | 8 reads + 6 DMA: both load segments fit under the partner group's 32-MFMA segment.)
+  // stream:  B(t): a,b,g(t+2)   A(t+1): d(t+2)   B(t+1): a,b,g(t+3) ...   every wait leaves 4 younger pieces: vmcnt(8)
   issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
   if (nk > 1) {
     issue(0, 1); issue(1, 1); issue(2, 1);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // alpha, beta, gamma (0) landed
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -424,59 +428,43 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
       acc[4 * (mh) + mi][2 * (nh) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsel[ni][ks], xf[mi][ks], \
                                                                                   acc[4 * (mh) + mi][2 * (nh) + ni], 0, 0, 0)
-  // counted wait: five younger pieces (10 loads) stay in flight; near the end of K the stream is shorter -> drain
-#define T2_WAIT(full) do { if (full) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); \
+#define T2_WAIT(full) do { if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 
   for (int t = 0; t < nk; ++t) {
     const char* sb = smem + (t & 1) * T2_BUF;
-    // ================= P1: quadrant (0,0) =================
+    // ================= phase A =================
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) w0[ni][ks] = *(const bf16x8_t*)(sb + fw + ni * 2048 + ((p0 ^ (ks * 4)) << 4));
+      for (int ks = 0; ks < 2; ++ks) {
+        w0[ni][ks] = *(const bf16x8_t*)(sb + fw + ni * 2048 + ((p0 ^ (ks * 4)) << 4));
+        w1[ni][ks] = *(const bf16x8_t*)(sb + fw + (2 + ni) * 2048 + ((p0 ^ (ks * 4)) << 4));
+      }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + mi * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 1 < nk) issue(3, t + 1);                 // delta(t+1)
-    T2_WAIT(t + 1 < nk);                              // gamma(t) landed (read in P2)
+    if (t + 1 < nk) issue(3, t + 1);                 // delta(t+1): A rows 64-127 of the other buffer, last read in B(t-1)
+    T2_WAIT(t + 1 < nk);                              // delta(t) landed (read in phase B)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     T2_BARRIER();
     __builtin_amdgcn_s_setprio(1);
     T2_MMA(w0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    T2_BARRIER();
-    // ================= P2: quadrant (0,1) =================
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) w1[ni][ks] = *(const bf16x8_t*)(sb + fw + (2 + ni) * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 2 < nk) issue(0, t + 2);                 // alpha(t+2): A rows 0-63 of this buffer were last read in P1
-    T2_WAIT(t + 2 < nk);                              // delta(t) landed (read in P3)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    T2_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
     T2_MMA(w1, 0, 1);
     __builtin_amdgcn_s_setprio(0);
     T2_BARRIER();
-    // ================= P3: quadrant (1,1) =================
+    // ================= phase B =================
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + (4 + mi) * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 2 < nk) issue(1, t + 2);                 // beta(t+2): its W rows were last read in P1
+    if (t + 2 < nk) { issue(0, t + 2); issue(1, t + 2); issue(2, t + 2); }   // slots last read in phase A of this tile
+    T2_WAIT(t + 2 < nk);                              // alpha, beta, gamma (t+1) landed (read in A of the next tile)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     T2_BARRIER();
     __builtin_amdgcn_s_setprio(1);
     T2_MMA(w1, 1, 1);
-    __builtin_amdgcn_s_setprio(0);
-    T2_BARRIER();
-    // ================= P4: quadrant (1,0); no reads =================
-    if (t + 2 < nk) issue(2, t + 2);                 // gamma(t+2): its W rows were last read in P2
-    T2_WAIT(t + 2 < nk);                              // alpha(t+1), beta(t+1) landed (read in P1 of the next tile)
-    T2_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
     T2_MMA(w0, 1, 0);
     __builtin_amdgcn_s_setprio(0);
     T2_BARRIER();
