@@ -188,6 +188,17 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)dK, 16, ko, 0, 0, 0);
     }
   };
+  auto stage_k1 = [&](int buf, int kv0, int i) {
+    const int c = w * CPW + i;
+    const int kr = min(kv0 + krow[i], p.S - 1);
+    const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024), 16, ko, 0, 0, 0);
+  };
+  auto stage_v1 = [&](int buf, int kv0, int i) {
+    const int c = w * CPW + i;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)((DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024),
+                                             16, voff[i], kv0 * 2, 0, 0);
+  };
   auto stage_v = [&](int buf, int kv0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -244,8 +255,9 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     // K(it+1), V(it) landed (issued one iteration ago); every wave is done with K(it) and V(it-1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (it + 2 < nkv) stage_k(it & 1, kv0 + 128);
-    if (it + 1 < nkv) stage_v((it + 1) & 1, kv0 + 64);
+    // (the LDS-DMA for K(it+2) / V(it+1) is issued piecewise between the MFMAs of the interleaved loop below:
+    //  a burst of 2*CPW buffer_load..lds per wave right after the barrier idles the matrix pipe of every SIMD)
+    const bool do_k = it + 2 < nkv, do_v = it + 1 < nkv;
     const char* sV = smem + 2 * KT_BYTES + (it & 1) * VT_BYTES;
 
     if (kv0 + 64 > p.S) {     // ragged last tile: keys >= S do not exist
@@ -302,6 +314,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
           kf = *(const bf16x8_t*)(sKn + t1 * (32 * 256) + (((2 * ks1 + hh) ^ kx) << 4));
         }
         snext[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], snext[g >> 3], 0, 0, 0);
+        if (g < CPW) { if (do_k) stage_k1(it & 1, kv0 + 128, g); }
+        else if (g < 2 * CPW) { if (do_v) stage_v1((it + 1) & 1, kv0 + 64, g - CPW); }
         const float e0 = __builtin_amdgcn_exp2f(scur[g >> 3][(2 * g) & 15] * p.c - mc);
         const float e1 = __builtin_amdgcn_exp2f(scur[g >> 3][((2 * g) & 15) + 1] * p.c - mc);
         ps += e0 + e1;
