@@ -47,7 +47,8 @@ SIGNATURES = {
     "drag_l2_normalize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     "drag_patchify_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "drag_scale_sum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
-    "drag_resnet_stem_style_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
+    "drag_resnet_stem_style_workspace_bytes": (c_int64, [c_int] * 3),
+    "drag_resnet_stem_style_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p, c_void_p]),
     "drag_patchify_f32_nchw": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "drag_conv3x3_bf16": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
     "drag_groupnorm_workspace_bytes": (c_int64, [c_int] * 4),

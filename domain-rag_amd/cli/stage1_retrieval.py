@@ -45,6 +45,8 @@ def build_parser():
     p.add_argument("--clip-weights", type=str, default=None, help="openai CLIP ViT-B/32 state_dict (.pt); default: synthetic")
     p.add_argument("--resnet-weights", type=str, default=None, help="torchvision resnet50 state_dict (.pt); default: synthetic")
     p.add_argument("--embed-batch", type=int, default=256)
+    p.add_argument("--style-cache", type=str, default=None,
+                   help="npz of corpus style vectors reused across queries and runs (default: <output-dir>/style_cache.npz)")
     return p
 
 
@@ -205,6 +207,11 @@ def main(argv=None):
         return 1
     all_shots: dict = {}
     style_cache: dict = {}
+    sc_path = args.style_cache or os.path.join(results_dir, "style_cache.npz")
+    if os.path.exists(sc_path):   # the reference recomputes all 100 candidates' style vectors for every query (:468-470)
+        z = np.load(sc_path, allow_pickle=False)
+        style_cache = {p: f for p, f in zip(z["paths"].tolist(), z["feats"])}
+        print(f"已加载 {len(style_cache)} 个缓存的风格特征: {sc_path}")
     if rank == 0:   # queries are few; the corpus embedding above is the sharded part
         for ds in args.datasets:
             all_shots[ds] = {}
@@ -215,6 +222,8 @@ def main(argv=None):
                     all_shots[ds][f"{shot}_shot"] = res
                 else:
                     print(f"跳过数据集 {ds} 的 {shot}_shot")
+        if style_cache:
+            np.savez(sc_path, paths=np.array(list(style_cache), dtype=str), feats=np.stack(list(style_cache.values())))
         if any(all_shots.values()):
             out = os.path.join(results_dir, "all_shots_retrieval_results.json")
             with open(out, "w", encoding="utf-8") as f:

@@ -3,9 +3,9 @@
 // Replaces ResNetEncoder.forward (conv1 7x7/2 + bn1(eval) + relu + maxpool 3x3/2) + calc_mean_std
 // (retrieval/clip100_resnet_style_all_shots.py:51-74,197-200): input [B,3,H,W] fp32 in [0,1] with NO
 // ImageNet normalisation, output [B, 128] = concat(channel mean, sqrt(unbiased var + 1e-5)).
-// One block per (image, channel): the 64x64 pooled map of a channel is produced and reduced without
-// ever touching HBM (two-pass mean / variance held in registers).  ~0.7 GFLOP per image: latency-,
-// not throughput-, bound; the image (786 KB) is read through L2 by the 64 channel blocks.
+// Two kernels: (A) one block per 8x8 tile of the pooled map x all 64 channels, input tile + transposed weights in
+// LDS (inner loop = broadcast LDS read + conflict-free LDS read + fmaf, k-order ch,ky,kx like a direct conv);
+// (B) one block per (image, channel): two-pass mean / unbiased variance of the pooled map.
 #include "drag_common.h"
 
 namespace {
@@ -14,68 +14,86 @@ struct StemArgs {
   const float* img;     // [B, 3, H, W]
   const float* w;       // [64, 3, 7, 7]
   const float *bn_scale, *bn_shift;  // folded eval BatchNorm: y = conv * scale + shift
+  float* pooled;        // scratch [B, 64, Hp, Wp]
   float* out;           // [B, 128]
-  int B, H, W;
+  int B, H, W, Hc, Wc, Hp, Wp;
   float eps;
 };
 
-constexpr int MAX_PER_THREAD = 16;  // pooled outputs per thread: (H/4)*(W/4) <= 256*16
+constexpr int ST_T = 8;                        // pooled outputs per tile edge
+constexpr int ST_IN = 4 * (ST_T - 1) + 4 + 7;  // 39 input rows/cols feed an 8x8 pooled tile
+constexpr int ST_INP = ST_IN + 1;              // row pitch
 
-__global__ __launch_bounds__(256) void stem_style_kernel(StemArgs p) {
-  __shared__ float sw[147];
+// kernel A: conv1 + bn + relu + maxpool for one 8x8 pooled tile x 64 channels.  The input tile (with its zero
+// halo) and the transposed weights [tap][channel] live in LDS: the inner loop is one broadcast LDS read (input,
+// same address for the 64 channel-lanes of a wave), one conflict-free LDS read (weight) and one fmaf.
+__global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs p) {
+  __shared__ float s_in[3 * ST_IN * ST_INP];
+  __shared__ float s_w[147 * 64];
+  const int tid = threadIdx.x;
+  const int tiles_x = (p.Wp + ST_T - 1) / ST_T;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, b = blockIdx.y;
+  const int py0 = ty * ST_T, px0 = tx * ST_T;
+  const int iy0 = 4 * py0 - 5, ix0 = 4 * px0 - 5;
+  const float* im = p.img + (long long)b * 3 * p.H * p.W;
+  for (int i = tid; i < 3 * ST_IN * ST_IN; i += 256) {
+    const int ch = i / (ST_IN * ST_IN), r = i - ch * ST_IN * ST_IN;
+    const int y = r / ST_IN, x = r - y * ST_IN;
+    const int iy = iy0 + y, ix = ix0 + x;
+    float v = 0.f;                                                   // conv zero padding
+    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = im[((long long)ch * p.H + iy) * p.W + ix];
+    s_in[(ch * ST_IN + y) * ST_INP + x] = v;
+  }
+  for (int i = tid; i < 147 * 64; i += 256) {
+    const int c = i & 63, tap = i >> 6;
+    s_w[tap * 64 + c] = p.w[c * 147 + tap];
+  }
+  __syncthreads();
+  const int c = tid & 63, g = tid >> 6;
+  const float sc = p.bn_scale[c], sh = p.bn_shift[c];
+  for (int i = 0; i < 16; ++i) {
+    const int pl = g * 16 + i, pyl = pl >> 3, pxl = pl & 7;
+    const int py = py0 + pyl, px = px0 + pxl;
+    if (py >= p.Hp || px >= p.Wp) continue;
+    float best = -INFINITY;                                          // maxpool pads with -inf
+    for (int dy = 0; dy < 3; ++dy) {
+      const int cy = 2 * py - 1 + dy;
+      if (cy < 0 || cy >= p.Hc) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int cx = 2 * px - 1 + dx;
+        if (cx < 0 || cx >= p.Wc) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+          for (int ky = 0; ky < 7; ++ky) {
+            const float* row = s_in + (ch * ST_IN + 4 * pyl + 2 * dy + ky) * ST_INP + 4 * pxl + 2 * dx;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) acc = fmaf(row[kx], s_w[((ch * 7 + ky) * 7 + kx) * 64 + c], acc);
+          }
+        best = fmaxf(best, fmaxf(acc * sc + sh, 0.f));
+      }
+    }
+    p.pooled[(((long long)b * 64 + c) * p.Hp + py) * p.Wp + px] = best;
+  }
+}
+
+// kernel B: per (image, channel) mean and unbiased std of the pooled map (two passes, fixed order)
+__global__ __launch_bounds__(256) void stem_stats_kernel(StemArgs p) {
   __shared__ float red[8];
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  if (tid < 147) sw[tid] = p.w[c * 147 + tid];
-  __syncthreads();
-  const int Hc = (p.H + 2 * 3 - 7) / 2 + 1, Wc = (p.W + 2 * 3 - 7) / 2 + 1;   // conv output
-  const int Hp = (Hc + 2 * 1 - 3) / 2 + 1, Wp = (Wc + 2 * 1 - 3) / 2 + 1;     // pooled output
-  const int n = Hp * Wp;
-  const float sc = p.bn_scale[c], sh = p.bn_shift[c];
-  const float* im = p.img + (long long)b * 3 * p.H * p.W;
-  float vals[MAX_PER_THREAD];
+  const int n = p.Hp * p.Wp;
+  const float* v = p.pooled + ((long long)b * 64 + c) * n;
   float sum = 0.f;
-#pragma unroll
-  for (int it = 0; it < MAX_PER_THREAD; ++it) {
-    const int o = it * 256 + tid;
-    float best = -INFINITY;
-    if (o < n) {
-      const int py = o / Wp, px = o - py * Wp;
-      for (int dy = 0; dy < 3; ++dy) {
-        const int cy = 2 * py - 1 + dy;
-        if (cy < 0 || cy >= Hc) continue;
-        for (int dx = 0; dx < 3; ++dx) {
-          const int cx = 2 * px - 1 + dx;
-          if (cx < 0 || cx >= Wc) continue;
-          float acc = 0.f;
-          for (int ch = 0; ch < 3; ++ch)
-            for (int ky = 0; ky < 7; ++ky) {
-              const int iy = 2 * cy - 3 + ky;
-              if (iy < 0 || iy >= p.H) continue;
-              for (int kx = 0; kx < 7; ++kx) {
-                const int ix = 2 * cx - 3 + kx;
-                if (ix < 0 || ix >= p.W) continue;
-                acc = fmaf(im[((long long)ch * p.H + iy) * p.W + ix], sw[(ch * 7 + ky) * 7 + kx], acc);
-              }
-            }
-          best = fmaxf(best, fmaxf(acc * sc + sh, 0.f));
-        }
-      }
-      sum += best;
-    }
-    vals[it] = best;
-  }
+  for (int i = tid; i < n; i += 256) sum += v[i];
   sum = wave_sum(sum);
   if ((tid & 63) == 0) red[tid >> 6] = sum;
   __syncthreads();
   const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
   float sq = 0.f;
-#pragma unroll
-  for (int it = 0; it < MAX_PER_THREAD; ++it) {
-    const int o = it * 256 + tid;
-    if (o < n) {
-      const float d = vals[it] - mean;
-      sq += d * d;
-    }
+  for (int i = tid; i < n; i += 256) {
+    const float d = v[i] - mean;
+    sq += d * d;
   }
   sq = wave_sum(sq);
   if ((tid & 63) == 0) red[4 + (tid >> 6)] = sq;
@@ -111,15 +129,27 @@ __global__ __launch_bounds__(256) void patchify_f32_kernel(PatchFArgs p) {
 
 }  // namespace
 
-extern "C" int drag_resnet_stem_style_f32(const float* img, const float* conv_w, const float* bn_scale, const float* bn_shift,
-                                          float* out, int32_t B, int32_t H, int32_t W, float eps, void* stream) {
-  DRAG_CHECK(img && conv_w && bn_scale && bn_shift && out, "drag_resnet_stem_style_f32: null pointer");
-  DRAG_CHECK(B > 0 && H >= 8 && W >= 8, "drag_resnet_stem_style_f32: bad shape");
+extern "C" int64_t drag_resnet_stem_style_workspace_bytes(int32_t B, int32_t H, int32_t W) {
   const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;
   const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
-  DRAG_CHECK(Hp * Wp <= 256 * MAX_PER_THREAD && Hp * Wp > 1, "drag_resnet_stem_style_f32: image too large (<= 256x256)");
-  StemArgs p{img, conv_w, bn_scale, bn_shift, out, B, H, W, eps};
-  hipLaunchKernelGGL(stem_style_kernel, dim3(64, B), dim3(256), 0, (hipStream_t)stream, p);
+  return (int64_t)B * 64 * Hp * Wp * 4;
+}
+
+extern "C" int drag_resnet_stem_style_f32(const float* img, const float* conv_w, const float* bn_scale, const float* bn_shift,
+                                          float* out, int32_t B, int32_t H, int32_t W, float eps, void* workspace,
+                                          void* stream) {
+  DRAG_CHECK(img && conv_w && bn_scale && bn_shift && out && workspace, "drag_resnet_stem_style_f32: null pointer");
+  DRAG_CHECK(B > 0 && H >= 8 && W >= 8, "drag_resnet_stem_style_f32: bad shape");
+  StemArgs p;
+  p.img = img; p.w = conv_w; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.pooled = (float*)workspace; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.eps = eps;
+  p.Hc = (H - 1) / 2 + 1; p.Wc = (W - 1) / 2 + 1;
+  p.Hp = (p.Hc - 1) / 2 + 1; p.Wp = (p.Wc - 1) / 2 + 1;
+  DRAG_CHECK(p.Hp * p.Wp > 1, "drag_resnet_stem_style_f32: image too small");
+  const int tiles = ((p.Hp + ST_T - 1) / ST_T) * ((p.Wp + ST_T - 1) / ST_T);
+  hipLaunchKernelGGL(stem_pool_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, p);
+  DRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(stem_stats_kernel, dim3(64, B), dim3(256), 0, (hipStream_t)stream, p);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -355,8 +355,9 @@ def resnet_stem_style(img_f32: torch.Tensor, conv_w, bn_scale, bn_shift, eps: fl
     _need(img_f32, torch.float32, "img")
     B, _, H, W = img_f32.shape
     out = torch.empty((B, 128), dtype=torch.float32, device=img_f32.device)
+    ws = torch.empty(lib.drag_resnet_stem_style_workspace_bytes(B, H, W), dtype=torch.uint8, device=img_f32.device)
     check(lib.drag_resnet_stem_style_f32(_p(img_f32), _p(conv_w), _p(bn_scale), _p(bn_shift), _p(out), B, H, W, eps,
-                                         _stream()), "drag_resnet_stem_style_f32")
+                                         _p(ws), _stream()), "drag_resnet_stem_style_f32")
     return out
 
 

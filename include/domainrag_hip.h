@@ -160,9 +160,10 @@ int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, i
 /* ResNet50 stem style vector: conv1 7x7/2 (no bias) + eval-BatchNorm (folded scale/shift) + ReLU + maxpool 3x3/2,
  * then per-channel mean and sqrt(unbiased var + eps) -> out f32 [B, 128] = [mean(64) | std(64)].
  * Replaces ResNetEncoder.forward + calc_mean_std (retrieval/clip100_resnet_style_all_shots.py:51-74,197-200).
- * img f32 [B,3,H,W] in [0,1] (H, W <= 256). */
+ * img f32 [B,3,H,W] in [0,1]; workspace: drag_resnet_stem_style_workspace_bytes(B,H,W) bytes (pooled maps). */
+int64_t drag_resnet_stem_style_workspace_bytes(int32_t B, int32_t H, int32_t W);
 int drag_resnet_stem_style_f32(const float* img, const float* conv_w, const float* bn_scale, const float* bn_shift,
-                               float* out, int32_t B, int32_t H, int32_t W, float eps, void* stream);
+                               float* out, int32_t B, int32_t H, int32_t W, float eps, void* workspace, void* stream);
 /* float NCHW (already normalised, e.g. clip `preprocess` output) -> patch rows like drag_patchify_u8 */
 int drag_patchify_f32_nchw(const float* img, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t ldo,
                            void* stream);
