@@ -75,8 +75,8 @@ class FluxTxt2ImgHIP:
     """``FluxPipeline.__call__(prompt_embeds=…, pooled_prompt_embeds=…, guidance_scale, num_inference_steps, height,
     width, generator)`` of stage 2 (batch_generate_flux_kshot.py:467-474)."""
 
-    def __init__(self, transformer: FluxTransformerHIP, vae: "vae_mod.FluxVaeHIP"):
-        self.tr, self.vae, self.dev = transformer, vae, transformer.device
+    def __init__(self, transformer: FluxTransformerHIP, vae: "vae_mod.FluxVaeHIP", use_graph: bool = True):
+        self.tr, self.vae, self.dev, self.use_graph = transformer, vae, transformer.device, use_graph
 
     def __call__(self, prompt_embeds, pooled, *, height: int, width: int, guidance_scale: float, num_inference_steps: int,
                  noise_tokens: torch.Tensor) -> torch.Tensor:
@@ -88,7 +88,8 @@ class FluxTxt2ImgHIP:
         guidance = torch.full((B,), float(guidance_scale)) if self.tr.cfg.guidance_embeds else None
         for i in range(num_inference_steps):
             t = torch.full((B,), float(timesteps[i]) / 1000.0)
-            v = self.tr(lat, prompt_embeds, pooled, t, img_ids, txt_ids, guidance)
+            fwd = self.tr.forward_graphed if self.use_graph else self.tr.forward
+            v = fwd(lat, prompt_embeds, pooled, t, img_ids, txt_ids, guidance)
             ops.flow_euler_rows(lat, v, B * h * w, 64, 64, 64, float(sigmas[i + 1] - sigmas[i]))
         return self.vae.decode_tokens(lat, B, h, w, ld=64)
 

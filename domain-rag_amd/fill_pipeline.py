@@ -25,9 +25,10 @@ from .scheduler import flow_sigmas, strength_start
 class FluxFillHIP:
     """Transformer + VAE of FLUX.1-Fill-dev (in_channels 384) with the FluxFillPipeline call sequence."""
 
-    def __init__(self, transformer: FluxTransformerHIP, vae: "vae_mod.FluxVaeHIP"):
+    def __init__(self, transformer: FluxTransformerHIP, vae: "vae_mod.FluxVaeHIP", use_graph: bool = True):
         self.tr, self.vae = transformer, vae
         self.dev = transformer.device
+        self.use_graph = use_graph      # replay the DiT forward as a hipGraph (bit-identical outputs; frees the host thread)
         self._key = None
 
     def _buffers(self, B, H, W, St):
@@ -63,7 +64,8 @@ class FluxFillHIP:
             guidance = torch.full((B,), float(guidance_scale))
             for i in range(t0, num_inference_steps):
                 t = torch.full((B,), float(timesteps[i]) / 1000.0)
-                v = self.tr(hidden, prompt_embeds, pooled, t, self._img_ids, self._txt_ids, guidance)
+                fwd = self.tr.forward_graphed if (self.use_graph and recorder is None) else self.tr.forward
+                v = fwd(hidden, prompt_embeds, pooled, t, self._img_ids, self._txt_ids, guidance)
                 ops.flow_euler_rows(hv, v, B * Si, 64, C, 64, float(sigmas[i + 1] - sigmas[i]))
             return self.vae.decode_tokens(hv, B, h, w, ld=C)
         finally:

@@ -75,3 +75,18 @@ def test_flux_depth_error_growth(gpu):
     rms_or = (ref - ref32).pow(2).mean().sqrt().item() / ref32.pow(2).mean().sqrt().item()
     print(f"depth 18 blocks: max-rel hip {e_hip:.4f} oracle-bf16 {e_or:.4f} | rms-rel hip {rms_hip:.4f} oracle-bf16 {rms_or:.4f}")
     assert e_hip < max(1e-2, 2.0 * e_or) and rms_hip < max(5e-3, 2.0 * rms_or), (e_hip, e_or, rms_hip, rms_or)
+
+
+def test_graph_replay_is_bit_identical(gpu):
+    """hipGraph capture/replay of the forward: same kernels in the same order -> identical bits, for changing timesteps"""
+    from domain_rag_amd.flux import FluxTransformerHIP
+    cfg, params, hidden, enc, pooled, t, gd, img_ids, txt_ids = _setup(
+        dict(in_channels=64, num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=128,
+             pooled_projection_dim=64), 2, 40, 8, 8, seed=4)
+    m = FluxTransformerHIP(cfg, params, gpu)
+    h, e, p = hidden.to(gpu), enc.to(gpu), pooled.to(gpu)
+    for tt in (torch.tensor([0.9, 0.9]), torch.tensor([0.4, 0.4]), torch.tensor([0.05, 0.7])):
+        eager = m.forward(h, e, p, tt, img_ids, txt_ids, gd).clone()
+        graphed = m.forward_graphed(h, e, p, tt, img_ids, txt_ids, gd).clone()
+        assert torch.equal(eager, graphed)
+    assert len(m._graphs) == 1
