@@ -67,6 +67,7 @@ struct GemmKArgs {
   int out_f32;
   unsigned a_bytes, w_bytes;
   int tiles_m, tiles_n;
+  int wide;       // C / resid / gate rows are 16-B aligned and N % 8 == 0: staged epilogue
 };
 
 
@@ -185,10 +186,115 @@ __device__ __forceinline__ void wave_epilogue(const GemmKArgs& p, int m0, int mr
   }
 }
 
+// ---- staged epilogue (bf16 output, 16-B aligned rows) -------------------------------------------------------------
+// Stores are priced per cache line touched per instruction (measured: the fragment-layout epilogue above, 16 rows x
+// 32 B per store instruction, cost 9.7 us of a 256x256 tile's ~75 us at K = 3072 — 58 us of a 460 us GEMM — and the
+// same with every tile aimed at one L2-resident location, i.e. issue-bound, not HBM-bound).  So each wave transposes
+// its 128x64 sub-tile through a private 2 KiB LDS slab, 16 rows (one MFMA row block) at a time:
+//   fragment side: v = acc + bias, activation, round to bf16 (every consumer below reads the bf16 value, as torch's
+//                  bf16 linear output), ds_write_b64 of 4 columns;
+//   row side     : lane (row l>>3 (+8), 16-B chunk l&7) reads 8 consecutive columns back, applies gate / residual
+//                  with 16-B loads and stores 16 B: one store instruction = 8 full 128-B lines.
+// Slab layout: row r at r*128 B; its 16-B slots are XOR-swizzled with (r & 7) and the 8-B halves of a slot with
+// (r >> 3), which makes the 16-lane ds_write_b64 groups and the ds_read_b128 groups bank-conflict free.
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+template <int MI, int TM, bool CHECK>
+__device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[4],
+                                            char* scr) {
+  const int q = l >> 4, r16 = l & 15;
+  const int c = l & 7, rl = l >> 3;
+  const ActCoef ac = act_coef(p.act);
+  const int b_first = m0 / p.cm.rpb;
+  const bool one_batch = b_first == (min(m0 + TM, p.M) - 1) / p.cm.rpb;     // whole tile inside one batch
+  // fragment side: bias of this lane's 4 columns per column block
+  float bias[4][4];
+  bool actv[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = nw0 + ni * 16 + q * 4;
+    bias[ni][0] = bias[ni][1] = bias[ni][2] = bias[ni][3] = 0.f;
+    if (p.bias && (!CHECK || n < p.N)) {
+      const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
+      bias[ni][0] = bf_lo(bb[0]); bias[ni][1] = bf_hi(bb[0]); bias[ni][2] = bf_lo(bb[1]); bias[ni][3] = bf_hi(bb[1]);
+    }
+    actv[ni] = p.act != DRAG_ACT_NONE && n >= p.act_n0;
+  }
+  int woff[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+    woff[ni] = r16 * 128 + (((2 * ni + (q >> 1)) ^ (r16 & 7)) << 4) + (((q & 1) ^ (r16 >> 3)) << 3);
+  const int roff = rl * 128 + ((c ^ rl) << 4);                // + j * 1024; halves swapped for j = 1
+  // row side: this lane's 8 columns
+  const int n = nw0 + c * 8;
+  const bool col_ok = !CHECK || n + 8 <= p.N;                 // N % 8 == 0 on this path
+  float g[8];
+  if (p.gate && one_batch && col_ok) {
+    const u32x4_t gg = *(const u32x4_t*)(p.gate + (long long)b_first * p.ldg + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[2 * i] = bf_lo(gg[i]); g[2 * i + 1] = bf_hi(gg[i]); }
+  }
+  const long long off0 = p.cm.off(min(mw0, p.M - 1));
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float v[4] = {acc[mi][ni][0] + bias[ni][0], acc[mi][ni][1] + bias[ni][1], acc[mi][ni][2] + bias[ni][2],
+                    acc[mi][ni][3] + bias[ni][3]};
+      if (actv[ni]) {
+        // torch: y = linear(x) is a bf16 tensor before the activation reads it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = rbf(v[r]);
+          v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
+        }
+      }
+      u32x2_t o;
+      o[0] = pack2bf(v[0], v[1]);
+      o[1] = pack2bf(v[2], v[3]);
+      *(u32x2_t*)(scr + woff[ni]) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = mw0 + mi * 16 + j * 8 + rl;
+      u32x4_t y = *(const u32x4_t*)(scr + roff + j * 1024);
+      if (j == 1) y = (u32x4_t){y[2], y[3], y[0], y[1]};
+      if (CHECK && (m >= p.M || !col_ok)) continue;
+      const long long coff = (one_batch ? off0 + (long long)(m - mw0) * p.cm.ld : p.cm.off(m)) + n;
+      if (p.resid) {
+        const u32x4_t x = *(const u32x4_t*)(p.resid + coff);
+        if (p.gate) {
+          // diffusers computes  x = x + gate * y  with y, gate, x bf16 tensors: the product is rounded, then the sum
+          if (!one_batch) {
+            const u32x4_t gg = *(const u32x4_t*)(p.gate + (long long)(m / p.cm.rpb) * p.ldg + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g[2 * i] = bf_lo(gg[i]); g[2 * i + 1] = bf_hi(gg[i]); }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            y[i] = pack2bf(bf_lo(x[i]) + rbf(g[2 * i] * bf_lo(y[i])), bf_hi(x[i]) + rbf(g[2 * i + 1] * bf_hi(y[i])));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = pack2bf(bf_lo(x[i]) + bf_lo(y[i]), bf_hi(x[i]) + bf_hi(y[i]));
+        }
+      }
+      *(u32x4_t*)((bf16_t*)p.C + coff) = y;
+    }
+  }
+}
+
+template <int MI, int TM>
+__device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[4],
+                                                char* scr) {
+  if (m0 + TM <= p.M && n0 + TM <= p.N) staged_rows<MI, TM, false>(p, m0, mw0, n0, nw0, l, acc, scr);
+  else staged_rows<MI, TM, true>(p, m0, mw0, n0, nw0, l, acc, scr);
+}
+
 // tile selection shared by both kernels: XCD-contiguous, grouped along M for L2 reuse of the W panel
-__device__ __forceinline__ void pick_tile(const GemmKArgs& p, int& tm, int& tn) {
+__device__ __forceinline__ void pick_tile(const GemmKArgs& p, int bid, int& tm, int& tn) {
   const int nwg = p.tiles_m * p.tiles_n;
-  const int wg = xcd_remap((int)blockIdx.x, nwg);
+  const int wg = xcd_remap(bid, nwg);
   constexpr int GROUP_M = 8;
   const int in_group = GROUP_M * p.tiles_n;
   const int gid = wg / in_group;
@@ -201,7 +307,7 @@ __device__ __forceinline__ void pick_tile(const GemmKArgs& p, int& tm, int& tn) 
 
 template <int MODE>  // 0: batched rows, 1: conv3x3 implicit GEMM
 __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 4 * 2048];  // A0 A1 B0 B1 + one epilogue slab per wave
   const int w = wave_id();
   const int l = lane_id();
   const int wr = w >> 1, wc = w & 1;
@@ -295,7 +401,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
   }
 
   // ---- epilogue: lane holds C[m = .. + (l&15)][n = .. + (l>>4)*4 + 0..3] ----
-  wave_epilogue<4, BM>(p, m0, m0 + wr * 64 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
+  if (p.wide) staged_epilogue<4, BM>(p, m0, m0 + wr * 64, n0, n0 + wc * 64, l, acc, smem + 4 * TILE_BYTES + w * 2048);
+  else wave_epilogue<4, BM>(p, m0, m0 + wr * 64 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
 }
 
 
@@ -337,57 +444,75 @@ constexpr int T2_BUF = 4 * T2_HALF;            // A0 A1 B0 B1
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * T2_BUF];
+  __shared__ __attribute__((aligned(16))) char smem[2 * T2_BUF + 8 * 2048];   // + one 2 KiB epilogue slab per wave
   const int w = wave_id();
   const int l = lane_id();
   const int wr = w >> 2, wc = w & 3;
-  int tm, tn;
-  pick_tile(p, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
+  // ---- persistent: this workgroup computes tiles vb, vb + P, vb + 2P ... (P = gridDim.x, a multiple of 8 whenever a
+  // workgroup has more than one tile, so every tile of a workgroup maps to the XCD the workgroup runs on).  The LDS-DMA
+  // stream runs CONTINUOUSLY across tile boundaries: the last two K-steps of a tile already fetch K-steps 0 and 1 of
+  // the next one, so the epilogue's stores overlap the next tile's loads and only the first tile pays a prologue.
+  const int P = (int)gridDim.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int vb = (int)blockIdx.x;
 
-  const long long a0 = MODE == 0 ? p.am.off(m0) : p.cv.off(m0);
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a0), 0, 0x7ffffff0u, 0x00020000);
-  const int wrows = min(256, p.N - n0);
-  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0,
-                                                                 (unsigned)((long long)wrows * p.K * 2), 0x00020000);
-  // ---- staging role: every piece has 16 chunks of 8 rows; this wave moves chunks c = 2w, 2w+1 of each piece.
+  // ---- load state of ONE tile (switched in place two K-steps before the tile's first MFMA)
+  __amdgpu_buffer_rsrc_t rsA, rsW;
+  unsigned vo[4][2];          // [piece: 0 alpha, 1 beta, 2 gamma, 3 delta][chunk] global byte offset (per lane)
+  int lo[4][2];               // LDS byte offset of the chunk inside a K-tile buffer (wave-uniform, tile-independent)
+  // staging role: every piece has 16 chunks of 8 rows; this wave moves chunks c = 2w, 2w+1 of each piece.
   // chunk c -> operand half (c>>3) and an 8-row group inside it:
   //   alpha: rows 8*(c&7)              delta: rows 64 + 8*(c&7)
   //   beta : sub=c&7: rows 8*sub (sub<4) | 64 + 8*(sub-4)      gamma: rows 32 + 8*sub | 96 + 8*(sub-4)
-  unsigned vo[4][2];          // [piece: 0 alpha, 1 beta, 2 gamma, 3 delta][chunk] global byte offset (per lane)
-  int lo[4][2];               // LDS byte offset of the chunk inside a K-tile buffer (wave-uniform)
+  auto chunk_row0 = [&](int pc, int sub) {
+    if (pc == 0) return 8 * sub;
+    if (pc == 3) return 64 + 8 * sub;
+    if (pc == 1) return sub < 4 ? 8 * sub : 64 + 8 * (sub - 4);
+    return sub < 4 ? 32 + 8 * sub : 96 + 8 * (sub - 4);
+  };
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc)
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
-      const int c = w * 2 + c2, half = c >> 3, sub = c & 7;
-      int row0;                                            // first row of the chunk inside its half
-      if (pc == 0) row0 = 8 * sub;
-      else if (pc == 3) row0 = 64 + 8 * sub;
-      else if (pc == 1) row0 = sub < 4 ? 8 * sub : 64 + 8 * (sub - 4);
-      else row0 = sub < 4 ? 32 + 8 * sub : 96 + 8 * (sub - 4);
-      const int row = row0 + (l >> 3);                     // this lane's row inside the half
-      const int slot = (l & 7) ^ ((row >> 1) & 7);
-      const bool isA = pc == 0 || pc == 3;
-      if (isA) {
-        const int ra = min(m0 + half * 128 + row, p.M - 1);
-        vo[pc][c2] = (unsigned)(((MODE == 0 ? p.am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
-      } else {
-        const int rw = min(half * 128 + row, wrows - 1);
-        vo[pc][c2] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
-      }
-      lo[pc][c2] = ((isA ? 0 : 2) + half) * T2_HALF + row0 * 128;
+      const int c = w * 2 + c2, half = c >> 3;
+      lo[pc][c2] = ((pc == 0 || pc == 3 ? 0 : 2) + half) * T2_HALF + chunk_row0(pc, c & 7) * 128;
     }
+  auto load_state = [&](int tile) {
+    int tm, tn;
+    pick_tile(p, tile, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    // descriptors are based at the tile's first row, so operands of any size work with 32-bit in-tile offsets
+    const long long a0 = MODE == 0 ? p.am.off(m0) : p.cv.off(m0);
+    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a0), 0, 0x7ffffff0u, 0x00020000);
+    const int wrows = min(256, p.N - n0);
+    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0, (unsigned)((long long)wrows * p.K * 2),
+                                            0x00020000);
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const int c = w * 2 + c2, half = c >> 3;
+        const int row = chunk_row0(pc, c & 7) + (l >> 3);      // this lane's row inside the half
+        const int slot = (l & 7) ^ ((row >> 1) & 7);
+        if (pc == 0 || pc == 3) {
+          const int ra = min(m0 + half * 128 + row, p.M - 1);  // clamp: rows past the edge are never stored
+          vo[pc][c2] = (unsigned)(((MODE == 0 ? p.am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
+        } else {
+          const int rw = min(half * 128 + row, wrows - 1);
+          vo[pc][c2] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
+        }
+      }
+  };
   const int cchunks = MODE == 1 ? p.cv.Cin / BK : 1;
-  const int nk = p.K / BK;
-  auto issue = [&](int pc, int kt) {
+  const int nk = p.K / BK;                          // >= 4 (use_t256)
+  auto issue = [&](int pc, int kt, int buf) {       // K-step kt of the tile in the load state -> LDS buffer buf
     int soff = kt * (BK * 2);
     if (MODE == 1 && (pc == 0 || pc == 3)) {
       const int tap = kt / cchunks, cc = kt - tap * cchunks;
       const int r = tap / 3, sx = tap - r * 3;
       soff = ((r * p.cv.Wp + sx) * p.cv.Cin + cc * BK) * 2;
     }
-    DRAG_LDS char* d = (DRAG_LDS char*)smem + (kt & 1) * T2_BUF;
+    DRAG_LDS char* d = (DRAG_LDS char*)smem + buf * T2_BUF;
     if (pc == 0 || pc == 3) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + lo[pc][0]), 16, vo[pc][0], soff, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + lo[pc][1]), 16, vo[pc][1], soff, 0, 0);
@@ -402,84 +527,118 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
   const int fx = wr * T2_HALF + (l & 15) * 128;                                   // + mi*2048
   const int fw = (2 + (wc >> 1)) * T2_HALF + ((wc & 1) * 64 + (l & 15)) * 128;    // + ni*2048
 
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // ---- TWO phases per K-tile (32 MFMAs each), 4 barriers per K-tile:
-  //   phase A: reads W cols 0-63 + X rows 0-63 (16 x b128), issues delta(t+1),            quadrants (0,0) (0,1)
-  //   phase B: reads X rows 64-127 (8),                     issues alpha,beta,gamma(t+2), quadrants (1,1) (1,0)
+  // ---- TWO phases per K-step (32 MFMAs each), 4 barriers per K-step:
+  //   phase A: reads W cols 0-63 + X rows 0-63 (16 x b128), issues delta(g+1),            quadrants (0,0) (0,1)
+  //   phase B: reads X rows 64-127 (8),                     issues alpha,beta,gamma(g+2), quadrants (1,1) (1,0)
   // (16 reads + 2 DMA | 8 reads + 6 DMA: both load segments fit under the partner group's 32-MFMA segment.)
-  // stream:  B(t): a,b,g(t+2)   A(t+1): d(t+2)   B(t+1): a,b,g(t+3) ...   every wait leaves 4 younger pieces: vmcnt(8)
-  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
-  if (nk > 1) {
-    issue(0, 1); issue(1, 1); issue(2, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // alpha, beta, gamma (0) landed
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  // stream:  B(g): a,b,g(g+2)   A(g+1): d(g+2)   B(g+1): a,b,g(g+3) ...   every wait leaves 4 younger pieces: vmcnt(8).
+  // g counts K-steps over ALL tiles of this workgroup (buffer = g & 1).
+  load_state(vb);
+  issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0); issue(3, 0, 0);
+  issue(0, 1, 1); issue(1, 1, 1); issue(2, 1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // alpha, beta, gamma (0) landed
   T2_BARRIER();
   if (wr == 1) T2_BARRIER();                       // stagger the second wave group by one barrier
 
   bf16x8_t xf[4][2], w0[2][2], w1[2][2];
+  f32x4_t acc[8][4];
 #define T2_MMA(wsel, mh, nh) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
       acc[4 * (mh) + mi][2 * (nh) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsel[ni][ks], xf[mi][ks], \
                                                                                   acc[4 * (mh) + mi][2 * (nh) + ni], 0, 0, 0)
-#define T2_WAIT(full) do { if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
-                           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+  // wait until at most `8 + extra` VMEM operations are outstanding; with nothing younger in the stream: drain.
+  // Right after an interior tile's epilogue the >= 16 stores it issued sit between the piece waited for and the
+  // youngest pieces (VMEM operations of a wave retire in issue order), so 16 more may stay in flight.
+#define T2_WAIT(more, relaxed) do { if (!(more)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+                                    else if (relaxed) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); \
+                                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
 
-  for (int t = 0; t < nk; ++t) {
-    const char* sb = smem + (t & 1) * T2_BUF;
-    // ================= phase A =================
+  int g = 0;
+  bool after_interior_epilogue = false;
+  for (;;) {
+    const bool have_next = vb + P < nwg;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        w0[ni][ks] = *(const bf16x8_t*)(sb + fw + ni * 2048 + ((p0 ^ (ks * 4)) << 4));
-        w1[ni][ks] = *(const bf16x8_t*)(sb + fw + (2 + ni) * 2048 + ((p0 ^ (ks * 4)) << 4));
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nk; ++t, ++g) {
+      const char* sb = smem + (g & 1) * T2_BUF;
+      const bool more1 = t + 1 < nk || have_next;      // K-step g+1 exists
+      const bool more2 = t + 2 < nk || have_next;      // K-step g+2 exists
+      const bool relaxed = after_interior_epilogue && t == 0;
+      // ================= phase A =================
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          w0[ni][ks] = *(const bf16x8_t*)(sb + fw + ni * 2048 + ((p0 ^ (ks * 4)) << 4));
+          w1[ni][ks] = *(const bf16x8_t*)(sb + fw + (2 + ni) * 2048 + ((p0 ^ (ks * 4)) << 4));
+        }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + mi * 2048 + ((p0 ^ (ks * 4)) << 4));
+      if (more1) issue(3, t + 1 < nk ? t + 1 : 0, (g + 1) & 1);   // delta(g+1): A rows 64-127 of the other buffer, last read in B(g-1)
+      T2_WAIT(more1, relaxed);                          // delta(g) landed (read in phase B)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      T2_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+      T2_MMA(w0, 0, 0);
+      T2_MMA(w1, 0, 1);
+      __builtin_amdgcn_s_setprio(0);
+      T2_BARRIER();
+      // ================= phase B =================
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + (4 + mi) * 2048 + ((p0 ^ (ks * 4)) << 4));
+      // every later load of this tile has been issued: from here on the stream fetches the next tile
+      if (t == nk - 2 && have_next) load_state(vb + P);
+      if (more2) {                                     // slots last read in phase A of this K-step
+        const int kt = t + 2 < nk ? t + 2 : t + 2 - nk;
+        issue(0, kt, g & 1); issue(1, kt, g & 1); issue(2, kt, g & 1);
       }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + mi * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 1 < nk) issue(3, t + 1);                 // delta(t+1): A rows 64-127 of the other buffer, last read in B(t-1)
-    T2_WAIT(t + 1 < nk);                              // delta(t) landed (read in phase B)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    T2_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-    T2_MMA(w0, 0, 0);
-    T2_MMA(w1, 0, 1);
-    __builtin_amdgcn_s_setprio(0);
-    T2_BARRIER();
-    // ================= phase B =================
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) xf[mi][ks] = *(const bf16x8_t*)(sb + fx + (4 + mi) * 2048 + ((p0 ^ (ks * 4)) << 4));
-    if (t + 2 < nk) { issue(0, t + 2); issue(1, t + 2); issue(2, t + 2); }   // slots last read in phase A of this tile
-    T2_WAIT(t + 2 < nk);                              // alpha, beta, gamma (t+1) landed (read in A of the next tile)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    T2_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-    T2_MMA(w1, 1, 1);
-    T2_MMA(w0, 1, 0);
-    __builtin_amdgcn_s_setprio(0);
-    T2_BARRIER();
+      T2_WAIT(more2, relaxed);                          // alpha, beta, gamma (g+1) landed (read in A of the next K-step)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      T2_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+      T2_MMA(w1, 1, 1);
+      T2_MMA(w0, 1, 0);
+      __builtin_amdgcn_s_setprio(0);
+      T2_BARRIER();
+    }
+    if (!have_next && wr == 0) T2_BARRIER();         // balance the stagger before the last epilogue
+    int tm, tn;
+    pick_tile(p, vb, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    if (p.wide) staged_epilogue<8, 256>(p, m0, m0 + wr * 128, n0, n0 + wc * 64, l, acc, smem + 2 * T2_BUF + w * 2048);
+    else wave_epilogue<8, 256>(p, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
+    if (!have_next) break;
+    after_interior_epilogue = m0 + 256 <= p.M && n0 + 256 <= p.N;
+    vb += P;
   }
 #undef T2_MMA
 #undef T2_WAIT
-  if (wr == 0) T2_BARRIER();                       // balance the stagger
-
-  wave_epilogue<8, 256>(p, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
 }
 
 }  // namespace
 
 // tile policy: the 256x256 kernel needs enough tiles to fill 256 CUs and rows to amortise its prologue
 static bool use_t256(long long M, int N, int K) { return M >= 2048 && N >= 256 && K >= 256 && getenv("DRAG_GEMM_T128") == nullptr; }
+
+// persistent grid of the 256x256 kernel: one workgroup per CU (128 KiB of LDS each), fewer when there are fewer tiles
+static int t256_grid(int ntiles) {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    ncu = n & ~7;                                  // multiple of the 8 XCDs, so a workgroup's tiles stay on its XCD's L2
+    if (ncu == 0) ncu = 8;
+  }
+  if (getenv("DRAG_GEMM_NONPERSISTENT") != nullptr) return ntiles;
+  return ntiles < ncu ? ntiles : ncu;
+}
 
 static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, const void* bias, const void* gate,
                        const void* resid, int M, int N, int K, int ldc, int c_rpb, long long c_bs, int ldg, int act,
@@ -490,6 +649,9 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   k.cm.rpb = c_rpb > 0 ? c_rpb : M; k.cm.bs = c_bs; k.cm.ld = ldc;
   k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
   k.a_bytes = 0; k.w_bytes = 0;
+  k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&
+           (!resid || ((uintptr_t)resid & 15) == 0) && (!gate || (((uintptr_t)gate & 15) == 0 && ldg % 8 == 0)) &&
+           getenv("DRAG_GEMM_NARROW") == nullptr;
   k.tiles_m = (M + BM - 1) / BM; k.tiles_n = (N + BN - 1) / BN;
   return k.tiles_m * k.tiles_n;
 }
@@ -518,7 +680,7 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
              "drag_gemm_bf16: tile span too large for 32-bit offsets");
   if (use_t256(a->M, a->N, a->K)) {
     k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
-    hipLaunchKernelGGL(gemm_bf16_t256<0>, dim3(k.tiles_m * k.tiles_n), dim3(512), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(gemm_bf16_t256<0>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
   } else {
     hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
   }
@@ -546,7 +708,7 @@ extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
   DRAG_CHECK(((long long)(BM * a->stride + 3 * a->Wp * 2) * a->Cin) * 2 < (1ll << 30), "drag_conv3x3_bf16: tile span too large");
   if (use_t256(M, a->Cout, 9 * a->Cin)) {
     k.tiles_m = (int)((M + 255) / 256); k.tiles_n = (a->Cout + 255) / 256;
-    hipLaunchKernelGGL(gemm_bf16_t256<1>, dim3(k.tiles_m * k.tiles_n), dim3(512), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(gemm_bf16_t256<1>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
   } else
     hipLaunchKernelGGL(gemm_bf16_t128<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
   DRAG_LAUNCH_CHECK();

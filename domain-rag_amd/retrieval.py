@@ -169,7 +169,7 @@ class StemStyle:
             except ImportError:   # no OpenCV in this image: PIL bilinear (resize kernels differ slightly from cv2)
                 from PIL import Image
                 img = np.asarray(Image.open(image_path).convert("RGB").resize((256, 256), Image.BILINEAR))
-            x = torch.from_numpy(np.ascontiguousarray(img)).float().permute(2, 0, 1).unsqueeze(0) / 255.0
+            x = torch.from_numpy(np.array(img, copy=True)).float().permute(2, 0, 1).unsqueeze(0) / 255.0
             return self(x)[0].cpu().numpy()
         except Exception as e:  # reference behaviour: log and skip
             print(f"计算ResNet特征时出错: {e}, 图像: {image_path}")

@@ -17,11 +17,11 @@ for (M, N, K) in shapes:
     A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     res = []
-    for env in ({}, {"DRAG_GEMM_P4": "1"}):
-        for k in ("DRAG_GEMM_P4", "DRAG_GEMM_T128"): os.environ.pop(k, None)
+    for env in ({}, {"DRAG_GEMM_NONPERSISTENT": "1"}):
+        for k in ("DRAG_GEMM_NONPERSISTENT", "DRAG_GEMM_T128"): os.environ.pop(k, None)
         os.environ.update(env)
         ms = min(bench(lambda: ops.gemm(A, W, out=C)) for _ in range(3))
         res.append(2 * M * N * K / ms / 1e9)
-    for k in ("DRAG_GEMM_P4", "DRAG_GEMM_T128"): os.environ.pop(k, None)
-    print(f"gemm {M}x{N}x{K}: 2-phase {res[0]:.0f} | 4-phase {res[1]:.0f} TF/s", flush=True)
+    for k in ("DRAG_GEMM_NONPERSISTENT", "DRAG_GEMM_T128"): os.environ.pop(k, None)
+    print(f"gemm {M}x{N}x{K}: persistent {res[0]:.0f} | one tile per workgroup {res[1]:.0f} TF/s", flush=True)
     del A, W, C

@@ -293,3 +293,39 @@ def test_conv3x3_t256(gpu):
     ops.conv3x3(xp.to(gpu), w.permute(0, 2, 3, 1).contiguous().to(gpu), y, B=B, Ho=H, Wo=W, Hp=H + 2, Wp=W + 2, Cin=Ci, Cout=Co,
                 bias=b.to(gpu))
     assert _rel(y.cpu().permute(0, 3, 1, 2), ref) < 8e-3
+
+
+def test_gemm_staged_epilogue_equals_fragment_epilogue(gpu):
+    """the LDS-transposed (16-B store) epilogue and the fragment-layout (8-B store) one must agree bit for bit:
+    same fp32 sums, same rounding points — plain, bias+act, gated residual over batched rows whose tiles straddle
+    batch boundaries, edge tiles (N % 256 != 0, M % 256 != 0), both tile sizes"""
+    import os
+    from domain_rag_amd import ops
+
+    def both(fn):
+        wide = fn().clone()
+        os.environ["DRAG_GEMM_NARROW"] = "1"
+        try:
+            narrow = fn().clone()
+        finally:
+            del os.environ["DRAG_GEMM_NARROW"]
+        assert torch.equal(wide, narrow)
+        return wide
+
+    for (M, N, K) in [(2321, 520, 320), (5000, 3072, 512), (300, 136, 128)]:
+        a, w, b = _randn((M, K), 31).to(gpu), _randn((N, K), 32, 0.05).to(gpu), _randn((N,), 33).to(gpu)
+        both(lambda: ops.gemm(a, w))
+        both(lambda: ops.gemm(a, w, bias=b, act=1, act_n0=64))
+    for (B, St, Si, D, Kk) in [(3, 100, 1500, 512, 256), (2, 24, 200, 256, 128)]:
+        S = St + Si
+        x, aa = _randn((B, S, D), 7), _randn((B, S, Kk), 8).to(gpu)
+        ww, bb, mod = _randn((D, Kk), 9, 0.1).to(gpu), _randn((D,), 10).to(gpu), _randn((B, 3 * D), 11).to(gpu)
+
+        def run():
+            xd = x.to(gpu)
+            ops.gemm(aa.view(-1)[St * Kk:], ww, out=xd.view(-1)[St * D:], bias=bb, M=B * Si, a_rows_per_batch=Si,
+                     a_batch_stride=S * Kk, lda=Kk, c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D,
+                     gate=mod.view(-1)[D:], resid=xd.view(-1)[St * D:], ldg=3 * D)
+            return xd
+        both(run)
+        both(lambda: ops.gemm(aa.view(-1, Kk), ww, resid=x.to(gpu).view(-1, D)))
