@@ -28,6 +28,15 @@ class ConvArgs(ctypes.Structure):
                [(n, c_int) for n in ("B", "Ho", "Wo", "Hp", "Wp", "Cin", "Cout", "ldy", "stride", "oy", "ox", "act")]
 
 
+class ResampleArgs(ctypes.Structure):
+    """mirror of ``drag_resample_args``"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("tmp", c_void_p), ("batch", c_int), ("channels", c_int),
+                ("src_h", c_int), ("src_w", c_int), ("src_image_stride", c_int64), ("src_row_stride", c_int),
+                ("out_h", c_int), ("out_w", c_int), ("dst_image_stride", c_int64), ("dst_row_stride", c_int),
+                ("kx", c_void_p), ("bx", c_void_p), ("ksize_x", c_int), ("ky", c_void_p), ("by", c_void_p), ("ksize_y", c_int),
+                ("tmp_row0", c_int), ("tmp_rows", c_int), ("src_col0", c_int), ("src_row0", c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/domainrag_hip.h declares
 SIGNATURES = {
     "drag_version": (c_int, []),
@@ -46,6 +55,7 @@ SIGNATURES = {
     "drag_cosine_topk_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "drag_l2_normalize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     "drag_patchify_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
+    "drag_resample_u8": (c_int, [ctypes.POINTER(ResampleArgs), c_void_p]),
     "drag_scale_sum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "drag_resnet_stem_style_workspace_bytes": (c_int64, [c_int] * 3),
     "drag_resnet_stem_style_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p, c_void_p]),

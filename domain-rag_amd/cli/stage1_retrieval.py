@@ -45,6 +45,8 @@ def build_parser():
     p.add_argument("--clip-weights", type=str, default=None, help="openai CLIP ViT-B/32 state_dict (.pt); default: synthetic")
     p.add_argument("--resnet-weights", type=str, default=None, help="torchvision resnet50 state_dict (.pt); default: synthetic")
     p.add_argument("--embed-batch", type=int, default=256)
+    p.add_argument("--host-preprocess", action="store_true",
+                   help="resize on the host with PIL like the reference (default: PIL-exact resize on the GPU; same bits)")
     p.add_argument("--style-cache", type=str, default=None,
                    help="npz of corpus style vectors reused across queries and runs (default: <output-dir>/style_cache.npz)")
     return p
@@ -190,6 +192,8 @@ def main(argv=None):
     rank = dist.get_rank() if world > 1 else 0
     print(f"使用设备: {device}")
     model, preprocess = R.load_clip("ViT-B/32", device, weights=args.clip_weights)
+    if not args.host_preprocess:
+        preprocess = R.load_clip_device_preprocess(device)
     stem = R.StemStyle(torch.load(args.resnet_weights, map_location="cpu") if args.resnet_weights else None, device)
     feats, paths = {}, {}
     if args.dataset_source in ("coco", "both"):

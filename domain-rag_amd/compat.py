@@ -110,7 +110,7 @@ class FluxPriorReduxPipeline(_Pipe):
             return p or ""
 
         t5, pooled = self.text.get(one(prompt), one(prompt_2))
-        x = E.siglip_input(images, self.vit_cfg.image_size).to(self.device)
+        x = E.siglip_input_device(images, self.vit_cfg.image_size, self.device)
         pe, pp = self.prior(x, t5, pooled, per_image(prompt_embeds_scale), per_image(pooled_prompt_embeds_scale), group=n)
         return PriorOutput(prompt_embeds=pe, pooled_prompt_embeds=pp)
 

@@ -172,7 +172,7 @@ __global__ void timestep_embedding_kernel(const float* t, bf16_t* out, int B, in
 
 // uint8 RGB [B, H, W, 3] -> normalised patch rows [B*(H/P)*(W/P), ldo] bf16, k = c*P*P + py*P + px
 // (the flattening of a Conv2d(3, D, P, stride=P) weight), columns >= 3*P*P zero-filled.
-struct PatchArgs { const uint8_t* img; bf16_t* out; int B, H, W, P, ldo; float mean[3], istd[3]; };
+struct PatchArgs { const uint8_t* img; bf16_t* out; int B, H, W, P, ldo; float mean[3], std[3]; };
 __global__ __launch_bounds__(256) void patchify_kernel(PatchArgs p) {
   const int gh = p.H / p.P, gw = p.W / p.P;
   const long long total = (long long)p.B * gh * gw * p.ldo;
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchArgs p) {
       const long long t = row / gw;
       const int ph = (int)(t % gh), b = (int)(t / gh);
       const uint8_t u = p.img[(((long long)b * p.H + ph * p.P + py) * p.W + pw * p.P + px) * 3 + c];
-      v = ((float)u * (1.0f / 255.0f) - p.mean[c]) * p.istd[c];
+      // ToTensor then Normalize as torch computes them: two IEEE divisions (u * (1/255) differs in 126 of 256 values)
+      v = ((float)u / 255.0f - p.mean[c]) / p.std[c];
     }
     p.out[i] = f2bf(v);
   }
@@ -293,7 +294,7 @@ extern "C" int drag_patchify_u8(const void* img, void* out, int32_t B, int32_t H
   DRAG_CHECK(B > 0 && P > 0 && H >= P && W >= P && ldo >= 3 * P * P, "drag_patchify_u8: bad shape");
   PatchArgs p;
   p.img = (const uint8_t*)img; p.out = (bf16_t*)out; p.B = B; p.H = H; p.W = W; p.P = P; p.ldo = ldo;
-  for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.istd[c] = 1.0f / std3[c]; }
+  for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.std[c] = std3[c]; }
   const long long total = (long long)B * (H / P) * (W / P) * ldo;
   hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p);
   DRAG_LAUNCH_CHECK();

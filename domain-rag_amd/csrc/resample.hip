@@ -1,0 +1,149 @@
+// resample.hip — Pillow-exact 8-bit separable image resample on gfx950 (byte / int32 work, HBM-bound).
+//
+// Replaces PIL.Image.resize (libImaging ImagingResample, 8bpc paths) where the reference resizes every image that
+// enters a vision tower: openai-CLIP `_transform` Resize(224, BICUBIC)+CenterCrop behind clip.load
+// (retrieval/clip100_resnet_style_all_shots.py:209,171,270-287) and SiglipImageProcessor's 384x384 BICUBIC inside
+// FluxPriorReduxPipeline (batch_generate_flux_kshot.py:459-465, outpainting_updown_sampling_redux.py:1237-1243).
+// The host computes Pillow's 22-bit fixed-point coefficient tables (domain-rag_amd/resample.py); the kernels apply
+// them exactly as Pillow does:  out = clamp8(((1 << 21) + sum_k pixel[first + k] * kk[k]) >> 22), horizontal pass
+// first (rounded to uint8, only the rows the vertical pass reads), then vertical.  Results are bit-identical to PIL,
+// so embeddings — and therefore top-k indices — do not depend on where the resize ran.
+//
+// Layout: interleaved HWC uint8 with explicit row / image strides (a crop is a pointer offset + sliced tables).
+// Horizontal pass: one thread per output pixel (all channels), windows of neighbouring threads overlap -> L1 hits.
+// Vertical pass: one thread per 4 consecutive output bytes of a row -> fully coalesced 4-byte loads per tap.
+#include "drag_common.h"
+
+namespace {
+
+constexpr int RS_PREC = 32 - 8 - 2;   // Pillow PRECISION_BITS
+
+__device__ __forceinline__ uint32_t clamp8(int v) { return (uint32_t)min(max(v >> RS_PREC, 0), 255); }
+
+struct RsArgs {
+  const uint8_t* src;
+  uint8_t* dst;
+  const int32_t* kk;      // [n_out, ksize]
+  const int32_t* bounds;  // [n_out, 2] = (first source index, tap count)
+  int ksize, n_out;       // outputs along the resampled axis
+  int lines;              // horizontal: rows per image; vertical: bytes per output row (out_w * channels)
+  int channels;
+  int first_off;          // subtracted from bounds[.][0] (vertical pass over a row-window temp image)
+  long long src_img, dst_img;
+  int src_row, dst_row;   // strides in bytes
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void resample_h_kernel(RsArgs p) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= p.n_out) return;
+  const int first = p.bounds[2 * x] - p.first_off, n = p.bounds[2 * x + 1];
+  const int32_t* k = p.kk + (long long)x * p.ksize;
+  const uint8_t* s = p.src + b * p.src_img + (long long)y * p.src_row + (long long)first * C;
+  int acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 1 << (RS_PREC - 1);
+  for (int i = 0; i < n; ++i) {
+    const int w = k[i];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] += (int)s[i * C + c] * w;
+  }
+  uint8_t* d = p.dst + b * p.dst_img + (long long)y * p.dst_row + (long long)x * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) d[c] = (uint8_t)clamp8(acc[c]);
+}
+
+__global__ __launch_bounds__(256) void resample_v_kernel(RsArgs p) {
+  const int q = blockIdx.x * 256 + threadIdx.x;       // 4-byte group inside the output row
+  const int y = blockIdx.y, b = blockIdx.z;
+  const int x0 = q * 4;
+  if (x0 >= p.lines) return;
+  const int first = p.bounds[2 * y] - p.first_off, n = p.bounds[2 * y + 1];
+  const int32_t* k = p.kk + (long long)y * p.ksize;
+  const uint8_t* s = p.src + b * p.src_img + (long long)first * p.src_row + x0;
+  uint8_t* d = p.dst + b * p.dst_img + (long long)y * p.dst_row + x0;
+  const bool full = x0 + 4 <= p.lines && ((((uintptr_t)s | (uintptr_t)d) & 3) == 0) && (p.src_row & 3) == 0;
+  int a0 = 1 << (RS_PREC - 1), a1 = a0, a2 = a0, a3 = a0;
+  if (full) {
+    for (int i = 0; i < n; ++i) {
+      const int w = k[i];
+      const uint32_t v = *(const uint32_t*)(s + (long long)i * p.src_row);
+      a0 += (int)(v & 255u) * w; a1 += (int)((v >> 8) & 255u) * w; a2 += (int)((v >> 16) & 255u) * w; a3 += (int)(v >> 24) * w;
+    }
+    *(uint32_t*)d = clamp8(a0) | (clamp8(a1) << 8) | (clamp8(a2) << 16) | (clamp8(a3) << 24);
+  } else {
+    const int m = min(4, p.lines - x0);
+    for (int j = 0; j < m; ++j) {
+      int a = 1 << (RS_PREC - 1);
+      for (int i = 0; i < n; ++i) a += (int)s[(long long)i * p.src_row + j] * k[i];
+      d[j] = (uint8_t)clamp8(a);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_window_kernel(const uint8_t* src, uint8_t* dst, int row_bytes, int src_row, int dst_row,
+                                                          long long src_img, long long dst_img) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= row_bytes) return;
+  dst[blockIdx.z * dst_img + (long long)blockIdx.y * dst_row + x] = src[blockIdx.z * src_img + (long long)blockIdx.y * src_row + x];
+}
+
+}  // namespace
+
+extern "C" int drag_resample_u8(const drag_resample_args* a, void* stream) {
+  DRAG_CHECK(a != nullptr && a->src && a->dst, "drag_resample_u8: null pointer");
+  DRAG_CHECK(a->batch > 0 && a->batch <= 65535 && a->channels >= 1 && a->channels <= 4, "drag_resample_u8: batch in [1, 65535], channels in [1, 4]");
+  DRAG_CHECK(a->src_h > 0 && a->src_w > 0 && a->out_h > 0 && a->out_w > 0 && a->out_h <= 65535 && a->src_h <= 65535,
+             "drag_resample_u8: sizes must be in [1, 65535]");
+  DRAG_CHECK((a->kx == nullptr) == (a->bx == nullptr) && (a->ky == nullptr) == (a->by == nullptr),
+             "drag_resample_u8: a pass needs both its weight and its bounds table");
+  DRAG_CHECK(a->kx || a->src_col0 + a->out_w <= a->src_w, "drag_resample_u8: without a horizontal pass the window must lie inside the source");
+  DRAG_CHECK(a->ky || a->src_row0 + a->out_h <= a->src_h, "drag_resample_u8: without a vertical pass the window must lie inside the source");
+  DRAG_CHECK(!(a->kx && a->ky) || (a->tmp && a->tmp_rows > 0 && a->tmp_row0 >= 0 && a->tmp_row0 + a->tmp_rows <= a->src_h),
+             "drag_resample_u8: both passes need tmp and a row window inside the source");
+  DRAG_CHECK((!a->kx || a->ksize_x > 0) && (!a->ky || a->ksize_y > 0), "drag_resample_u8: ksize must be positive");
+  const int C = a->channels;
+  hipStream_t st = (hipStream_t)stream;
+  RsArgs h{}, v{};
+  const int tmp_row_bytes = a->out_w * C;
+  if (a->kx) {
+    // rows that go through the horizontal pass: the vertical pass's window, or exactly the output rows
+    const int row0 = a->ky ? a->tmp_row0 : a->src_row0;
+    const int rows = a->ky ? a->tmp_rows : a->out_h;
+    h.src = a->src + (long long)row0 * a->src_row_stride;
+    h.dst = a->ky ? a->tmp : a->dst;
+    h.kk = a->kx; h.bounds = a->bx; h.ksize = a->ksize_x; h.n_out = a->out_w; h.lines = rows; h.channels = C; h.first_off = 0;
+    h.src_img = a->src_image_stride; h.src_row = a->src_row_stride;
+    h.dst_img = a->ky ? (long long)a->tmp_rows * tmp_row_bytes : a->dst_image_stride;
+    h.dst_row = a->ky ? tmp_row_bytes : a->dst_row_stride;
+    const dim3 grid((a->out_w + 255) / 256, rows, a->batch);
+    switch (C) {
+      case 1: hipLaunchKernelGGL(resample_h_kernel<1>, grid, dim3(256), 0, st, h); break;
+      case 2: hipLaunchKernelGGL(resample_h_kernel<2>, grid, dim3(256), 0, st, h); break;
+      case 3: hipLaunchKernelGGL(resample_h_kernel<3>, grid, dim3(256), 0, st, h); break;
+      default: hipLaunchKernelGGL(resample_h_kernel<4>, grid, dim3(256), 0, st, h); break;
+    }
+    DRAG_LAUNCH_CHECK();
+  }
+  if (a->ky) {
+    v.src = a->kx ? a->tmp : a->src + (long long)a->src_col0 * C;
+    v.dst = a->dst;
+    v.kk = a->ky; v.bounds = a->by; v.ksize = a->ksize_y; v.n_out = a->out_h; v.lines = tmp_row_bytes; v.channels = C;
+    v.first_off = a->kx ? a->tmp_row0 : 0;
+    v.src_img = a->kx ? (long long)a->tmp_rows * tmp_row_bytes : a->src_image_stride;
+    v.src_row = a->kx ? tmp_row_bytes : a->src_row_stride;
+    v.dst_img = a->dst_image_stride; v.dst_row = a->dst_row_stride;
+    const dim3 grid(((tmp_row_bytes + 3) / 4 + 255) / 256, a->out_h, a->batch);
+    hipLaunchKernelGGL(resample_v_kernel, grid, dim3(256), 0, st, v);
+    DRAG_LAUNCH_CHECK();
+  }
+  if (!a->kx && !a->ky) {     // same size: Pillow returns a copy
+    const dim3 grid((tmp_row_bytes + 255) / 256, a->out_h, a->batch);
+    hipLaunchKernelGGL(copy_window_kernel, grid, dim3(256), 0, st,
+                       a->src + (long long)a->src_row0 * a->src_row_stride + (long long)a->src_col0 * C, a->dst, tmp_row_bytes,
+                       a->src_row_stride, a->dst_row_stride, (long long)a->src_image_stride, (long long)a->dst_image_stride);
+    DRAG_LAUNCH_CHECK();
+  }
+  return 0;
+}

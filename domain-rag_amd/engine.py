@@ -45,6 +45,17 @@ def siglip_input(pil_images, size: int) -> torch.Tensor:
     return torch.from_numpy(np.stack(arr))
 
 
+def siglip_input_device(pil_images, size: int, device) -> torch.Tensor:
+    """same as ``siglip_input`` with the BICUBIC resize on the GPU (``drag_resample_u8``, bit-identical to PIL):
+    raw decoded bytes are uploaded once, nothing is resized on the host -> uint8 [n, size, size, 3] on device"""
+    from . import resample
+    out = torch.empty((len(pil_images), size, size, 3), dtype=torch.uint8, device=device)
+    for i, im in enumerate(pil_images):
+        raw = torch.from_numpy(np.array(im.convert("RGB"), dtype=np.uint8, copy=True)).to(device, non_blocking=True)
+        resample.siglip_resize_u8(raw, size, out=out[i])
+    return out
+
+
 class TextCache:
     """prompt -> (T5 embeds [Lt, J] bf16, pooled [P] bf16).  Real encodings are read from
     ``<model_root>/prompt_cache/<sha1>.pt`` (written once by any tool that has the text encoders); synthetic mode
@@ -134,5 +145,5 @@ class Engine:
     def prior_embeds(self, pil_images, prompt: str, embeds_scale, pooled_scale):
         """pipe_prior_redux(images, prompt=…, prompt_2="", prompt_embeds_scale=…, pooled_prompt_embeds_scale=…)"""
         t5, pooled = self.text.get(prompt, "")
-        imgs = siglip_input(pil_images, self.vit_cfg.image_size).to(self.dev)
+        imgs = siglip_input_device(pil_images, self.vit_cfg.image_size, self.dev)
         return self.prior(imgs, t5, pooled, embeds_scale, pooled_scale, group=len(pil_images))

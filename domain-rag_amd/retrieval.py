@@ -63,6 +63,16 @@ def clip_preprocess(pil_image, size: int = 224) -> torch.Tensor:
     return x.permute(2, 0, 1).contiguous()
 
 
+def clip_preprocess_device(pil_image, device="cuda", size: int = 224) -> torch.Tensor:
+    """same transform with the resize on the GPU: decoded RGB bytes are uploaded as they are and
+    ``drag_resample_u8`` (bit-identical to PIL's BICUBIC) resizes + centre-crops -> uint8 [size, size, 3] on device.
+    ToTensor / Normalize run inside ``drag_patchify_u8`` with torch's arithmetic, so ``encode_image`` of this equals
+    ``encode_image(clip_preprocess(pil_image))`` bit for bit."""
+    from . import resample
+    raw = torch.from_numpy(np.array(pil_image.convert("RGB"), dtype=np.uint8, copy=True)).to(device, non_blocking=True)
+    return resample.clip_preprocess_u8(raw, size)
+
+
 # ------------------------------------------------------------------ CLIP
 class ClipImageModel:
     """``model`` half of ``clip.load``; only the image tower is on Domain-RAG's path."""
@@ -93,6 +103,12 @@ def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None 
     else:
         g = init_generic_params(cfg, seed, device=device if str(device) != "cpu" else "cpu")
     return ClipImageModel(VitHIP(cfg, g, device)), clip_preprocess
+
+
+def load_clip_device_preprocess(device="cuda"):
+    """the ``preprocess`` to pass around when the resize should run on the GPU (corpus embedding)"""
+    import functools
+    return functools.partial(clip_preprocess_device, device=device)
 
 
 # ------------------------------------------------------------------ exact inner-product index

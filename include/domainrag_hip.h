@@ -164,6 +164,36 @@ int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, i
 int64_t drag_resnet_stem_style_workspace_bytes(int32_t B, int32_t H, int32_t W);
 int drag_resnet_stem_style_f32(const float* img, const float* conv_w, const float* bn_scale, const float* bn_shift,
                                float* out, int32_t B, int32_t H, int32_t W, float eps, void* workspace, void* stream);
+/* Pillow-exact 8-bit separable resample of interleaved HWC uint8 images (bit-identical to PIL.Image.resize for
+ * BILINEAR / BICUBIC / LANCZOS).  Replaces the PIL resize inside openai-CLIP's `preprocess` (Resize(224, BICUBIC) +
+ * CenterCrop; retrieval/clip100_resnet_style_all_shots.py:209,171,270-287) and SiglipImageProcessor's 384x384 BICUBIC
+ * inside FluxPriorReduxPipeline (batch_generate_flux_kshot.py:459-465, outpainting_updown_sampling_redux.py:1237-1243).
+ * The caller supplies Pillow's fixed-point tables (device int32): per output index `bounds` = (first source index,
+ * tap count) and `kk` = ksize weights of 22 fractional bits; out = clamp8(((1<<21) + sum pixel*kk) >> 22).  Both
+ * passes: horizontal into `tmp` (rows [tmp_row0, tmp_row0+tmp_rows) of the source, batch*tmp_rows*out_w*channels
+ * bytes), then vertical.  kx == NULL / ky == NULL skips that pass (that axis is then the window starting at
+ * src_col0 / src_row0); a crop of the resized image = tables sliced to the crop.  All strides in bytes. */
+typedef struct drag_resample_args {
+  const uint8_t* src;
+  uint8_t* dst;
+  uint8_t* tmp;
+  int32_t batch, channels;
+  int32_t src_h, src_w;
+  int64_t src_image_stride;
+  int32_t src_row_stride;
+  int32_t out_h, out_w;
+  int64_t dst_image_stride;
+  int32_t dst_row_stride;
+  const int32_t* kx;
+  const int32_t* bx;
+  int32_t ksize_x;
+  const int32_t* ky;
+  const int32_t* by;
+  int32_t ksize_y;
+  int32_t tmp_row0, tmp_rows;
+  int32_t src_col0, src_row0;
+} drag_resample_args;
+int drag_resample_u8(const drag_resample_args* args, void* stream);
 /* float NCHW (already normalised, e.g. clip `preprocess` output) -> patch rows like drag_patchify_u8 */
 int drag_patchify_f32_nchw(const float* img, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t ldo,
                            void* stream);
