@@ -19,6 +19,7 @@ from datetime import datetime
 import torch
 
 from ..engine import Engine, generator_noise, pack_noise
+from .. import hostlogic as H
 from ..retrieval import shard_bounds
 
 COCO_IMAGE_SCALE, TARGET_IMAGE_SCALE, COCO_TEXT_SCALE, TARGET_TEXT_SCALE = 0.8, 1.0, 1.0, 1.0
@@ -37,7 +38,8 @@ def build_parser():
     # additions
     p.add_argument("--lamainpaint_dir", type=str, default="./lamainpaint")
     p.add_argument("--model_root", type=str, default="./model")
-    p.add_argument("--coco_dir", type=str, default="./retrieval/coco")
+    p.add_argument("--coco_dir", type=str, default="./retrieval/coco/train2017",
+                   help="the reference's hard-coded coco_dataset_dir (batch_…:29)")
     p.add_argument("--synthetic-weights", action="store_true")
     p.add_argument("--tiny", action="store_true", help="test hook: tiny architectures, small images")
     p.add_argument("--num_inference_steps", type=int, default=STEPS)
@@ -48,46 +50,6 @@ def build_parser():
 
 DATASET_GROUPS = {"dataset1": ["ArTaxOr", "clipart1k"], "dataset2": ["DIOR", "FISH"], "dataset3": ["NEU-DET", "UODD"],
                   "dataset4": ["NWPU_VHR_10", "Camouflage"]}
-
-
-def resolve_path(path: str, roots) -> str | None:
-    """get_correct_image_path (:1332-1406) in spirit: try the path as written, then relative to the known roots"""
-    if os.path.exists(path):
-        return path
-    for r in roots:
-        for cand in (os.path.join(r, path), os.path.join(r, os.path.basename(path)),
-                     os.path.join(r, *path.replace("\\", "/").split("/")[-2:])):
-            if os.path.exists(cand):
-                return cand
-    return None
-
-
-def top5_from_json(results: dict, dataset: str, shot: int, sample: str, coco_dir: str, rng: random.Random):
-    """get_top5_similar_images_from_json (:1105-1330): results[ds]["<k>_shot"][sample] -> first entry ->
-    similar_images with rank <= 5, sorted by rank -> [(similarity, path, rank)].  Missing sample: 5 random corpus
-    images with similarities 1.0, 0.9, ... (NEU-DET raises instead)."""
-    node = results.get(dataset, {})
-    node = node.get(f"{shot}_shot", node)
-    entry = node.get(sample)
-    if entry is None:
-        for k in node:                       # sample-name variants (with / without extension, case)
-            if os.path.splitext(k)[0].lower() == sample.lower():
-                entry = node[k]
-                break
-    if entry is None:
-        if dataset == "NEU-DET":
-            raise ValueError(f"无法在NEU-DET数据集中找到样本 {sample} 或其类别")
-        print(f"将为样本 {sample} 使用随机COCO图像")
-        pool = []
-        for root, _, files in os.walk(coco_dir):
-            pool += [os.path.join(root, f) for f in files if f.lower().endswith((".jpg", ".jpeg", ".png"))]
-        pool.sort()
-        return [(1.0 - i * 0.1, p, i + 1) for i, p in enumerate(rng.sample(pool, min(5, len(pool))))]
-    if isinstance(entry, list):
-        entry = entry[0] if entry else {}
-    sims = [s for s in entry.get("similar_images", []) if int(s.get("rank", 99)) <= 5]
-    sims.sort(key=lambda s: s["rank"])
-    return [(float(s.get("similarity", 0.0)), s["image_path"], int(s["rank"])) for s in sims]
 
 
 def generate_one(engine: Engine, ref_path, target_path, out_path, rank, similarity, args, database):
@@ -161,18 +123,13 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
         sdir = os.path.join(base, name)
         os.makedirs(sdir, exist_ok=True)
         try:
-            top = top5_from_json(results, dataset, shot, name, args.coco_dir, rng)
+            top = H.top5_similar_images(results, name, dataset, shot, args.coco_dir, rng)
         except ValueError as ex:
             with open(os.path.join(sdir, "error.txt"), "w") as f:
                 f.write(str(ex))
             bad += 1
             continue
-        for sim, path, r in top:
-            real = resolve_path(path, [args.coco_dir, os.path.dirname(args.retrieval_results_dir), "."])
-            if real is None:
-                print(f"警告：找不到参考图像 {path}")
-                bad += 1
-                continue
+        for sim, real, r in top:          # paths are already fixed up and checked (hostlogic.correct_image_path)
             if generate_one(engine, real, target, os.path.join(sdir, f"generated_image_rank{r}.png"), r, sim, args, args.database):
                 ok += 1
             else:

@@ -56,7 +56,7 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
 
     # ---- stage 2
     _run("domain_rag_amd.cli.stage2_generate", ["--dataset", ds, "--shots", "1", "--retrieval_results_dir", str(rr), "--output_dir", "result",
-                                                "--coco_dir", "./retrieval/coco", "--synthetic-weights", "--tiny",
+                                                "--coco_dir", "./retrieval/coco/train2017", "--synthetic-weights", "--tiny",
                                                 "--num_inference_steps", "2"], cwd=root)
     base = root / "result" / f"{ds}_1shot_retrieval" / "results_coco_0.8_target_1.0_cocotext_1.0_targettext_1.0_20260101_000000"
     for r in range(1, 6):
