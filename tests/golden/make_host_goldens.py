@@ -119,6 +119,28 @@ def main():
                    "redux_prompt": s3.redux_prompt_params, "default_strength": s3.default_strength,
                    "default_guidance": s3.default_guidance_scale, "min_dim": s3.MIN_DIMENSION, "max_dim": s3.MAX_DIMENSION}
     g["create_gpu_process_id"] = s3.create_gpu_process_id("7", 3)
+    # ---- annotation lookup + bbox crops (get_bbox_and_original_image), on a synthetic COCO-format dataset
+    ann = {"images": [{"id": 7, "file_name": "abc_001.jpg"}, {"id": "8", "file_name": "zzz.png"}, {"id": 9, "file_name": "noann.jpg"},
+                      {"id": 10, "file_name": "missingfile.jpg"}, {"id": 11, "file_name": "sub/dir_img.jpg"}],
+           "annotations": [{"image_id": "7", "bbox": [1, 2, 3, 4], "category_id": 2}, {"image_id": 7, "bbox": [5.9, 6.2, 700, 8], "category_id": 9},
+                           {"image_id": 8, "bbox": ["-3", "5.9", "1000", "2"], "category_id": 2}, {"image_id": 10, "bbox": [0, 0, 1, 1], "category_id": 2},
+                           {"image_id": 11, "bbox": [63, 47, 0, 0], "category_id": 3}],
+           "categories": [{"id": 2, "name": "beetle"}, {"id": 3, "name": "moth"}]}
+    dtmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(dtmp, "DS", "annotations")); os.makedirs(os.path.join(dtmp, "DS", "train", "sub"))
+    json.dump(ann, open(os.path.join(dtmp, "DS", "annotations", "1_shot.json"), "w"))
+    sizes_on_disk = {"abc_001.jpg": (64, 48), "zzz.png": (100, 50), "noann.jpg": (8, 8), "sub/dir_img.jpg": (64, 48)}
+    for fn, sz in sizes_on_disk.items():
+        Image.new("RGB", sz).save(os.path.join(dtmp, "DS", "train", fn))
+    s3.datasets_dir = dtmp
+    s3.load_image = lambda path: Image.open(path).convert("RGB")     # diffusers.utils.load_image on a local file (stubbed module)
+    cases = []
+    for sid in ["abc_001", "abc", "xx_abc_001_yy", "zzz", "noann", "missingfile", "nope", "dir_img", "sub/dir_img"]:
+        img, crops, boxes, image_id, cats = s3.get_bbox_and_original_image("DS", sid, 1)
+        cases.append({"sample_id": sid, "found": img is not None, "image_size": list(img.size) if img is not None else None,
+                      "crop_sizes": [list(c.size) if c is not None else None for c in crops] if crops is not None else None,
+                      "bboxes": boxes, "image_id": image_id, "categories": cats})
+    g["get_bbox_and_original_image"] = {"annotations": ann, "files": {k: list(v) for k, v in sizes_on_disk.items()}, "cases": cases}
     # ---- stage 1 helpers
     paths = ["../../pipeline/datasets/coco/train2017/1.jpg", "../../datasets/coco/val2017/2.jpg", "./coco/3.jpg", 5, None,
              "/abs/../../datasets/coco/x.jpg"]
