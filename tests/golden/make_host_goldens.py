@@ -145,6 +145,39 @@ def main():
     paths = ["../../pipeline/datasets/coco/train2017/1.jpg", "../../datasets/coco/val2017/2.jpg", "./coco/3.jpg", 5, None,
              "/abs/../../datasets/coco/x.jpg"]
     g["clean_image_path"] = [{"in": p, "out": s1.clean_image_path(p)} for p in paths]
+    # ---- two-stage retrieval plumbing around the (stubbed) numeric kernels
+    # second stage: style vectors are injected, so this pins distance / stable sort / similarity / rank / path cleaning
+    rng = np.random.default_rng(5)
+    style = {f"../../datasets/coco/train2017/{i}.jpg": rng.standard_normal(128).astype(np.float32) for i in range(12)}
+    style["../../datasets/coco/train2017/3.jpg"] = style["../../datasets/coco/train2017/7.jpg"].copy()      # a tie
+    style["../../datasets/coco/train2017/5.jpg"] = None                                                      # unreadable
+    style["q.jpg"] = rng.standard_normal(128).astype(np.float32)
+    cleaned = {s1.clean_image_path(k): v for k, v in style.items()}
+    s1.compute_resnet_features = lambda path, model, device: cleaned.get(path)
+    first = [{"similarity": float(1.0 - 0.01 * i), "image_path": f"../../datasets/coco/train2017/{i}.jpg", "index": i,
+              **({"source_dataset": "coco"} if i % 4 else {})} for i in range(12)]
+    g["resnet_second_stage_rerank"] = {
+        "style": {k: (v.tolist() if v is not None else None) for k, v in cleaned.items()}, "query": "q.jpg", "first": first,
+        "out": s1.resnet_second_stage_rerank("q.jpg", first, None, None),
+        "out_query_unreadable": s1.resnet_second_stage_rerank("unreadable.jpg", first[:3], None, None)}
+    # first stage: exact inner product with a numpy stand-in for faiss (scores are well separated: order is unambiguous)
+    class _NumpyFlatIP:
+        def __init__(self, d): self.x = np.zeros((0, d), np.float32)
+        def add(self, x): self.x = np.vstack([self.x, x])
+        def search(self, q, k):
+            sc = q @ self.x.T
+            I = np.argsort(-sc, axis=1, kind="stable")[:, :k]
+            return np.take_along_axis(sc, I, 1), I.astype(np.int64)
+    s1.faiss.IndexFlatIP = _NumpyFlatIP
+    q = np.zeros(64, np.float32); q[0] = 1.0
+    fa = np.zeros((5, 64), np.float32); fa[:, 0] = [0.9, 0.1, 0.5, 0.7, 0.3]
+    fb = np.zeros((3, 64), np.float32); fb[:, 0] = [0.8, 0.2, 0.6]
+    feats = {"coco": fa, "miniimagenet": fb, "empty": np.zeros((0, 64), np.float32), "none": None}
+    pths = {"coco": [f"c{i}.jpg" for i in range(5)], "miniimagenet": [f"m{i}.jpg" for i in range(3)], "empty": [], "none": None}
+    g["clip_first_stage_retrieval"] = {"query": q.tolist(), "features": {k: (v.tolist() if v is not None else None) for k, v in feats.items()},
+                                       "paths": pths, "out_k100": s1.clip_first_stage_retrieval(q, feats, pths, top_k=100),
+                                       "out_k3": s1.clip_first_stage_retrieval(q, feats, pths, top_k=3),
+                                       "out_nothing": s1.clip_first_stage_retrieval(q, {"none": None}, {"none": None}, top_k=3)}
     m, s = s1.calc_mean_std(torch.arange(96.0).reshape(2, 3, 4, 4))
     g["calc_mean_std"] = {"mean": m.flatten().tolist(), "std": s.flatten().tolist()}
     with open(OUT, "w") as f:

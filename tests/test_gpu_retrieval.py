@@ -74,3 +74,18 @@ def test_two_stage_flow_on_files(gpu, tmp_path):
     assert [r["rank"] for r in final] == list(range(1, 13))
     assert final[0]["image_path"] == paths[4] and abs(final[0]["similarity"] - 1.0) < 1e-6
     assert set(final[0]) == {"rank", "similarity", "image_path", "source_dataset"}
+
+
+def test_first_stage_plumbing_matches_reference(gpu):
+    """clip_first_stage_retrieval (retrieval/…:396-451): several datasets stacked in dict order, empty / None ones
+    skipped, k = min(top_k, N), {similarity, image_path, source_dataset, index} — golden captured from the reference
+    (its faiss replaced by an exact numpy inner product; scores well separated, so order is unambiguous)"""
+    import json, os
+    import numpy as np
+    from domain_rag_amd import retrieval as R
+    gg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_logic.json")))["clip_first_stage_retrieval"]
+    feats = {k: (np.asarray(v, dtype=np.float32).reshape(-1, 64) if v is not None else None) for k, v in gg["features"].items()}
+    q = np.asarray(gg["query"], dtype=np.float32)
+    assert R.clip_first_stage_retrieval(q, feats, gg["paths"], top_k=100, device=gpu) == gg["out_k100"]
+    assert R.clip_first_stage_retrieval(q, feats, gg["paths"], top_k=3, device=gpu) == gg["out_k3"]
+    assert R.clip_first_stage_retrieval(q, {"none": None}, {"none": None}, top_k=3, device=gpu) == gg["out_nothing"]

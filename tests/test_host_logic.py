@@ -112,3 +112,20 @@ def test_annotation_lookup_matches_reference():
         assert [w, h] == c["image_size"] and boxes == c["bboxes"] and cats == c["categories"] and info["id"] == c["image_id"]
         crops = [H.crop_box(b, w, h) for b in boxes]
         assert [[x1 - x0, y1 - y0] for x0, y0, x1, y1 in crops] == c["crop_sizes"], c
+
+
+def test_second_stage_rerank_matches_reference():
+    """resnet_second_stage_rerank (retrieval/…:454-497) with injected style vectors: L2 distance in fp32, stable sort
+    (a tie keeps CLIP order), unreadable candidates dropped, similarity 1/(1+d), cleaned paths, source default"""
+    from domain_rag_amd import retrieval as R
+    gg = GOLD["resnet_second_stage_rerank"]
+    vecs = {k: (np.asarray(v, dtype=np.float32) if v is not None else None) for k, v in gg["style"].items()}
+
+    class FakeStem:
+        def features_from_path(self, path):
+            return vecs.get(path)
+    out = R.resnet_second_stage_rerank(gg["query"], gg["first"], FakeStem())
+    assert out == gg["out"]
+    cache: dict = {}
+    assert R.resnet_second_stage_rerank(gg["query"], gg["first"], FakeStem(), cache) == gg["out"] and len(cache) == 11
+    assert R.resnet_second_stage_rerank("unreadable.jpg", gg["first"][:3], FakeStem()) == gg["out_query_unreadable"]
