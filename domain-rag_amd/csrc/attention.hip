@@ -15,6 +15,7 @@
 // (no transposes, no cross-lane traffic in the loop).
 #include "drag_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -224,57 +225,65 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // S^T tile = K Q^T for the K tile in buffer `buf` (lane: query l&31, keys 32t + (r&3) + 8(r>>2) + 4hh)
-  auto qk = [&](int buf, f32x16_t (&sa)[2]) {
-    const char* sK = smem + buf * KT_BYTES;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sa[t][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(sK + krd + t * (32 * 256) + (((2 * ks + hh) ^ kx) << 4));
-        sa[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa[t], 0, 0, 0);
-      }
-    }
-  };
 
-  // Software pipeline: while the VALU works on the softmax of tile j, the matrix pipe already computes
+  const int nkv = p.s_pad / 64;
+  f32x16_t scur[2], snext[2];
+  {
+  // ---- depth-1 pipeline: while the VALU works on the softmax of tile j, the matrix pipe already computes
   // S(j+1) = K(j+1) Q^T (independent of it), then O += P(j) V(j).  K therefore runs one tile ahead of V:
   // iteration j needs K(j+1) and V(j) in LDS and stages K(j+2), V(j+1).
-  const int nkv = p.s_pad / 64;
+  // The loop is unrolled by two with the buffer parity as a compile-time constant: every ds_read address is one of 12
+  // loop-invariant VGPRs (8 K slots, 4 V^T slots: the XOR swizzle makes them lane-dependent) plus an immediate, the
+  // S accumulators ping-pong between two register sets instead of being copied, and the first MFMA of a chain takes
+  // C = 0 as an inline constant.
+  // Measured alternatives (same box, interleaved runs, B=8 S=5337): a depth-2 pipeline that also overlaps P(j-1) V(j-1)
+  // with the softmax of tile j (32 uniform {MFMA, exp} steps, fragment ring 3 deep) 1003 vs 1058 TFLOP/s for this loop;
+  // this loop without its barrier +4 %, without barrier and vmcnt wait +4 % (synchronisation is not the limiter).
+  // PMC (B=8 S=5337): effective clock 1.70 GHz (power-limited; 2.4 nominal), MFMA pipe 52-59 % busy at that clock.
+  int ak[8], av[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) ak[ks] = krd + (((2 * ks + hh) ^ kx) << 4);
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) av[s2] = vrd + (((2 * s2 + hh) ^ vx) << 4);
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   stage_k(0, 0);
   stage_v(0, 0);
   if (nkv > 1) stage_k(1, 64);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  f32x16_t scur[2], snext[2];
-  qk(0, scur);
-  for (int it = 0; it < nkv; ++it) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[ks] + t * (32 * 256)));
+      scur[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : scur[t], 0, 0, 0);
+    }
+  // one KV tile; PAR = it & 1 is a compile-time constant; reads S from sc, writes S(it+1) to sn
+  auto body = [&](const int it, auto par, f32x16_t (&sc)[2], f32x16_t (&sn)[2]) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr int KN = ((PAR + 1) & 1) * KT_BYTES;                 // K(it+1)
+    constexpr int VB = 2 * KT_BYTES + PAR * VT_BYTES;              // V(it)
     const int kv0 = it * 64;
     // K(it+1), V(it) landed (issued one iteration ago); every wave is done with K(it) and V(it-1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // (the LDS-DMA for K(it+2) / V(it+1) is issued piecewise between the MFMAs of the interleaved loop below:
     //  a burst of 2*CPW buffer_load..lds per wave right after the barrier idles the matrix pipe of every SIMD)
-    const bool do_k = it + 2 < nkv, do_v = it + 1 < nkv;
-    const char* sV = smem + 2 * KT_BYTES + (it & 1) * VT_BYTES;
-
     if (kv0 + 64 > p.S) {     // ragged last tile: keys >= S do not exist
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= p.S) scur[t][r] = -INFINITY;
+          if (key >= p.S) sc[t][r] = -INFINITY;
         }
     }
     // ---- online softmax (exp2 domain), deferred rescale ----
-    float mt = scur[0][0];
+    float mt = sc[0][0];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, scur[t][r]);
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[t][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     // Only move the running max (and rescale O, l) when some row's max grew by more than 2^8 in the
     // exp2 domain; otherwise P = exp2(s - m_old) is bounded by 2^8, which fp32 accumulation and the
@@ -293,50 +302,58 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     // ---- matrix pipe: S(it+1) = K(it+1) Q^T   ||   VALU: P(it) = exp2(S(it) - m), row sums, bf16 packing.
     // The two streams are independent, but hipcc emits 16 back-to-back MFMAs followed by the whole softmax, so the
     // interleave is written out: 16 steps of {prefetch next K fragment, 1 MFMA, 2 exps + pack}, each fenced with
-    // sched_barrier so the order survives.  An MFMA occupies the matrix pipe for 32 cycles after issue; the ~8 VALU
-    // of the step execute under it.  S(it+1) is computed unconditionally (in the last iteration it reads a stale K
-    // buffer and is discarded).
-    const float mc = m_run * p.c;
+    // sched_barrier so the order survives.  S(it+1) is computed unconditionally (in the last iteration it reads a
+    // stale K buffer and is discarded).
+    const float nmc = -(m_run * p.c);
     float ps = 0.f;
     u32x4_t pk[4];
     {
-      const char* sKn = smem + ((it + 1) & 1) * KT_BYTES + krd;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) snext[t][r] = 0.f;
-      bf16x8_t kf = *(const bf16x8_t*)(sKn + (((0 + hh) ^ kx) << 4));
+      bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[0] + KN));
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const bf16x8_t kcur = kf;
         if (g < 15) {
           const int t1 = (g + 1) >> 3, ks1 = (g + 1) & 7;
-          kf = *(const bf16x8_t*)(sKn + t1 * (32 * 256) + (((2 * ks1 + hh) ^ kx) << 4));
+          kf = *(const bf16x8_t*)(smem + (ak[ks1] + (KN + t1 * (32 * 256))));
         }
-        snext[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], snext[g >> 3], 0, 0, 0);
-        if (g < CPW) { if (do_k) stage_k1(it & 1, kv0 + 128, g); }
-        else if (g < 2 * CPW) { if (do_v) stage_v1((it + 1) & 1, kv0 + 64, g - CPW); }
-        const float e0 = __builtin_amdgcn_exp2f(scur[g >> 3][(2 * g) & 15] * p.c - mc);
-        const float e1 = __builtin_amdgcn_exp2f(scur[g >> 3][((2 * g) & 15) + 1] * p.c - mc);
+        sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], (g & 7) == 0 ? zero16 : sn[g >> 3], 0, 0, 0);
+        // unconditional (no branches: a branch here splits the block and hipcc then hoists the whole softmax out of the
+        // interleave): past the last tile the K rows clamp to S-1 and the V^T offsets fall outside the descriptor's range
+        // (reads return 0); both land in buffers nobody reads any more
+        if (g < CPW) stage_k1(PAR, kv0 + 128, g);
+        else if (g < 2 * CPW) stage_v1((PAR + 1) & 1, kv0 + 64, g - CPW);
+        // the softmax arithmetic is side-effect free, so instruction selection is free to cluster all of it ahead of the
+        // first step (it did: the steps then held only ds_read + MFMA).  Two empty asm volatile statements chain its
+        // inputs after the previous step and its results before this step's fence.
+        float y0, y1;      // s * c - m*c; written as asm so that the chain anchor costs no register copies
+        asm volatile("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %5"
+                     : "=&v"(y0), "=&v"(y1) : "v"(sc[g >> 3][(2 * g) & 15]), "v"(sc[g >> 3][((2 * g) & 15) + 1]), "s"(p.c), "v"(nmc));
+        const float e0 = __builtin_amdgcn_exp2f(y0);
+        const float e1 = __builtin_amdgcn_exp2f(y1);
         ps += e0 + e1;
-        pk[g >> 2][g & 3] = pack2bf(e0, e1);
+        uint32_t wd = pack2bf(e0, e1);
+        asm volatile("" : "+v"(wd), "+v"(ps));
+        pk[g >> 2][g & 3] = wd;
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     l_run += ps;
     bf16x8_t pf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) pf[s] = __builtin_bit_cast(bf16x8_t, pk[s]);
+    for (int s2 = 0; s2 < 4; ++s2) pf[s2] = __builtin_bit_cast(bf16x8_t, pk[s2]);
     // ---- O^T += V^T P^T ----
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8_t vf = *(const bf16x8_t*)(sV + vrd + dt * (32 * 128) + (((2 * s + hh) ^ vx) << 4));
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8_t vf = *(const bf16x8_t*)(smem + (av[s2] + (VB + dt * (32 * 128))));
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
       }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) scur[t] = snext[t];
+  };
+  for (int it = 0; it < nkv; it += 2) {
+    body(it, std::integral_constant<int, 0>{}, scur, snext);
+    if (it + 1 < nkv) body(it + 1, std::integral_constant<int, 1>{}, snext, scur);
+  }
   }
 
   // ---- epilogue: lane holds O[query l&31][d = 32dt + 8(r>>2) + 4hh + (r&3)] ----
@@ -395,7 +412,7 @@ extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt,
   DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
   const int groups = (B * H + 7) / 8;
-  const bool w8 = getenv("DRAG_ATTN_W4") == nullptr && S >= 1024;     // 8-wave blocks halve the DMA issue per wave
+  const bool w8 = getenv("DRAG_ATTN_W4") == nullptr && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
   const int QB = w8 ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);

@@ -1,17 +1,17 @@
-import math, os, sys
+"""attention kernel variants, interleaved (DVFS drift cancels): 8-wave vs 4-wave blocks"""
+import math, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from domain_rag_amd import ops
 dev = torch.device("cuda:0")
-def bench(fn, iters=20, warm=5):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize()
+def bench(fn, iters=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 729, 16)]:
+VARIANTS = {"8-wave": {}, "4-wave": {"DRAG_ATTN_W4": "1"}}
+for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
     D = H * 128
     qkv = torch.randn(B, S, 3 * D, device=dev).bfloat16()
     s_pad = (S + 63) // 64 * 64
@@ -19,16 +19,15 @@ for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 729, 16)]:
     wq = torch.ones(128, device=dev).bfloat16()
     cos = torch.ones(S, 64, device=dev); sin = torch.zeros(S, 64, device=dev)
     o = torch.empty(B, S, D, device=dev, dtype=torch.bfloat16)
-    ms_p = bench(lambda: ops.qk_norm_rope_vt(qkv, vt, wq, wq, wq, wq, cos, sin, B, S, H, 3 * D, 1241))
+    ops.qk_norm_rope_vt(qkv, vt, wq, wq, wq, wq, cos, sin, B, S, H, 3 * D, 1241)
     fl = 4.0 * S * S * 128 * H * B
-    res = []
-    for abl in ("0",):
-        os.environ["DRAG_ATTN_ABL"] = abl
-        ms_a = min(bench(lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))) for _ in range(2))
-        res.append(f"abl{abl} {fl/ms_a/1e9:.0f}")
-    os.environ.pop("DRAG_ATTN_ABL")
-    os.environ["DRAG_ATTN_W4"] = "1"
-    ms_a = min(bench(lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))) for _ in range(2))
-    res.append(f"4-wave {fl/ms_a/1e9:.0f}")
-    os.environ.pop("DRAG_ATTN_W4")
-    print(f"attn B={B} S={S} H={H}: prep {ms_p:.3f} ms | " + " | ".join(res) + " TF/s (0 real, 1 no-DMA, 2 no-exp, 3 no V ds_read)", flush=True)
+    run = lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+    t = {k: [] for k in VARIANTS}
+    for rep in range(6):
+        for name, env in VARIANTS.items():
+            for k in ("DRAG_ATTN_PIPE1", "DRAG_ATTN_W4", "DRAG_ATTN_NOSYNC"): os.environ.pop(k, None)
+            os.environ.update(env)
+            if rep == 0: bench(run, 3)
+            t[name].append(bench(run))
+    for k in ("DRAG_ATTN_PIPE1", "DRAG_ATTN_W4", "DRAG_ATTN_NOSYNC"): os.environ.pop(k, None)
+    print(f"attn B={B} S={S} H={H}: " + " | ".join(f"{k} {fl/statistics.median(v)/1e9:.0f} TF/s" for k, v in t.items()), flush=True)

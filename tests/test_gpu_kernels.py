@@ -174,7 +174,7 @@ def _attn_case(gpu, B, S, H, s_txt, seed, spike=False):
     assert _rel(o, ref) < 3e-2
 
 
-@pytest.mark.parametrize("B,S,H,s_txt", [(1, 64, 1, 0), (2, 200, 2, 24), (1, 333, 3, 77), (1, 1241 + 256, 2, 1241)])
+@pytest.mark.parametrize("B,S,H,s_txt", [(1, 64, 1, 0), (2, 200, 2, 24), (1, 333, 3, 77), (1, 1241 + 256, 2, 1241), (1, 4300, 2, 100)])
 def test_attention(gpu, B, S, H, s_txt):
     _attn_case(gpu, B, S, H, s_txt, seed=11)
 
