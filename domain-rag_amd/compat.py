@@ -15,8 +15,9 @@ so the call sites work unchanged:
 
 There are no checkpoints offline: ``DRAG_SYNTHETIC_WEIGHTS=1`` builds seeded random weights of the same
 architectures and ``DRAG_TINY=1`` the reduced test configuration; without them ``from_pretrained`` reads the
-checkpoint directories the reference reads and raises if they are missing.  Text encoders passed to
-``from_pretrained`` are accepted and ignored: the prompt encodings come from ``TextCache`` (engine.py).
+checkpoint directories the reference reads and raises if they are missing.  Text encoders / tokenizers passed to
+``FluxPriorReduxPipeline.from_pretrained`` (the reference passes its ``transformers`` modules) encode a prompt the
+first time it is seen; the result is cached on disk (``TextCache``, engine.py) — the prompt is constant per dataset.
 """
 from __future__ import annotations
 
@@ -88,8 +89,10 @@ class FluxPriorReduxPipeline(_Pipe):
             rp = load_safetensors_dir(os.path.join(self._path, "image_embedder"))
         self.vit_cfg = vitcfg
         self.prior = redux_mod.ReduxPriorHIP(vitcfg, vitp, rp, dev)
+        kw = self._kwargs
         self.text = E.TextCache(os.path.dirname(self._path.rstrip("/")) or ".", synthetic,
-                                E.TINY["t5_tokens"] if tiny else redux_mod.T5_TOKENS, J, P, dev)
+                                E.TINY["t5_tokens"] if tiny else redux_mod.T5_TOKENS, J, P, dev,
+                                encoders=(kw.get("text_encoder"), kw.get("text_encoder_2"), kw.get("tokenizer"), kw.get("tokenizer_2")))
 
     def __call__(self, image, prompt="", prompt_2="", prompt_embeds_scale=1.0, pooled_prompt_embeds_scale=1.0, **_):
         self._require()

@@ -56,13 +56,30 @@ def siglip_input_device(pil_images, size: int, device) -> torch.Tensor:
     return out
 
 
-class TextCache:
-    """prompt -> (T5 embeds [Lt, J] bf16, pooled [P] bf16).  Real encodings are read from
-    ``<model_root>/prompt_cache/<sha1>.pt`` (written once by any tool that has the text encoders); synthetic mode
-    derives seeded stand-ins from the prompt hash."""
+def encode_prompt_with(text_encoder, text_encoder_2, tokenizer, tokenizer_2, prompt: str, prompt_2: str = "", max_sequence_length: int = 512):
+    """FluxPriorReduxPipeline.encode_prompt with the caller's own ``transformers`` modules (the ones the reference builds
+    in ``load_model``, batch_…:120-137 / outpainting_…:505-522): pooled = CLIP-L ``pooler_output`` of ``prompt`` (77 tokens,
+    padded / truncated), embeds = T5 last hidden state of ``prompt_2 or prompt`` (512 tokens).  Runs once per distinct
+    prompt (the prompt is constant per dataset) and is cached; it is not on the per-image path."""
+    prompt_2 = prompt_2 or prompt
+    with torch.no_grad():
+        ids = tokenizer([prompt], padding="max_length", max_length=getattr(tokenizer, "model_max_length", 77), truncation=True,
+                        return_tensors="pt").input_ids
+        pooled = text_encoder(ids.to(next(text_encoder.parameters()).device), output_hidden_states=False).pooler_output
+        ids2 = tokenizer_2([prompt_2], padding="max_length", max_length=max_sequence_length, truncation=True,
+                           return_tensors="pt").input_ids
+        embeds = text_encoder_2(ids2.to(next(text_encoder_2.parameters()).device), output_hidden_states=False)[0]
+    return embeds[0].float().cpu(), pooled[0].float().cpu()
 
-    def __init__(self, model_root: str, synthetic: bool, Lt: int, J: int, P: int, device):
+
+class TextCache:
+    """prompt -> (T5 embeds [Lt, J] bf16, pooled [P] bf16).  Order: memory; ``<model_root>/prompt_cache/<sha1>.pt``;
+    the caller's text encoders if given (``encoders`` = (text_encoder, text_encoder_2, tokenizer, tokenizer_2), result
+    written back to the cache file); synthetic mode derives seeded stand-ins from the prompt hash."""
+
+    def __init__(self, model_root: str, synthetic: bool, Lt: int, J: int, P: int, device, encoders=None):
         self.root, self.synthetic, self.Lt, self.J, self.P, self.dev = model_root, synthetic, Lt, J, P, device
+        self.encoders = encoders if encoders is not None and all(e is not None for e in encoders) else None
         self._mem: dict = {}
 
     def get(self, prompt: str, prompt_2: str = ""):
@@ -72,12 +89,21 @@ class TextCache:
             if os.path.exists(path):
                 d = torch.load(path, map_location="cpu")
                 t5, pooled = d["prompt_embeds"].reshape(-1, self.J), d["pooled_prompt_embeds"].reshape(-1)
+            elif self.encoders is not None:
+                t5, pooled = encode_prompt_with(*self.encoders, prompt, prompt_2, self.Lt)
+                try:
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    torch.save({"prompt": prompt, "prompt_2": prompt_2, "prompt_embeds": t5.to(torch.bfloat16),
+                                "pooled_prompt_embeds": pooled.to(torch.bfloat16)}, path)
+                except OSError as e:        # read-only model directory: keep the encoding in memory only
+                    print(f"prompt cache not written ({e})")
             elif self.synthetic:
                 g = torch.Generator().manual_seed(int(key[:8], 16))
                 t5, pooled = torch.randn(self.Lt, self.J, generator=g), torch.randn(self.P, generator=g)
             else:
                 raise FileNotFoundError(f"no cached text encoding for prompt {prompt!r}: expected {path} "
-                                        "(dict with prompt_embeds [512,4096], pooled_prompt_embeds [768])")
+                                        "(dict with prompt_embeds [512,4096], pooled_prompt_embeds [768]), or pass the text "
+                                        "encoders / tokenizers to FluxPriorReduxPipeline.from_pretrained as the reference does")
             self._mem[key] = (t5.to(self.dev, torch.bfloat16).contiguous(), pooled.to(self.dev, torch.bfloat16).contiguous())
         return self._mem[key]
 
