@@ -72,14 +72,24 @@ def encode_prompt_with(text_encoder, text_encoder_2, tokenizer, tokenizer_2, pro
     return embeds[0].float().cpu(), pooled[0].float().cpu()
 
 
+def load_text_encoders(flux_dir: str, device="cuda"):
+    """the four objects the reference's ``load_model`` builds from ``<model>/FLUX.1-*/{text_encoder, text_encoder_2,
+    tokenizer, tokenizer_2}`` (batch_…:120-137), bf16"""
+    from transformers import CLIPTextModel, CLIPTokenizer, T5EncoderModel, T5TokenizerFast
+    te = CLIPTextModel.from_pretrained(flux_dir, subfolder="text_encoder", torch_dtype=torch.bfloat16).to(device).eval()
+    te2 = T5EncoderModel.from_pretrained(flux_dir, subfolder="text_encoder_2", torch_dtype=torch.bfloat16).to(device).eval()
+    return te, te2, CLIPTokenizer.from_pretrained(flux_dir, subfolder="tokenizer"), T5TokenizerFast.from_pretrained(flux_dir, subfolder="tokenizer_2")
+
+
 class TextCache:
     """prompt -> (T5 embeds [Lt, J] bf16, pooled [P] bf16).  Order: memory; ``<model_root>/prompt_cache/<sha1>.pt``;
     the caller's text encoders if given (``encoders`` = (text_encoder, text_encoder_2, tokenizer, tokenizer_2), result
     written back to the cache file); synthetic mode derives seeded stand-ins from the prompt hash."""
 
-    def __init__(self, model_root: str, synthetic: bool, Lt: int, J: int, P: int, device, encoders=None):
+    def __init__(self, model_root: str, synthetic: bool, Lt: int, J: int, P: int, device, encoders=None, loader=None):
         self.root, self.synthetic, self.Lt, self.J, self.P, self.dev = model_root, synthetic, Lt, J, P, device
         self.encoders = encoders if encoders is not None and all(e is not None for e in encoders) else None
+        self.loader = loader            # () -> encoders tuple, called on the first cache miss only (T5-XXL is 9.5 GB)
         self._mem: dict = {}
 
     def get(self, prompt: str, prompt_2: str = ""):
@@ -89,7 +99,9 @@ class TextCache:
             if os.path.exists(path):
                 d = torch.load(path, map_location="cpu")
                 t5, pooled = d["prompt_embeds"].reshape(-1, self.J), d["pooled_prompt_embeds"].reshape(-1)
-            elif self.encoders is not None:
+            elif self.encoders is not None or (self.loader is not None and not self.synthetic):
+                if self.encoders is None:
+                    self.encoders = self.loader()
                 t5, pooled = encode_prompt_with(*self.encoders, prompt, prompt_2, self.Lt)
                 try:
                     os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -166,7 +178,8 @@ class Engine:
         self.prior = redux_mod.ReduxPriorHIP(vitcfg, vitp, rp, dev)
         self.pipe = FluxFillHIP(tr, vae) if kind == "fill" else FluxTxt2ImgHIP(tr, vae)
         self.text = TextCache(flux_dir, synthetic, TINY["t5_tokens"] if tiny else redux_mod.T5_TOKENS, cfg.joint_attention_dim,
-                              cfg.pooled_projection_dim, dev)
+                              cfg.pooled_projection_dim, dev,
+                              loader=(lambda: load_text_encoders(flux_dir, dev)) if os.path.isdir(os.path.join(flux_dir, "text_encoder_2")) else None)
 
     def prior_embeds(self, pil_images, prompt: str, embeds_scale, pooled_scale):
         """pipe_prior_redux(images, prompt=…, prompt_2="", prompt_embeds_scale=…, pooled_prompt_embeds_scale=…)"""
