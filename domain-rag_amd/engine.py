@@ -177,7 +177,7 @@ class Engine:
         self.cfg, self.vit_cfg = cfg, vitcfg
         self.prior = redux_mod.ReduxPriorHIP(vitcfg, vitp, rp, dev)
         self.pipe = FluxFillHIP(tr, vae) if kind == "fill" else FluxTxt2ImgHIP(tr, vae)
-        self.text = TextCache(flux_dir, synthetic, TINY["t5_tokens"] if tiny else redux_mod.T5_TOKENS, cfg.joint_attention_dim,
+        self.text = TextCache(model_root, synthetic, TINY["t5_tokens"] if tiny else redux_mod.T5_TOKENS, cfg.joint_attention_dim,
                               cfg.pooled_projection_dim, dev,
                               loader=(lambda: load_text_encoders(flux_dir, dev)) if os.path.isdir(os.path.join(flux_dir, "text_encoder_2")) else None)
 
