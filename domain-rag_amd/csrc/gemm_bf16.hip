@@ -624,7 +624,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
 }  // namespace
 
 // tile policy: the 256x256 kernel needs enough tiles to fill 256 CUs and rows to amortise its prologue
-static bool use_t256(long long M, int N, int K) { return M >= 2048 && N >= 256 && K >= 256 && getenv("DRAG_GEMM_T128") == nullptr; }
+// tile policy (both kernels give bit-identical results: same k-order per output element).  The 256x256 kernel is the
+// faster one per tile, but it needs enough tiles to fill the 256 CUs and loses to the 128x128 kernel when the last round of
+// tiles is mostly empty (measured at M = 1024 / 1536 / 1753, scripts/bench_gemm_small_m.py: 216 tiles 1226 vs 957 TFLOP/s,
+// 504 tiles 1384 vs 1069, but 72 tiles 510 vs 680 and 288 tiles 927 vs 993).
+static bool use_t256(long long M, int N, int K) {
+  if (getenv("DRAG_GEMM_T128") != nullptr || N < 256 || K < 256) return false;
+  if (M >= 2048) return true;
+  if (M < 1024) return false;
+  const long long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  if (tiles < 128) return false;
+  if (tiles <= 256) return true;
+  const long long rounds = (tiles + 255) / 256;
+  return tiles * 10 >= rounds * 256 * 7;              // last-round efficiency >= 0.7
+}
 
 // persistent grid of the 256x256 kernel: one workgroup per CU (128 KiB of LDS each), fewer when there are fewer tiles
 static int t256_grid(int ntiles) {
