@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ops import _p, _stream, check
+from .ops import _stream, check
 
 PRECISION_BITS = 32 - 8 - 2
 _SUPPORT = {"bilinear": 1.0, "bicubic": 2.0, "lanczos": 3.0}

@@ -16,7 +16,6 @@ the global row order, so top-k indices equal the single-GPU result bit-for-bit.
 from __future__ import annotations
 
 import math
-import os
 
 import numpy as np
 import torch

@@ -19,7 +19,7 @@ kernels accumulate in fp32), or dtype=torch.float32 for a high-precision yardsti
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import torch
 import torch.nn.functional as F

@@ -3,7 +3,6 @@ global index space, and result merging — the same code the GPUs run with backe
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
