@@ -10,18 +10,18 @@ def bench(fn, iters=8):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-VARIANTS = {"staged": {}, "nt": {"DRAG_GEMM_DBG": "3"}, "skew2": {"DRAG_GEMM_DBG": "12"}, "skew5": {"DRAG_GEMM_DBG": "15"}, "skew10": {"DRAG_GEMM_DBG": "20"}}
+VARIANTS = {"persistent + staged epilogue": {}, "fragment-layout epilogue": {"DRAG_GEMM_NARROW": "1"}, "one tile per workgroup": {"DRAG_GEMM_NONPERSISTENT": "1"}}
 M, N = int(os.environ.get("M", 32768)), int(os.environ.get("N", 3072))
-for K in (1024, 3072, 12288):
+for K in (256, 1024, 3072, 12288):
     A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     t = {k: [] for k in VARIANTS}
     for rep in range(7):
         for name, env in VARIANTS.items():
-            os.environ.pop("DRAG_GEMM_NONPERSISTENT", None); os.environ.pop("DRAG_GEMM_DBG", None); os.environ.pop("DRAG_GEMM_NARROW", None); os.environ.update(env)
+            os.environ.pop("DRAG_GEMM_NONPERSISTENT", None); os.environ.pop("DRAG_GEMM_NARROW", None); os.environ.update(env)
             if rep == 0: bench(lambda: ops.gemm(A, W, out=C), 3)
             t[name].append(bench(lambda: ops.gemm(A, W, out=C)))
-    os.environ.pop("DRAG_GEMM_NONPERSISTENT", None); os.environ.pop("DRAG_GEMM_DBG", None); os.environ.pop("DRAG_GEMM_NARROW", None)
+    os.environ.pop("DRAG_GEMM_NONPERSISTENT", None); os.environ.pop("DRAG_GEMM_NARROW", None)
     lib = statistics.median(bench(lambda: torch.matmul(A, W.t(), out=C)) for _ in range(5))
     fl = 2 * M * N * K / 1e9
     ntile = ((M + 255) // 256) * ((N + 255) // 256)
