@@ -236,6 +236,25 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
     for (int i = 0; i < 4; ++i) { g[2 * i] = bf_lo(gg[i]); g[2 * i + 1] = bf_hi(gg[i]); }
   }
   const long long off0 = p.cm.off(min(mw0, p.M - 1));
+  // residual rows are requested RD row blocks (passes) ahead of their use into a small register ring: one exposed HBM
+  // latency per tile instead of one per pass (the per-pass form cost a gated GEMM 18 % at K = 3072); the whole tile at
+  // once (64 VGPRs at MI = 8) pushed the 256x256 kernel into scratch spills inside its main loop
+  constexpr int RD = MI < 2 ? MI : 2;
+  u32x4_t rres[RD][2];
+  auto load_resid = [&](int mi2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = mw0 + mi2 * 16 + j * 8 + rl;
+      rres[mi2 % RD][j] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (CHECK && (m >= p.M || !col_ok)) continue;
+      const long long coff = (one_batch ? off0 + (long long)(m - mw0) * p.cm.ld : p.cm.off(m)) + n;
+      rres[mi2 % RD][j] = *(const u32x4_t*)(p.resid + coff);
+    }
+  };
+  if (p.resid) {
+#pragma unroll
+    for (int mi = 0; mi < RD; ++mi) load_resid(mi);
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -263,7 +282,7 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
       if (CHECK && (m >= p.M || !col_ok)) continue;
       const long long coff = (one_batch ? off0 + (long long)(m - mw0) * p.cm.ld : p.cm.off(m)) + n;
       if (p.resid) {
-        const u32x4_t x = *(const u32x4_t*)(p.resid + coff);
+        const u32x4_t x = rres[mi % RD][j];
         if (p.gate) {
           // diffusers computes  x = x + gate * y  with y, gate, x bf16 tensors: the product is rounded, then the sum
           if (!one_batch) {
@@ -281,6 +300,7 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
       }
       *(u32x4_t*)((bf16_t*)p.C + coff) = y;
     }
+    if (p.resid && mi + RD < MI) load_resid(mi + RD);
   }
 }
 
