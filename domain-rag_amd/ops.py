@@ -34,7 +34,12 @@ class GemmRecorder:
     def kernel_of(shape, conv=False):
         """the dispatch rule of drag_gemm_bf16 / drag_conv3x3_bf16 (csrc/gemm_bf16.hip: use_t256)"""
         M, N, K = shape
-        return ("gemm_bf16_t256" if (M >= 2048 and N >= 256 and K >= 256) else "gemm_bf16_t128") + ("<1>" if conv else "<0>")
+        big = False
+        if N >= 256 and K >= 256:
+            tiles = ((M + 255) // 256) * ((N + 255) // 256)
+            rounds = (tiles + 255) // 256
+            big = M >= 2048 or (M >= 1024 and tiles >= 128 and (tiles <= 256 or tiles * 10 >= rounds * 256 * 7))
+        return ("gemm_bf16_t256" if big else "gemm_bf16_t128") + ("<1>" if conv else "<0>")
 
     def by_kernel(self):
         """{kernel name: (launches, total_ms, flops)}"""
