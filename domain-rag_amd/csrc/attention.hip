@@ -238,7 +238,9 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   // C = 0 as an inline constant.
   // Measured alternatives (same box, interleaved runs, B=8 S=5337): a depth-2 pipeline that also overlaps P(j-1) V(j-1)
   // with the softmax of tile j (32 uniform {MFMA, exp} steps, fragment ring 3 deep) 1003 vs 1058 TFLOP/s for this loop;
-  // this loop without its barrier +4 %, without barrier and vmcnt wait +4 % (synchronisation is not the limiter).
+  // this loop without its barrier +4 %, without barrier and vmcnt wait +4 % (synchronisation is not the limiter);
+  // K / V^T staged through registers (buffer_load -> ds_write_b128 at the end of the iteration) instead of LDS-DMA
+  // 1041 vs 1088 TFLOP/s.
   // PMC (B=8 S=5337): effective clock 1.70 GHz (power-limited; 2.4 nominal), MFMA pipe 52-59 % busy at that clock.
   int ak[8], av[4];
 #pragma unroll
