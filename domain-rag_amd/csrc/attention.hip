@@ -240,7 +240,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   // with the softmax of tile j (32 uniform {MFMA, exp} steps, fragment ring 3 deep) 1003 vs 1058 TFLOP/s for this loop;
   // this loop without its barrier +4 %, without barrier and vmcnt wait +4 % (synchronisation is not the limiter);
   // K / V^T staged through registers (buffer_load -> ds_write_b128 at the end of the iteration) instead of LDS-DMA
-  // 1041 vs 1088 TFLOP/s.
+  // 1041 vs 1088 TFLOP/s; the two wave halves run half an iteration apart (softmax half of one SIMD partner beside the
+  // P V half of the other, two barriers per tile, V^T triple-buffered) 1047 vs 1068.
   // PMC (B=8 S=5337): effective clock 1.70 GHz (power-limited; 2.4 nominal), MFMA pipe 52-59 % busy at that clock.
   int ak[8], av[4];
 #pragma unroll
