@@ -102,6 +102,7 @@ def _pad64(c: int) -> int:
 
 class FluxVaeHIP:
     def __init__(self, cfg: VaeConfig, params: dict, device="cuda"):
+        self.attn_block_bytes = 1 << 31        # bound of the mid-block attention's fp32 score block (see _attn)
         self.cfg, self.dev = cfg, torch.device(device)
         self.w: dict[str, torch.Tensor] = {}
         for k, v in params.items():
@@ -170,15 +171,20 @@ class FluxVaeHIP:
         o = self._buf("attn_o", (B * T, C))
         Tp = (T + 63) // 64 * 64                       # K of the P·V GEMM, zero-padded
         vt = self._buf("attn_vt", (C, Tp), zero=True)
-        s = self._buf("attn_s", (T, T), dtype=torch.float32)
-        pbuf = self._buf("attn_p", (T, Tp))
+        # query rows are independent: the fp32 score block is bounded to ~2 GiB (T = 122 500 at the 2800-px cap would
+        # otherwise need a 60 GB matrix); at 1024^2 (T = 16 384, 1.07 GB) it is still one block
+        Tq = min(T, max(64, (self.attn_block_bytes // (6 * T)) // 64 * 64))
+        s = self._buf("attn_s", (Tq, T), dtype=torch.float32)
+        pbuf = self._buf("attn_p", (Tq, Tp))
         for b in range(B):
             nb = n.view(B, T, C)[b]
             # V^T = Wv · X^T (bias added after P·V: softmax rows sum to one)
             ops.gemm(w[pre + "to_v.weight"], nb, out=vt, M=C, lda=C, ldc=Tp)
-            ops.gemm(q.view(B, T, C)[b], k.view(B, T, C)[b], out=s, out_f32=True)
-            ops.softmax_rows(s, pbuf, T, T, 1.0 / math.sqrt(C), ldy=Tp)
-            ops.gemm(pbuf, vt, out=o.view(B, T, C)[b], bias=w[pre + "to_v.bias"], M=T, lda=Tp, ldc=C)
+            for r0 in range(0, T, Tq):
+                rows = min(Tq, T - r0)
+                ops.gemm(q.view(B, T, C)[b][r0:r0 + rows], k.view(B, T, C)[b], out=s, out_f32=True)
+                ops.softmax_rows(s, pbuf, rows, T, 1.0 / math.sqrt(C), ldy=Tp)
+                ops.gemm(pbuf, vt, out=o.view(B, T, C)[b][r0:r0 + rows], bias=w[pre + "to_v.bias"], M=rows, lda=Tp, ldc=C)
         y = self._buf(tag, (B, H, W, C))
         ops.gemm(o, w[pre + "to_out.0.weight"], out=y, bias=w[pre + "to_out.0.bias"], resid=x)
         return y

@@ -119,3 +119,17 @@ def test_vae_decode_encode_vs_oracle(gpu, blocks, layers, B, h, w):
         refb = ov.pack_latents(ov.sample_latents(ov.encode_moments(p, x.bfloat16(), block_out=blocks, layers=layers), nz))
         e, e_or = _rel(toks, ref), _rel(refb, ref)
         assert e < max(1.5e-2, 2.5 * e_or), (use_mask, e, e_or)
+
+
+def test_mid_attention_query_blocks_are_exact(gpu):
+    """the mid-block attention bounds its fp32 score block by processing query rows in blocks: rows are independent, so
+    any block size must give the same bits (block of 64 rows here vs one block)"""
+    from domain_rag_amd import vae
+    cfg = vae.VaeConfig(block_out_channels=(128, 256), layers_per_block=1)
+    p = vae.init_params(cfg, seed=4)
+    tok = _rand((2, 12 * 10, 64), 6).to(gpu)
+    one = vae.FluxVaeHIP(cfg, p, gpu)
+    ref = one.decode_tokens(tok, 2, 12, 10).clone()
+    blocked = vae.FluxVaeHIP(cfg, p, gpu)
+    blocked.attn_block_bytes = 6 * (24 * 20) * 64            # -> 64 query rows per block (T = 480)
+    assert torch.equal(blocked.decode_tokens(tok, 2, 12, 10), ref)
