@@ -140,7 +140,7 @@ class FluxTxt2ImgHIP:
             fwd = self.tr.forward_graphed if self.use_graph else self.tr.forward
             v = fwd(lat, prompt_embeds, pooled, t, img_ids, txt_ids, guidance)
             ops.flow_euler_rows(lat, v, B * h * w, 64, 64, 64, float(sigmas[i + 1] - sigmas[i]))
-        return self.vae.decode_tokens(lat, B, h, w, ld=64)
+        return self.vae.decode_tokens(lat, B, h, w, ld=64).clone()      # the decoder's buffer is reused by the next call
 
 
 class Engine:

@@ -67,7 +67,7 @@ class FluxFillHIP:
                 fwd = self.tr.forward_graphed if (self.use_graph and recorder is None) else self.tr.forward
                 v = fwd(hidden, prompt_embeds, pooled, t, self._img_ids, self._txt_ids, guidance)
                 ops.flow_euler_rows(hv, v, B * Si, 64, C, 64, float(sigmas[i + 1] - sigmas[i]))
-            return self.vae.decode_tokens(hv, B, h, w, ld=C)
+            return self.vae.decode_tokens(hv, B, h, w, ld=C).clone()      # the decoder's buffer is reused by the next call
         finally:
             ops.set_recorder(None)
 

@@ -68,4 +68,6 @@ class ReduxPriorHIP:
         ps = torch.tensor(list(pooled_scale) * G, dtype=torch.float32).to(self.dev)
         ops.scale_sum(self._slab, es, self._out, G, N, L * Dt)
         ops.scale_sum(self._pooled_in, ps, self._pout, G, N, P)
-        return self._out, self._pout
+        # fresh tensors: the work buffers are reused by the next call, and callers may keep several priors alive
+        # (the diffusers pipeline returns new tensors too)
+        return self._out.clone(), self._pout.clone()

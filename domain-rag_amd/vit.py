@@ -221,6 +221,6 @@ class VitHIP:
             ops.layernorm(x, pooled, B, D, gamma=self.ln_post[0], beta=self.ln_post[1], ldx=T * D, eps=cfg.ln_eps)
             return ops.gemm(pooled, self.proj, out_f32=True)
         ops.layernorm(x, ws["out"], M, D, gamma=self.ln_post[0], beta=self.ln_post[1], eps=cfg.ln_eps)
-        return ws["out"].view(B, T, D)
+        return ws["out"].view(B, T, D)          # a view of the workspace: valid until the next call (the Redux prior consumes it at once)
 
     __call__ = forward

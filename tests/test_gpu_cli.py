@@ -85,3 +85,10 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
     assert len(res["samples"][0]["outpainted_images"]) == 5 and res["samples"][0]["categories"] == ["Coleoptera"]
     fin = root / "final_results" / "process_7" / "1_shot" / ds / "1_shot"
     assert len(list(fin.glob("*_final_result*.png"))) == 10
+    # the backgrounds of a sample are composited as one batch; one at a time (like the reference) must give the same pixels
+    _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "8", "--dataset", ds, "--shot", "1", "--synthetic-weights", "--tiny",
+                                                 "--num_inference_steps", "2", "--seed", "3", "--bg_batch", "1"], cwd=root)
+    sd8 = root / "outpaint_hires" / "process_8" / ds / "1_shot" / "beetle_01"
+    for r in range(1, 6):
+        assert np.array_equal(np.asarray(Image.open(sd / f"{pre}_hires_result_{r}.png")), np.asarray(Image.open(sd8 / f"{pre}_hires_result_{r}.png")))
+        assert json.load(open(sd / f"{pre}_params_{r}.json"))["seed"] == json.load(open(sd8 / f"{pre}_params_{r}.json"))["seed"]

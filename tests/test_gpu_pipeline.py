@@ -92,3 +92,17 @@ def test_txt2img_pipeline_vs_oracle(gpu, guidance_embeds, steps):
     e = (out.float() / 255.0 - outs["f32"].permute(0, 2, 3, 1)).abs().max().item()
     assert out.shape == (1, res, res, 3)
     assert e < max(1e-2 + 0.5 / 255, 2.5 * e_or), (e, e_or)
+
+
+def test_prior_outputs_do_not_alias(gpu):
+    """two priors computed back to back must both stay valid (callers batch several backgrounds)"""
+    from domain_rag_amd import redux, vit
+    vitcfg = vit.VitConfig(image_size=56, patch_size=14, hidden=192, heads=2, layers=1, intermediate=304)
+    prior = redux.ReduxPriorHIP(vitcfg, vit.init_generic_params(vitcfg, 2), redux.init_redux_params(192, 256, seed=3), gpu)
+    g = torch.Generator().manual_seed(1)
+    bg = torch.randint(0, 256, (2, 56, 56, 3), generator=g, dtype=torch.uint8).to(gpu)
+    t5 = torch.randn(24, 256, generator=g).bfloat16().to(gpu); pooled = torch.randn(64, generator=g).bfloat16().to(gpu)
+    a, pa = prior(bg[0:1], t5, pooled, [1.0], [1.0], group=1)
+    a0 = a.clone()
+    b, pb = prior(bg[1:2], t5, pooled, [1.0], [1.0], group=1)
+    assert torch.equal(a, a0) and not torch.equal(a, b) and a.data_ptr() != b.data_ptr() and pa.data_ptr() != pb.data_ptr()
