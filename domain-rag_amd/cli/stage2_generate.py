@@ -44,6 +44,7 @@ def build_parser():
     p.add_argument("--tiny", action="store_true", help="test hook: tiny architectures, small images")
     p.add_argument("--num_inference_steps", type=int, default=STEPS)
     p.add_argument("--size", type=int, default=SIZE)
+    p.add_argument("--ref_batch", type=int, default=8, help="references of one target generated per batch (1 = one at a time like the reference)")
     p.add_argument("--fallback-seed", type=int, default=None, help="seed the random-COCO fallback (reference: unseeded)")
     return p
 
@@ -52,44 +53,68 @@ DATASET_GROUPS = {"dataset1": ["ArTaxOr", "clipart1k"], "dataset2": ["DIOR", "FI
                   "dataset4": ["NWPU_VHR_10", "Camouflage"]}
 
 
-def generate_one(engine: Engine, ref_path, target_path, out_path, rank, similarity, args, database):
-    """generate_image (:439-524)"""
+def generate_ranked(engine: Engine, target_path, items, sdir, args, database):
+    """generate_image (:439-524) for the retrieved references of ONE target, composited as one batch (the reference
+    runs them one at a time; each image's arithmetic is independent of its batch neighbours, so the pixels are the same).
+    ``items`` = [(similarity, ref_path, rank)].  Returns (n_ok, n_failed); failures are logged and skipped."""
     from PIL import Image
+    ok = bad = 0
     try:
-        ref_img, tgt_img = Image.open(ref_path).convert("RGB"), Image.open(target_path).convert("RGB")
-        w, h = tgt_img.size
-        w, h = max((w // 16) * 16, 64), max((h // 16) * 16, 64)        # computed and recorded, not used (:447-456,:470-471)
-        pe, pp = engine.prior_embeds([ref_img, tgt_img], PROMPT, [COCO_IMAGE_SCALE, TARGET_IMAGE_SCALE],
-                                     [COCO_TEXT_SCALE, TARGET_TEXT_SCALE])
-        noise = pack_noise(generator_noise(SEED, 1, args.size, args.size, 1)[0])
-        img = engine.pipe(pe, pp, height=args.size, width=args.size, guidance_scale=GUIDANCE,
-                          num_inference_steps=args.num_inference_steps, noise_tokens=noise)
-        os.makedirs(os.path.dirname(out_path), exist_ok=True)
-        Image.fromarray(img[0].cpu().numpy()).save(out_path)
-        d = os.path.dirname(out_path)
-        pf = os.path.join(d, "params.txt")
-        if not os.path.exists(pf):
-            with open(pf, "w") as f:
-                f.write(f"数据库类型: {database}\n参考图像权重: {COCO_IMAGE_SCALE}\n目标图像权重: {TARGET_IMAGE_SCALE}\n"
-                        f"参考文本权重: {COCO_TEXT_SCALE}\n目标文本权重: {TARGET_TEXT_SCALE}\n提示词: {PROMPT}\n指导比例: {GUIDANCE}\n"
-                        f"推理步数: {args.num_inference_steps}\n生成图像尺寸: {w}x{h}\n原始图像尺寸: {tgt_img.size[0]}x{tgt_img.size[1]}\n")
-        rs = f"rank{rank}" if rank is not None else ""
-        ss = f"_sim{similarity:.4f}" if similarity is not None else ""
-        with open(os.path.join(d, f"ref_info{rs}{ss}.txt"), "w") as f:
-            f.write(f"数据库类型: {database}\n参考图像: {ref_path}\n目标图像: {target_path}\n生成图像尺寸: {w}x{h}\n"
-                    f"原始图像尺寸: {tgt_img.size[0]}x{tgt_img.size[1]}\n")
-            if rank is not None:
-                f.write(f"排名: {rank}\n")
-            if similarity is not None:
-                f.write(f"相似度: {similarity}\n")
-        tgt_out = os.path.join(d, "target_input.png")
-        if not os.path.exists(tgt_out):
-            shutil.copy(target_path, tgt_out)
-        shutil.copy(ref_path, os.path.join(d, f"ref_input{rs}.jpg"))
-        return True
+        tgt_img = Image.open(target_path).convert("RGB")
     except Exception as e:   # reference convention: log, continue
         print(f"生成图像时出错: {str(e)}")
-        return False
+        return 0, len(items)
+    w, h = tgt_img.size
+    w, h = max((w // 16) * 16, 64), max((h // 16) * 16, 64)        # computed and recorded, not used (:447-456,:470-471)
+    ready = []
+    for sim, ref_path, rank in items:
+        try:
+            ref_img = Image.open(ref_path).convert("RGB")
+            ready.append((sim, ref_path, rank, engine.prior_embeds([ref_img, tgt_img], PROMPT, [COCO_IMAGE_SCALE, TARGET_IMAGE_SCALE],
+                                                                   [COCO_TEXT_SCALE, TARGET_TEXT_SCALE])))
+        except Exception as e:
+            print(f"生成图像时出错: {str(e)}")
+            bad += 1
+    bs = max(1, args.ref_batch)
+    for c0 in range(0, len(ready), bs):
+        chunk = ready[c0:c0 + bs]
+        try:
+            pe, pp = torch.cat([c[3][0] for c in chunk], 0), torch.cat([c[3][1] for c in chunk], 0)
+            noise = pack_noise(generator_noise(SEED, 1, args.size, args.size, 1)[0]).expand(len(chunk), -1, -1).contiguous()   # seed 0 every time (:468)
+            imgs = engine.pipe(pe, pp, height=args.size, width=args.size, guidance_scale=GUIDANCE,
+                               num_inference_steps=args.num_inference_steps, noise_tokens=noise).cpu().numpy()
+        except Exception as e:
+            print(f"生成图像时出错: {str(e)}")
+            bad += len(chunk)
+            continue
+        os.makedirs(sdir, exist_ok=True)
+        for (similarity, ref_path, rank, _), arr in zip(chunk, imgs):
+            try:
+                Image.fromarray(arr).save(os.path.join(sdir, f"generated_image_rank{rank}.png"))
+                pf = os.path.join(sdir, "params.txt")
+                if not os.path.exists(pf):
+                    with open(pf, "w") as f:
+                        f.write(f"数据库类型: {database}\n参考图像权重: {COCO_IMAGE_SCALE}\n目标图像权重: {TARGET_IMAGE_SCALE}\n"
+                                f"参考文本权重: {COCO_TEXT_SCALE}\n目标文本权重: {TARGET_TEXT_SCALE}\n提示词: {PROMPT}\n指导比例: {GUIDANCE}\n"
+                                f"推理步数: {args.num_inference_steps}\n生成图像尺寸: {w}x{h}\n原始图像尺寸: {tgt_img.size[0]}x{tgt_img.size[1]}\n")
+                rs = f"rank{rank}" if rank is not None else ""
+                ss = f"_sim{similarity:.4f}" if similarity is not None else ""
+                with open(os.path.join(sdir, f"ref_info{rs}{ss}.txt"), "w") as f:
+                    f.write(f"数据库类型: {database}\n参考图像: {ref_path}\n目标图像: {target_path}\n生成图像尺寸: {w}x{h}\n"
+                            f"原始图像尺寸: {tgt_img.size[0]}x{tgt_img.size[1]}\n")
+                    if rank is not None:
+                        f.write(f"排名: {rank}\n")
+                    if similarity is not None:
+                        f.write(f"相似度: {similarity}\n")
+                tgt_out = os.path.join(sdir, "target_input.png")
+                if not os.path.exists(tgt_out):
+                    shutil.copy(target_path, tgt_out)
+                shutil.copy(ref_path, os.path.join(sdir, f"ref_input{rs}.jpg"))
+                ok += 1
+            except Exception as e:
+                print(f"生成图像时出错: {str(e)}")
+                bad += 1
+    return ok, bad
 
 
 def process_dataset(engine, results, dataset, shot, args, rank, world):
@@ -129,11 +154,9 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
                 f.write(str(ex))
             bad += 1
             continue
-        for sim, real, r in top:          # paths are already fixed up and checked (hostlogic.correct_image_path)
-            if generate_one(engine, real, target, os.path.join(sdir, f"generated_image_rank{r}.png"), r, sim, args, args.database):
-                ok += 1
-            else:
-                bad += 1
+        n_ok, n_bad = generate_ranked(engine, target, top, sdir, args, args.database)   # paths are already fixed up and checked
+        ok += n_ok
+        bad += n_bad
     return ok, bad
 
 
