@@ -51,7 +51,7 @@ def siglip_input_device(pil_images, size: int, device) -> torch.Tensor:
     from . import resample
     out = torch.empty((len(pil_images), size, size, 3), dtype=torch.uint8, device=device)
     for i, im in enumerate(pil_images):
-        raw = torch.from_numpy(np.array(im.convert("RGB"), dtype=np.uint8, copy=True)).to(device, non_blocking=True)
+        raw = torch.from_numpy(np.array(im.convert("RGB"), dtype=np.uint8, copy=True)).to(device)
         resample.siglip_resize_u8(raw, size, out=out[i])
     return out
 

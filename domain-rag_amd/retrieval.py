@@ -68,7 +68,7 @@ def clip_preprocess_device(pil_image, device="cuda", size: int = 224) -> torch.T
     ToTensor / Normalize run inside ``drag_patchify_u8`` with torch's arithmetic, so ``encode_image`` of this equals
     ``encode_image(clip_preprocess(pil_image))`` bit for bit."""
     from . import resample
-    raw = torch.from_numpy(np.array(pil_image.convert("RGB"), dtype=np.uint8, copy=True)).to(device, non_blocking=True)
+    raw = torch.from_numpy(np.array(pil_image.convert("RGB"), dtype=np.uint8, copy=True)).to(device)
     return resample.clip_preprocess_u8(raw, size)
 
 
