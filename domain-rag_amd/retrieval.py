@@ -277,9 +277,14 @@ def allgather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tenso
     return torch.cat(parts, 0)
 
 
-def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list[str], batch: int = 256):
+def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list[str], batch: int = 256, decode_workers: int | None = None):
     """compute_coco_clip_features (ref :236-298), batched and rank-sharded.  Returns (features float32 [n,512]
-    numpy in path order, valid_paths).  Unreadable images are skipped like the reference (:290-292)."""
+    numpy in path order, valid_paths).  Unreadable images are skipped like the reference (:290-292).
+    File decoding (PIL releases the GIL while it decodes) runs ``decode_workers`` images ahead on a thread pool; the
+    GPU work (resize when ``preprocess`` is the device one, embedding) stays on this thread, in path order."""
+    import collections
+    import concurrent.futures as cf
+    import os as _os
     import torch.distributed as dist
     from PIL import Image
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -297,14 +302,27 @@ def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list
             ok[ii] = 1.0
             buf.clear(); idxs.clear()
 
-    for j, p in enumerate(image_paths[s:e]):
-        try:
-            buf.append(preprocess(Image.open(clean_image_path(p)).convert("RGB")))
-            idxs.append(j)
-        except Exception as ex:
-            print(f"处理图像 {p} 时出错: {ex}")
-        if len(buf) == batch:
-            flush()
+    def decode(p):
+        img = Image.open(clean_image_path(p)).convert("RGB")
+        img.load()
+        return img
+
+    workers = decode_workers if decode_workers is not None else min(16, _os.cpu_count() or 1)
+    mine = image_paths[s:e]
+    with cf.ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+        pending: collections.deque = collections.deque()
+        nxt = 0
+        for j, p in enumerate(mine):
+            while nxt < len(mine) and len(pending) < 4 * max(1, workers):
+                pending.append(pool.submit(decode, mine[nxt])); nxt += 1
+            fut = pending.popleft()
+            try:
+                buf.append(preprocess(fut.result()))
+                idxs.append(j)
+            except Exception as ex:
+                print(f"处理图像 {p} 时出错: {ex}")
+            if len(buf) == batch:
+                flush()
     flush()
     allf = allgather_rows(torch.cat([feats, ok], 1), len(image_paths))
     keep = allf[:, 512] > 0.5
