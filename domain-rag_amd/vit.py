@@ -168,7 +168,7 @@ class VitHIP:
         T, D, H = cfg.tokens, cfg.hidden, cfg.heads
         nP = T - (1 if cfg.cls_token else 0)
         bf = dict(dtype=torch.bfloat16, device=self.dev)
-        tmpl = self.pos[None].expand(B, T, D).contiguous()
+        tmpl = self.pos[None].expand(B, T, D).clone()      # clone: for B = 1 .contiguous() would alias self.pos and the += below would corrupt it
         if cfg.cls_token:
             tmpl[:, 0] += self.cls           # setup-time constant (class_embedding + positional_embedding[0])
         ws = dict(tmpl=tmpl, patches=torch.empty((B * nP, self.Kp), **bf), x=torch.empty((B, T, D), **bf),

@@ -64,3 +64,17 @@ def test_redux_prior(gpu, N, es, ps):
         r_pe, r_pp = ored.redux_prior(lat32[gi * N:(gi + 1) * N], rp32, t5.float(), pooled.float(), es, ps)
         assert _rel(pe[gi], r_pe[0]) < 2e-2
         assert _rel(pp[gi], r_pp[0]) < 1e-2
+
+
+def test_clip_embedding_is_independent_of_batch_history(gpu):
+    """one image at a time (the reference's loop shape), then batches, then single again: every row must keep its bits
+    (a B = 1 workspace once aliased the positional embedding and added the class token into it)"""
+    from domain_rag_amd import retrieval as R
+    model, _ = R.load_clip("ViT-B/32", device=gpu)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (45, 224, 224, 3), generator=g, dtype=torch.uint8).to(gpu)
+    first = model.encode_image(x[:1]).clone()
+    batch = model.encode_image(x).clone()           # M = 2250: the GEMMs mix both tile kernels
+    again = model.encode_image(x[:1]).clone()
+    small = model.encode_image(x[:7]).clone()
+    assert torch.equal(first, again) and torch.equal(first[0], batch[0]) and torch.equal(small, batch[:7])
