@@ -131,7 +131,13 @@ class FluxTxt2ImgHIP:
                  noise_tokens: torch.Tensor) -> torch.Tensor:
         B = prompt_embeds.shape[0]
         h, w = height // 16, width // 16
-        lat = noise_tokens.to(self.dev, torch.bfloat16).clone()
+        key = (B, h, w, prompt_embeds.shape[1])
+        if getattr(self, "_key", None) != key:      # stable addresses: one captured graph serves every call of this shape
+            bf = dict(dtype=torch.bfloat16, device=self.dev)
+            self._lat, self._pe, self._pp = torch.empty((B, h * w, 64), **bf), torch.empty_like(prompt_embeds, **bf), torch.empty_like(pooled, **bf)
+            self._key = key
+        self._lat.copy_(noise_tokens); self._pe.copy_(prompt_embeds); self._pp.copy_(pooled)
+        lat, prompt_embeds, pooled = self._lat, self._pe, self._pp
         sigmas, timesteps = flow_sigmas(num_inference_steps, h * w)
         img_ids, txt_ids = latent_image_ids(h, w), torch.zeros(prompt_embeds.shape[1], 3)
         guidance = torch.full((B,), float(guidance_scale)) if self.tr.cfg.guidance_embeds else None

@@ -35,7 +35,11 @@ class FluxFillHIP:
         key = (B, H, W, St)
         if self._key != key:
             h, w = H // 16, W // 16
-            self._hidden = torch.empty((B, h * w, self.tr.cfg.in_channels), dtype=torch.bfloat16, device=self.dev)
+            cfg = self.tr.cfg
+            bf = dict(dtype=torch.bfloat16, device=self.dev)
+            self._hidden = torch.empty((B, h * w, cfg.in_channels), **bf)
+            # the prior's embeddings are copied here: stable addresses, so one captured graph serves every call of this shape
+            self._pe, self._pp = torch.empty((B, St, cfg.joint_attention_dim), **bf), torch.empty((B, cfg.pooled_projection_dim), **bf)
             self._img_ids, self._txt_ids = latent_image_ids(h, w), torch.zeros(St, 3)
             self._key = key
         return self._hidden
@@ -51,6 +55,8 @@ class FluxFillHIP:
         Si, St = h * w, prompt_embeds.shape[1]
         C = self.tr.cfg.in_channels
         hidden = self._buffers(B, H, W, St)
+        self._pe.copy_(prompt_embeds); self._pp.copy_(pooled)
+        prompt_embeds, pooled = self._pe, self._pp
         hv = hidden.view(-1)
         ops.set_recorder(recorder)
         try:

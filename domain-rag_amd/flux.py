@@ -140,8 +140,14 @@ class FluxTransformerHIP:
         self._ws_key, self._ws = key, ws
         return ws
 
+    @staticmethod
+    def _ids_key(txt_ids, img_ids):
+        """identity of the position ids (order-sensitive: 4 x 6 and 6 x 4 latents have the same token count and sums)"""
+        return (tuple(txt_ids.shape), tuple(img_ids.shape), hash(txt_ids.cpu().float().contiguous().numpy().tobytes()),
+                hash(img_ids.cpu().float().contiguous().numpy().tobytes()))
+
     def _rope(self, txt_ids, img_ids):
-        key = (tuple(txt_ids.shape), tuple(img_ids.shape), float(img_ids.sum()), float(txt_ids.sum()))
+        key = self._ids_key(txt_ids, img_ids)
         if self._rope_key != key:
             cos, sin = rope_tables(torch.cat([txt_ids.cpu().float(), img_ids.cpu().float()], dim=0), self.cfg.axes_dims_rope)
             self._rope_cs = (cos.to(self.device), sin.to(self.device))
@@ -269,29 +275,48 @@ class FluxTransformerHIP:
         return ws["out"].view(B, Si, cfg.out_channels)
 
     # ------------------------------------------------------------------ hipGraph replay
+    MAX_GRAPHS = 3          # captured forwards kept alive (each owns a workspace: ~1 GB per image at 1024^2)
+
     def forward_graphed(self, hidden, enc, pooled, timestep, img_ids, txt_ids, guidance=None):
         """Same result as ``forward`` (bit-identical: same kernels, same order), but the ~800 launches of one forward
-        are captured ONCE into a hipGraph per (shape, buffer addresses) and replayed: the host cost of a forward
-        drops from ~57 ms of Python/ctypes enqueueing to one graph launch, which is what bounds small batches
-        (at B=1 a forward is 83 ms of GPU time, much of it short kernels the host cannot feed fast enough).
-        Inputs must live in stable buffers (they do in the pipelines); only the timestep changes between replays
-        and travels through a persistent device buffer updated before the launch."""
+        are captured ONCE into a hipGraph and replayed; only the timestep / guidance values change between replays and
+        travel through device buffers updated before the launch.  The GPU was never launch-bound (host enqueue 4.8 ms
+        vs 83.7 ms of GPU time at B = 1): the replay (0.2 ms) frees the host thread for image I/O.
+        A captured graph bakes in the addresses of everything the forward touched, so a cache entry OWNS its workspace,
+        RoPE tables and time buffers (they must not be freed or reused while the graph lives), is keyed on the input
+        addresses, the shapes AND the RoPE table identity (the same token count can be a different h x w), and the
+        cache is a small LRU (image sizes vary from sample to sample in stage 3)."""
         t = torch.as_tensor(timestep, dtype=torch.float32).cpu().reshape(-1)
         g = None if guidance is None else torch.as_tensor(guidance, dtype=torch.float32).cpu().reshape(-1)
-        key = (hidden.data_ptr(), enc.data_ptr(), pooled.data_ptr(), tuple(hidden.shape), tuple(enc.shape), guidance is None)
-        self._set_times(t, g)
+        rope_key = self._ids_key(txt_ids, img_ids)
+        key = (hidden.data_ptr(), enc.data_ptr(), pooled.data_ptr(), tuple(hidden.shape), tuple(enc.shape), tuple(pooled.shape),
+               guidance is None, rope_key)
         cache = self.__dict__.setdefault("_graphs", {})
-        ent = cache.get(key)
+        ent = cache.pop(key, None)
         if ent is None:
-            self._rope(txt_ids, img_ids)                     # host-side table build + upload happen outside capture
-            self._workspace(hidden.shape[0], enc.shape[1], hidden.shape[1])
-            self.forward(hidden, enc, pooled, None, img_ids, txt_ids, g)   # warm-up: allocates every workspace
+            while len(cache) >= self.MAX_GRAPHS:
+                cache.pop(next(iter(cache)))                 # least recently used: drops its graph, workspace and tables
+            # private buffers for this capture: nothing the eager path (or another graph) will ever reallocate
+            self._ws_key = self._rope_key = None
+            self._t1000 = self._g1000 = None
+            self._set_times(t, g)
+            rope = self._rope(txt_ids, img_ids)              # host-side table build + upload happen outside capture
+            ws = self._workspace(hidden.shape[0], enc.shape[1], hidden.shape[1])
+            self.forward(hidden, enc, pooled, None, img_ids, txt_ids, g)   # warm-up: allocates every temporary
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(hidden, enc, pooled, None, img_ids, txt_ids, g)
-            ent = cache[key] = (graph, out)
-        ent[0].replay()
-        return ent[1]
+            ent = dict(graph=graph, out=out, ws=ws, rope=rope, times=(self._t1000, self._g1000))
+            # hand the buffers over: the next eager forward / capture allocates its own
+            self._ws_key = self._rope_key = None
+            self._t1000 = self._g1000 = None
+        cache[key] = ent                                     # (re)insert as most recently used
+        t1000, g1000 = ent["times"]
+        t1000.copy_((t.to(torch.bfloat16) * 1000).float())
+        if g is not None:
+            g1000.copy_((g.to(torch.bfloat16) * 1000).float())
+        ent["graph"].replay()
+        return ent["out"]
 
     __call__ = forward

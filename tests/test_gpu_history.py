@@ -1,0 +1,89 @@
+"""History independence: every host class caches work buffers / graphs keyed by shape.  Running shape A, then other
+shapes, then A again must reproduce A's bits exactly (two aliasing bugs of this kind existed: a batch-1 ViT workspace
+that aliased the positional embedding, and Redux prior outputs that were views of reused buffers)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _flux(gpu):
+    from domain_rag_amd.flux import FluxTransformerHIP, latent_image_ids
+    from domain_rag_amd.flux_params import FluxConfig, init_params
+    cfg = FluxConfig(in_channels=64, num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64)
+    return FluxTransformerHIP(cfg, init_params(cfg, seed=1), gpu), latent_image_ids
+
+
+def test_dit_forward_history(gpu):
+    m, ids = _flux(gpu)
+    g = torch.Generator().manual_seed(0)
+
+    def inputs(B, h, w, St):
+        return (torch.randn(B, h * w, 64, generator=g).bfloat16().to(gpu), torch.randn(B, St, 128, generator=g).bfloat16().to(gpu),
+                torch.randn(B, 64, generator=g).bfloat16().to(gpu), torch.full((B,), 0.7), ids(h, w), torch.zeros(St, 3), torch.full((B,), 3.5))
+    a = inputs(2, 8, 8, 24)
+    r1 = m.forward(*a).clone()
+    g1 = m.forward_graphed(*a).clone()
+    for other in (inputs(1, 8, 8, 24), inputs(3, 4, 12, 40), inputs(1, 6, 6, 8)):
+        m.forward(*other); m.forward_graphed(*other)
+    assert torch.equal(m.forward(*a), r1) and torch.equal(m.forward_graphed(*a), g1) and torch.equal(r1, g1)
+    # batch rows are independent: image 0 alone gives image 0 of the batch
+    one = tuple(t[:1] if torch.is_tensor(t) and t.shape[0] == 2 else t for t in a)
+    assert torch.equal(m.forward(*one)[0], r1[0])
+
+
+def test_vae_history(gpu):
+    from domain_rag_amd import vae
+    cfg = vae.VaeConfig(layers_per_block=1)
+    model = vae.FluxVaeHIP(cfg, vae.init_params(cfg, seed=2), gpu)
+    g = torch.Generator().manual_seed(1)
+    tokA = torch.randn(2, 6 * 4, 64, generator=g).bfloat16().to(gpu)
+    tokB = torch.randn(1, 5 * 7, 64, generator=g).bfloat16().to(gpu)
+    imgA = torch.randint(0, 256, (2, 96, 64, 3), generator=g, dtype=torch.uint8).to(gpu)
+    imgB = torch.randint(0, 256, (1, 80, 112, 3), generator=g, dtype=torch.uint8).to(gpu)
+    d1 = model.decode_tokens(tokA, 2, 6, 4).clone()
+    e1 = torch.empty((2, 6 * 4, 64), dtype=torch.bfloat16, device=gpu); model.encode_to_tokens(imgA, None, None, e1, 64)
+    model.decode_tokens(tokB, 1, 5, 7)
+    eB = torch.empty((1, 5 * 7, 64), dtype=torch.bfloat16, device=gpu); model.encode_to_tokens(imgB, None, None, eB, 64)
+    model.decode_tokens(tokA[:1], 1, 6, 4)
+    d2 = model.decode_tokens(tokA, 2, 6, 4).clone()
+    e2 = torch.empty((2, 6 * 4, 64), dtype=torch.bfloat16, device=gpu); model.encode_to_tokens(imgA, None, None, e2, 64)
+    assert torch.equal(d1, d2) and torch.equal(e1, e2)
+    assert torch.equal(model.decode_tokens(tokA[:1], 1, 6, 4)[0], d1[0])          # batch independence
+
+
+def test_siglip_and_prior_history(gpu):
+    from domain_rag_amd import redux, vit
+    vitcfg = vit.VitConfig(image_size=56, patch_size=14, hidden=192, heads=2, layers=2, intermediate=304)
+    prior = redux.ReduxPriorHIP(vitcfg, vit.init_generic_params(vitcfg, 2), redux.init_redux_params(192, 256, seed=3), gpu)
+    g = torch.Generator().manual_seed(2)
+    bg = torch.randint(0, 256, (4, 56, 56, 3), generator=g, dtype=torch.uint8).to(gpu)
+    t5 = torch.randn(24, 256, generator=g).bfloat16().to(gpu); pooled = torch.randn(64, generator=g).bfloat16().to(gpu)
+    a1 = prior(bg[:1], t5, pooled, [1.2], [1.0], group=1)
+    b1 = prior(bg[:2], t5, pooled, [0.8, 1.0], [1.0, 1.0], group=2)
+    prior(bg, t5, pooled, [1.0] * 4, [1.0] * 4, group=1)
+    a2 = prior(bg[:1], t5, pooled, [1.2], [1.0], group=1)
+    b2 = prior(bg[:2], t5, pooled, [0.8, 1.0], [1.0, 1.0], group=2)
+    assert all(torch.equal(x, y) for x, y in zip(a1 + b1, a2 + b2))
+
+
+def test_fill_pipeline_history(gpu):
+    from domain_rag_amd.engine import Engine, generator_noise, pack_noise
+    eng = Engine("fill", synthetic=True, tiny=True, device=gpu)
+    g = torch.Generator().manual_seed(3)
+
+    def job(B, H, W, seed):
+        img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(gpu)
+        msk = torch.full((B, H, W), 255, dtype=torch.uint8); msk[:, 8:24, 8:40] = 0
+        pe = torch.randn(B, 20, 256, generator=g).bfloat16().to(gpu); pp = torch.randn(B, 64, generator=g).bfloat16().to(gpu)
+        en, nz, mn = generator_noise(seed, B, H, W, 3)
+        return dict(image_u8=img, mask_u8=msk.to(gpu), prompt_embeds=pe, pooled=pp, guidance_scale=30.0, num_inference_steps=2, strength=0.9,
+                    enc_noise=en.to(gpu), masked_enc_noise=mn.to(gpu), noise_tokens=pack_noise(nz).to(gpu))
+
+    def run(j):
+        return eng.pipe(j["image_u8"], j["mask_u8"], j["prompt_embeds"], j["pooled"], **{k: v for k, v in j.items()
+                        if k not in ("image_u8", "mask_u8", "prompt_embeds", "pooled")})
+    A, B_, C = job(2, 64, 96, 1), job(1, 48, 48, 2), job(3, 64, 96, 3)
+    r1 = run(A)
+    run(B_); run(C); run(B_)
+    assert torch.equal(run(A), r1)
