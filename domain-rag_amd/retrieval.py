@@ -195,17 +195,19 @@ class StemStyle:
 _index_cache: dict = {}
 
 
-def _index_for(dataset_features: dict, device) -> tuple[IndexFlatIP, list, list]:
-    """build the resident index ONCE per corpus (the reference rebuilds it for every query, :419-430)"""
-    key = tuple((name, id(f), len(f)) for name, f in dataset_features.items() if f is not None and len(f) > 0)
-    hit = _index_cache.get(key)
-    if hit is None:
-        feats = [np.asarray(f, dtype=np.float32) for _, f in dataset_features.items() if f is not None and len(f) > 0]
-        idx = IndexFlatIP(feats[0].shape[1], device)
-        idx.add(np.vstack(feats))
-        _index_cache.clear()
-        _index_cache[key] = hit = idx
-    return hit
+def _index_for(dataset_features: dict, device) -> IndexFlatIP:
+    """build the resident index ONCE per corpus (the reference rebuilds it for every query, :419-430).  The cache keeps
+    the arrays it was built from alive and compares by identity: an ``id()`` alone can be reused by a new array."""
+    used = [(name, f) for name, f in dataset_features.items() if f is not None and len(f) > 0]
+    ent = _index_cache.get("entry")
+    if ent is not None and ent["device"] == str(device) and len(ent["used"]) == len(used) and \
+            all(n0 == n1 and f0 is f1 for (n0, f0), (n1, f1) in zip(ent["used"], used)):
+        return ent["index"]
+    feats = [np.asarray(f, dtype=np.float32) for _, f in used]
+    idx = IndexFlatIP(feats[0].shape[1], device)
+    idx.add(np.vstack(feats))
+    _index_cache["entry"] = dict(used=used, index=idx, device=str(device))
+    return idx
 
 
 def clip_first_stage_retrieval(query_feature, dataset_features: dict, dataset_paths: dict, top_k: int = 100, device="cuda"):

@@ -134,6 +134,14 @@ class FluxVaeHIP:
     def release(self):
         self._bufs.clear()
 
+    def _frame(self, B, H, W):
+        """work buffers are kept per (tag, shape); when the frame size changes the previous frame's set is dropped, so a
+        long run over many image sizes does not accumulate one full buffer set per size"""
+        key = (B, H, W)
+        if getattr(self, "_frame_key", None) != key:
+            self._bufs.clear()
+            self._frame_key = key
+
     # ------------------------------------------------------------------ layers (NHWC)
     def _conv(self, xp, name, B, H, W, Cin, out_tag, resid=None, stride=1, origin=0, Ho=None, Wo=None):
         w = self.w[name + ".weight"]
@@ -200,6 +208,7 @@ class FluxVaeHIP:
         cfg = self.cfg
         rev = tuple(reversed(cfg.block_out_channels))
         H, W = 2 * h, 2 * w
+        self._frame(B, 16 * h, 16 * w)
         zp = self._buf("dec_z", (B, H + 2, W + 2, 64), zero=True)
         ops.unpack_latents(tokens, zp, B, h, w, ld, 64, SCALING, SHIFT)
         x = self._conv(zp, "decoder.conv_in", B, H, W, cfg.latent_channels, "dec_in")
@@ -229,6 +238,7 @@ class FluxVaeHIP:
         cfg = self.cfg
         bo = cfg.block_out_channels
         B, H, W, _ = img_u8.shape
+        self._frame(B, H, W)
         xp = self._buf("enc_in", (B, H + 2, W + 2, 64), zero=True)
         ops.image_preprocess(img_u8, mask_u8, xp, B, H, W, 64)
         x = self._conv(xp, "encoder.conv_in", B, H, W, cfg.in_channels, "enc_x0")
