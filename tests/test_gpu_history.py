@@ -87,3 +87,25 @@ def test_fill_pipeline_history(gpu):
     r1 = run(A)
     run(B_); run(C); run(B_)
     assert torch.equal(run(A), r1)
+
+
+def test_txt2img_history_and_transposed_sizes(gpu):
+    """64 x 96 and 96 x 64 have the same token count: the RoPE tables (and any captured graph) must not be shared"""
+    from domain_rag_amd.engine import Engine, generator_noise, pack_noise
+    eng = Engine("dev", synthetic=True, tiny=True, device=gpu)
+    g = torch.Generator().manual_seed(4)
+    pe = torch.randn(1, 20, 256, generator=g).bfloat16().to(gpu); pp = torch.randn(1, 64, generator=g).bfloat16().to(gpu)
+
+    def run(H, W, use_graph):
+        eng.pipe.use_graph = use_graph
+        return eng.pipe(pe, pp, height=H, width=W, guidance_scale=2.5, num_inference_steps=2,
+                        noise_tokens=pack_noise(generator_noise(0, 1, H, W, 1)[0]))
+    wide_eager, tall_eager = run(64, 96, False), run(96, 64, False)
+    wide, tall = run(64, 96, True), run(96, 64, True)
+    assert torch.equal(wide, wide_eager) and torch.equal(tall, tall_eager)
+    assert torch.equal(run(64, 96, True), wide) and torch.equal(run(64, 96, False), wide_eager)
+    # fresh engine, transposed size FIRST: same pixels as above (nothing leaked between the two sizes)
+    eng2 = Engine("dev", synthetic=True, tiny=True, device=gpu)
+    eng2.pipe.use_graph = False
+    t2 = eng2.pipe(pe, pp, height=96, width=64, guidance_scale=2.5, num_inference_steps=2, noise_tokens=pack_noise(generator_noise(0, 1, 96, 64, 1)[0]))
+    assert torch.equal(t2, tall_eager)
