@@ -96,8 +96,13 @@ def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None 
         raise ValueError("Domain-RAG uses CLIP ViT-B/32 only")
     cfg = VitConfig.clip_vit_b32()
     if isinstance(weights, str):
-        weights = torch.load(weights, map_location="cpu")
+        try:                       # openai distributes ViT-B-32.pt as a TorchScript archive
+            weights = torch.jit.load(weights, map_location="cpu").state_dict()
+        except RuntimeError:
+            weights = torch.load(weights, map_location="cpu")
     if weights is not None:
+        weights = {k: v for k, v in weights.items() if torch.is_tensor(v)}
+        cfg = VitConfig.from_openai_state_dict(weights)
         g = openai_clip_to_generic(weights, cfg)
     else:
         g = init_generic_params(cfg, seed, device=device if str(device) != "cpu" else "cpu")

@@ -45,6 +45,17 @@ class VitConfig:
                    act=ops.ACT_QUICK_GELU, ln_eps=1e-5, cls_token=True, patch_bias=False, proj_dim=512,
                    mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711))
 
+    @classmethod
+    def from_openai_state_dict(cls, sd: dict) -> "VitConfig":
+        """ViT dimensions of an openai/CLIP state_dict (how ``clip.model.build_model`` infers them)"""
+        D, _, P, _ = sd["visual.conv1.weight"].shape
+        layers = len({k.split(".")[3] for k in sd if k.startswith("visual.transformer.resblocks.")})
+        grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+        c = cls.clip_vit_b32()
+        return cls(image_size=grid * P, patch_size=P, hidden=D, heads=D // 64, layers=layers,
+                   intermediate=sd["visual.transformer.resblocks.0.mlp.c_fc.weight"].shape[0], act=c.act, ln_eps=c.ln_eps, cls_token=True,
+                   patch_bias=False, proj_dim=sd["visual.proj"].shape[1], mean=c.mean, std=c.std)
+
     @property
     def tokens(self) -> int:
         return (self.image_size // self.patch_size) ** 2 + (1 if self.cls_token else 0)
