@@ -198,9 +198,11 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
     return log
 
 
-def collect_final_results(process_id, shot):
-    """copy_final_results_to_collection (:1813-1886)"""
-    root = f"./outpaint_hires/process_{process_id}"
+def collect_final_results(process_id, shot, source_process_id=None):
+    """copy_final_results_to_collection (:1813-1886).  ``source_process_id``: collect another process's outputs into this
+    process's collection (the per-GPU ``<P>_gpu<g>`` trees of a multi-GPU run; the reference scans only ``process_<P>``, which
+    then holds nothing but the merged JSON, and collects no images)."""
+    root = f"./outpaint_hires/process_{source_process_id or process_id}"
     dest_root = f"./final_results/process_{process_id}/{shot}_shot"
     n = 0
     for ds in sorted(os.listdir(root)) if os.path.isdir(root) else []:
@@ -217,7 +219,7 @@ def collect_final_results(process_id, shot):
 
 
 def run_rank(args, datasets, process_id, rank, world, gpu_process_id=None):
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank))) % max(torch.cuda.device_count(), 1)   # (more ranks than GPUs: share them)
     torch.cuda.set_device(local)
     engine = Engine("fill", args.model_root, synthetic=args.synthetic_weights, tiny=args.tiny, device=torch.device("cuda", local))
     rng = random.Random(None if args.seed is None else args.seed + rank)
@@ -281,6 +283,8 @@ def main(argv=None):
                 os.makedirs(od, exist_ok=True)
                 with open(os.path.join(od, f"outpaint_results_{args.shot}shot.json"), "w", encoding="utf-8") as f:
                     json.dump(merged, f, indent=2, ensure_ascii=False)
+        for g in range(n):
+            collect_final_results(process_id, args.shot, source_process_id=H.create_gpu_process_id(process_id, g))
         return max(rc) if rc else 0
     gpid = H.create_gpu_process_id(process_id, rank) if world > 1 else None
     run_rank(args, datasets, process_id, rank, world, gpid)

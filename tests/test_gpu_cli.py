@@ -92,3 +92,16 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
     for r in range(1, 6):
         assert np.array_equal(np.asarray(Image.open(sd / f"{pre}_hires_result_{r}.png")), np.asarray(Image.open(sd8 / f"{pre}_hires_result_{r}.png")))
         assert json.load(open(sd / f"{pre}_params_{r}.json"))["seed"] == json.load(open(sd8 / f"{pre}_params_{r}.json"))["seed"]
+    # ---- stage 3, --multi_gpu with two worker processes (they share the one GPU of the test box): contiguous sharding,
+    # per-GPU process ids, merged manifest with the multi-GPU bookkeeping, images collected from both workers
+    _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "9", "--dataset", ds, "--shot", "1", "--synthetic-weights", "--tiny",
+                                                 "--num_inference_steps", "2", "--seed", "3", "--multi_gpu", "--num_gpus", "2"], cwd=root)
+    merged = json.load(open(root / "outpaint_hires" / "process_9" / ds / "1_shot" / "outpaint_results_1shot.json"))
+    assert merged["multi_gpu"] is True and merged["num_gpus"] == 2 and merged["gpu_process_ids"] == ["9_gpu0", "9_gpu1"]
+    assert [smp["sample_id"] for smp in merged["samples"]] == ["beetle_01", "moth_02"]
+    assert (root / "outpaint_hires" / "process_9_gpu0" / ds / "1_shot" / "beetle_01").is_dir()
+    assert (root / "outpaint_hires" / "process_9_gpu1" / ds / "1_shot" / "moth_02").is_dir()
+    assert len(list((root / "final_results" / "process_9" / "1_shot" / ds / "1_shot").glob("*_final_result*.png"))) == 10
+    # worker 0 draws its seeds from args.seed + 0 like the single-process run: same pixels for its samples
+    sd9 = root / "outpaint_hires" / "process_9_gpu0" / ds / "1_shot" / "beetle_01"
+    assert np.array_equal(np.asarray(Image.open(sd / f"{pre}_hires_result_1.png")), np.asarray(Image.open(sd9 / f"{pre}_hires_result_1.png")))
