@@ -96,6 +96,35 @@ def main():
         masks.append({"W": W, "H": H, "bboxes": bbs, "sha256": hashlib.sha256(a.tobytes()).hexdigest(),
                       "white": int((a == 255).sum()), "mode": m.mode})
     g["generate_outpaint_mask"] = masks
+    # ---- randomised sweeps (seeded): more of the same two functions, arbitrary sizes / float boxes / boxes off the canvas
+    rs = np.random.default_rng(11)
+    sweep = []
+    for _ in range(300):
+        w, h = int(rs.integers(16, 5000)), int(rs.integers(16, 5000))
+        mind = int(rs.choice([512, 1024, 2048]))
+        try:
+            out, up, down, wu, wd = s3.process_image_resolution(Image.new("RGB", (w, h)), mind, 2800)
+            sweep.append([w, h, mind, out.size[0], out.size[1], up, down, wu, wd])
+        except ValueError:
+            sweep.append([w, h, mind, None])
+    g["process_image_resolution_sweep"] = sweep
+    msweep = []
+    for _ in range(120):
+        W, H = int(rs.integers(8, 400)), int(rs.integers(8, 400))
+        bbs = []
+        for _ in range(int(rs.integers(0, 4))):
+            x, y = float(rs.uniform(-0.3 * W, 1.2 * W)), float(rs.uniform(-0.3 * H, 1.2 * H))
+            bw, bh = float(rs.uniform(-5, 0.8 * W)), float(rs.uniform(-5, 0.8 * H))
+            if rs.random() < 0.5:
+                x, y, bw, bh = int(x), int(y), int(bw), int(bh)
+            bbs.append([x, y, bw, bh])
+        try:
+            m, _ = s3.generate_outpaint_mask(Image.new("RGB", (W, H)), bbs)
+            a = np.asarray(m)
+            msweep.append({"W": W, "H": H, "bboxes": bbs, "sha256": hashlib.sha256(a.tobytes()).hexdigest(), "white": int((a == 255).sum())})
+        except Exception as e:
+            msweep.append({"W": W, "H": H, "bboxes": bbs, "error": type(e).__name__})
+    g["generate_outpaint_mask_sweep"] = msweep
     # ---- sharding / merge
     g["split_samples_for_gpus"] = [{"n": n, "g": k, "sizes": [len(c) for c in s3.split_samples_for_gpus(list(range(n)), k)],
                                     "first": [c[0] if c else None for c in s3.split_samples_for_gpus(list(range(n)), k)]}

@@ -129,3 +129,24 @@ def test_second_stage_rerank_matches_reference():
     cache: dict = {}
     assert R.resnet_second_stage_rerank(gg["query"], gg["first"], FakeStem(), cache) == gg["out"] and len(cache) == 11
     assert R.resnet_second_stage_rerank("unreadable.jpg", gg["first"][:3], FakeStem()) == gg["out_query_unreadable"]
+
+
+def test_randomised_sweeps_match_reference():
+    """300 random sizes through the resolution policy and 120 random (float / negative / off-canvas) box sets through the
+    outpaint mask, expected values captured from the imported reference"""
+    import hashlib
+    from domain_rag_amd import hostlogic as H
+    for row in GOLD["process_image_resolution_sweep"]:
+        w, h, mind = row[:3]
+        if row[3] is None:
+            with pytest.raises(ValueError):
+                H.resolution_plan(w, h, mind, 2800)
+        else:
+            assert list(H.resolution_plan(w, h, mind, 2800)) == row[3:], row
+    for c in GOLD["generate_outpaint_mask_sweep"]:
+        if "error" in c:
+            with pytest.raises(Exception):
+                H.outpaint_mask_array(c["W"], c["H"], c["bboxes"])
+            continue
+        m = H.outpaint_mask_array(c["W"], c["H"], c["bboxes"])
+        assert int((m == 255).sum()) == c["white"] and hashlib.sha256(m.tobytes()).hexdigest() == c["sha256"], c
