@@ -119,6 +119,33 @@ def main():
                   "../missing/b.jpg", "/DATA_HDD/ly/Flux/retrieval/datasets/extra/a.jpg", "/DATA_HDD/ly/Flux/retrieval/datasets/extra/none.jpg",
                   "/somewhere/000000000004.png", "/somewhere/none.png", "/x/miniimagenet/train/n01/img.jpg"]:
             g["correct_path"].append({"path": p, **call(ref.get_correct_image_path, p)})
+        # fuzz: sample names assembled from category-like tokens, separators and numbers against the fixed trees
+        import random as _r
+        rr = _r.Random(7)
+        toks = ["pitted", "surface", "pitted_surface", "rolled", "rolled-in", "scale", "rolled-in_scale", "crazing", "craze", "inclusion",
+                "inclusions", "patches", "patch", "scratches", "scratch", "x", "ab", "img", "UPPER", "direct", "sample", "variant", "a-b", ""]
+        names = set()
+        while len(names) < 160:
+            k = rr.randint(1, 3)
+            parts = [rr.choice(toks) for _ in range(k)]
+            name = parts[0]
+            for q in parts[1:]:
+                name += rr.choice(["_", "-", ""]) + q
+            if rr.random() < 0.7:
+                name += rr.choice(["_", "-", ""]) + str(rr.choice([1, 3, 7, 12, 14, 22, 99, 106]))
+            if rr.random() < 0.15:
+                name = name.upper() if rr.random() < 0.5 else name.capitalize()
+            names.add(name)
+        g["fuzz"] = []
+        for name in sorted(names):
+            r1 = call(ref.find_neudet_sample, T["neu"], name, 5)
+            r2 = call(ref.get_top5_similar_images_from_json, T["generic"], name, "ArTaxOr", 5) if name not in ("",) else {"skip": True}
+            if "ok" in r2:
+                r2["ok"] = [[float(a), str(b), int(c)] for a, b, c in r2["ok"]]
+                if len(r2["ok"]) == 5 and all(os.path.dirname(b) == "./retrieval/coco/train2017" for _, b, _ in r2["ok"]) and \
+                        [c for _, _, c in r2["ok"]] == [1, 2, 3, 4, 5] and name not in str(T["generic"]):
+                    r2 = {"random_fallback": True}            # unseeded pick: only its shape is comparable
+            g["fuzz"].append({"sample": name, "neudet": r1, "generic_top5": r2, "coco": call(ref.find_coco_sample, T["coco"], name, 1)})
         # the random fallback (missing sample, generic dataset): similarities and ranks are fixed, the pick is random
         r = call(ref.get_top5_similar_images_from_json, T["generic"], "no_such_sample", "ArTaxOr", 5)
         g["random_fallback"] = {"n": len(r["ok"]), "sims": [float(a) for a, _, _ in r["ok"]], "ranks": [int(c) for _, _, c in r["ok"]],

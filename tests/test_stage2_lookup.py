@@ -55,3 +55,24 @@ def test_random_fallback_is_seedable(tree):
     b = H.top5_similar_images(G["trees"]["generic"], "no_such_sample", "ArTaxOr", 5, COCO_DIR, random.Random(3))
     assert a == b and len(a) == exp["n"] and [s for s, _, _ in a] == exp["sims"] and [r for _, _, r in a] == exp["ranks"]
     assert all(os.path.dirname(p) == COCO_DIR for _, p, _ in a) == exp["all_in_coco_dir"]
+
+
+def test_fuzzed_sample_names(tree):
+    """160 sample names assembled from category-like tokens: NEU-DET category parsing / aliases / substring fallbacks, the
+    COCO variants and the generic variants, against what the reference returned for the same names"""
+    n_fallback = 0
+    for c in G["fuzz"]:
+        name = c["sample"]
+        assert _run(H.find_neudet_sample, G["trees"]["neu"], name, 5) == ({"ok": c["neudet"]["ok"]} if "ok" in c["neudet"] else {"raises": "ValueError"}), c
+        assert _run(H.find_coco_sample, G["trees"]["coco"], name, 1) == {"ok": c["coco"]["ok"]}, c
+        gt = c["generic_top5"]
+        if "skip" in gt:
+            continue
+        got = _run(H.top5_similar_images, G["trees"]["generic"], name, "ArTaxOr", 5, COCO_DIR, random.Random(1))
+        if "random_fallback" in gt:
+            n_fallback += 1
+            assert "ok" in got and [r for _, _, r in got["ok"]] == [1, 2, 3, 4, 5] and all(os.path.dirname(p) == COCO_DIR for _, p, _ in got["ok"]), c
+        elif "raises" in gt:
+            assert got == {"raises": "ValueError"}, c
+        else:
+            assert [[float(a), str(b), int(r)] for a, b, r in got["ok"]] == gt["ok"], (c, got)
