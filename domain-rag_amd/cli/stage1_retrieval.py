@@ -70,36 +70,80 @@ def list_corpus_images(root: str, subdirs) -> list[str]:
     return out
 
 
-def load_feature_file(feat_path, paths_path, device):
-    """ref :536-610: .pt dict {embeddings|features, image_paths|paths} or .npy + json list"""
+def load_feature_file(feat_path, paths_path):
+    """the "pretrained features" step of load_or_compute_coco_features (ref :547-606): features from a .pt (dict key
+    ``embeddings``, else ``features``, else the object itself) or a .npy; paths from the .pt (``image_paths``, else
+    ``paths``), overridden by the json list when one is given.  Returns (features | None, paths list)."""
+    feats, paths, data = None, [], None
     if feat_path.endswith(".pt"):
-        d = torch.load(feat_path, map_location="cpu", weights_only=False)
-        feats = d.get("embeddings", d.get("features"))
-        paths = d.get("image_paths", d.get("paths"))
-        if feats is None or paths is None:
-            return None, None
-        feats = feats.float().cpu().numpy() if torch.is_tensor(feats) else np.asarray(feats, dtype=np.float32)
-        return feats, [R.clean_image_path(p) for p in paths]
-    if feat_path.endswith(".npy") and paths_path and os.path.exists(paths_path):
+        data = torch.load(feat_path, map_location="cpu", weights_only=False)
+        if isinstance(data, dict):
+            feats = data["embeddings"] if "embeddings" in data else data["features"] if "features" in data else data
+        else:
+            feats = data
+    elif feat_path.endswith(".npy"):
+        feats = np.load(feat_path)
+    if isinstance(data, dict) and ("image_paths" in data or "paths" in data):
+        paths = [R.clean_image_path(p) for p in (data["image_paths"] if "image_paths" in data else data["paths"])]
+    if paths_path and os.path.exists(paths_path):
         with open(paths_path) as f:
-            return np.load(feat_path), [R.clean_image_path(p) for p in json.load(f)]
-    return None, None
+            paths = [R.clean_image_path(p) for p in json.load(f)]
+    if torch.is_tensor(feats):
+        feats = feats.float().cpu().numpy()
+    return feats, paths
+
+
+def resolve_feature_cache(pre_feats, pre_paths, cache_f, cache_p, force_recompute=False, global_candidates=()):
+    """cache resolution order of load_or_compute_coco_features (ref :500-622), without the recompute itself:
+    global pre-extracted file (if asked) -> the given pretrained file -> the local cache under the results dir.
+    Returns (features, paths) or None when the caller has to recompute.  Like the reference, a pretrained file that yields
+    features but no paths does NOT fall back to the local cache: it recomputes."""
+    if force_recompute:
+        return None
+    feats = paths = None
+    for g in global_candidates:                       # (:511-548) {embeddings|features, image_paths}
+        if os.path.exists(g):
+            try:
+                d = torch.load(g, map_location="cpu", weights_only=False)
+                if isinstance(d, dict) and "image_paths" in d and ("embeddings" in d or "features" in d):
+                    feats = d["embeddings"] if "embeddings" in d else d["features"]
+                    feats = feats.float().cpu().numpy() if torch.is_tensor(feats) else np.asarray(feats)
+                    paths = [R.clean_image_path(p) for p in d["image_paths"]]
+                    break
+            except Exception as e:
+                print(f"加载全局特征文件 {g} 时出错: {e}")
+    if feats is None and pre_feats is not None:
+        if os.path.exists(pre_feats):
+            try:
+                feats, paths = load_feature_file(pre_feats, pre_paths)
+            except Exception as e:
+                print(f"加载预提取特征时出错: {e}")
+                feats = None
+        else:
+            print(f"警告：指定的预提取特征文件不存在: {pre_feats}")
+    if feats is None and os.path.exists(cache_f) and os.path.exists(cache_p):
+        try:
+            feats = np.load(cache_f)
+            with open(cache_p) as fh:
+                paths = [R.clean_image_path(p) for p in json.load(fh)]
+        except Exception as e:
+            print(f"加载本地缓存特征时出错: {e}")
+            feats = None
+    if feats is None or paths is None or len(feats) == 0 or len(paths) == 0:
+        return None
+    return feats, paths
 
 
 def load_or_compute_features(args, tag, root, subdirs, pre_feats, pre_paths, model, preprocess, results_dir, rank0=True):
     """ref :500-655 cache resolution order, then compute + save ``<tag>_clip_features.npy`` / ``<tag>_image_paths.json``"""
     cache_f = os.path.join(results_dir, f"{tag}_clip_features.npy")
     cache_p = os.path.join(results_dir, f"{tag}_image_paths.json")
-    if not args.force_recompute:
-        if pre_feats and os.path.exists(pre_feats):
-            f, p = load_feature_file(pre_feats, pre_paths, model.device)
-            if f is not None:
-                print(f"成功加载 {len(f)} 个预提取特征: {pre_feats}")
-                return f, p
-        if os.path.exists(cache_f) and os.path.exists(cache_p):
-            with open(cache_p) as fh:
-                print(f"从缓存加载特征: {cache_f}")
-                return np.load(cache_f), [R.clean_image_path(p) for p in json.load(fh)]
+    glob_c = (os.path.join("..", f"{tag}_embeddings_global.pt"), os.path.join("..", "result_clip_vision", f"{tag}_embeddings_global.pt")) \
+        if getattr(args, "global_features", False) else ()
+    hit = resolve_feature_cache(pre_feats, pre_paths, cache_f, cache_p, args.force_recompute, glob_c)
+    if hit is not None:
+        print(f"成功加载 {len(hit[0])} 个预提取特征")
+        return np.asarray(hit[0], dtype=np.float32), hit[1]
     paths = list_corpus_images(root, ("images", "train2017", "val2017", "train"))
     if not paths:
         print(f"错误：找不到图像: {root}")
