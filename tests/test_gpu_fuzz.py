@@ -1,0 +1,111 @@
+"""Seeded random configurations through the kernels (shapes, strides, epilogue combinations the hand-picked cases do not
+enumerate), each checked against the same oracles / references as the dedicated tests."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def test_gemm_random_configs(gpu):
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    rng = np.random.default_rng(1234)
+    g = torch.Generator().manual_seed(99)
+    for case in range(40):
+        K = int(rng.choice([64, 128, 192, 320, 512, 1024]))
+        N = int(rng.choice([8, 64, 72, 136, 256, 264, 520, 768, 1032]))
+        batched = bool(rng.random() < 0.5)
+        B = int(rng.integers(1, 5)) if batched else 1
+        rows = int(rng.choice([1, 7, 50, 129, 255, 256, 300, 777, 1100]))      # rows per batch
+        if case >= 28:                                                          # the 256x256 persistent kernel
+            rows, B = int(rng.choice([1241, 2048, 2500, 4096, 5337])), (int(rng.integers(1, 4)) if batched else 1)
+            N = int(rng.choice([256, 264, 520, 768, 1032, 3072]))
+        pad_rows = int(rng.integers(0, 40)) if batched else 0                   # rows of the joint buffer this GEMM skips
+        M = B * rows
+        S = rows + pad_rows
+        act = int(rng.choice([0, 0, 1, 2, 3]))
+        use_bias = bool(rng.random() < 0.7)
+        mode = str(rng.choice(["plain", "resid", "gate"]))
+        a_full = torch.randn(B, S, K, generator=g).bfloat16()
+        w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+        bias = torch.randn(N, generator=g).bfloat16() if use_bias else None
+        x_full = torch.randn(B, S, N, generator=g).bfloat16()
+        gate = torch.randn(B, 3 * N, generator=g).bfloat16()
+        xd, ad, gd = x_full.to(gpu), a_full.to(gpu), gate.to(gpu)
+        kw = dict(M=M, a_rows_per_batch=rows, a_batch_stride=S * K, lda=K, c_rows_per_batch=rows, c_batch_stride=S * N, ldc=N)
+        if mode == "gate":
+            kw.update(gate=gd.view(-1)[N:], resid=xd.view(-1)[pad_rows * N:], ldg=3 * N)
+        elif mode == "resid":
+            kw.update(resid=xd.view(-1)[pad_rows * N:])
+        ops.gemm(ad.view(-1)[pad_rows * K:], w.to(gpu), out=xd.view(-1)[pad_rows * N:], bias=None if bias is None else bias.to(gpu), act=act, **kw)
+        got = xd.cpu()
+        a_rows = a_full[:, pad_rows:].reshape(-1, K)
+        res_rows = x_full[:, pad_rows:].reshape(-1, N)
+        ref = ops_ref.gemm_ref(a_rows, w, bias, act=act, gate=gate[:, N:2 * N] if mode == "gate" else None,
+                               resid=res_rows if mode in ("gate", "resid") else None, rows_per_batch=rows)
+        tag = (case, M, N, K, rows, pad_rows, act, use_bias, mode)
+        assert torch.equal(got[:, :pad_rows], x_full[:, :pad_rows]), ("rows outside the view were touched", tag)
+        assert _rel(got[:, pad_rows:].reshape(-1, N), ref) < 1.5e-2, tag
+
+
+def test_attention_random_lengths(gpu):
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    rng = np.random.default_rng(7)
+    g = torch.Generator().manual_seed(3)
+    for case in range(14):
+        B, H = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        S = int(rng.choice([1, 2, 33, 64, 65, 100, 191, 192, 257, 300, 511, 600, 1025, 4099]))
+        D = H * 128
+        qkv = (torch.randn(B, S, 3 * D, generator=g) * float(rng.choice([0.5, 1.0, 3.0]))).bfloat16()
+        qd = qkv.to(gpu)
+        vt = torch.empty(B, H, 128, (S + 63) // 64 * 64, device=gpu, dtype=torch.bfloat16)
+        ops.qk_norm_rope_vt(qd, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
+        o = torch.empty(B, S, D, device=gpu, dtype=torch.bfloat16)
+        ops.attention(qd, qd.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+        q, k, v = (qkv[..., i * D:(i + 1) * D].view(B, S, H, 128).transpose(1, 2).float() for i in range(3))
+        ref = ops_ref.attention_ref(q, k, v, 1 / math.sqrt(128))
+        assert _rel(o, ref) < 1.5e-2, (case, B, S, H)
+
+
+def test_resample_random_sizes(gpu):
+    from PIL import Image
+    from domain_rag_amd import resample
+    rng = np.random.default_rng(21)
+    flt = {"bilinear": Image.BILINEAR, "bicubic": Image.BICUBIC, "lanczos": Image.LANCZOS}
+    for case in range(40):
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        ow, oh = int(rng.integers(1, 500)), int(rng.integers(1, 400))
+        c = int(rng.choice([1, 3, 3, 3, 4]))
+        name = str(rng.choice(list(flt)))
+        img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        pil = Image.fromarray(img[:, :, 0], "L") if c == 1 else Image.fromarray(img, "RGB" if c == 3 else "RGBA")
+        ref = np.asarray(pil.resize((ow, oh), flt[name]))
+        if c == 4:
+            continue      # PIL premultiplies alpha for RGBA: not a plain 4-channel resample (documented: RGB / L only)
+        got = resample.resize_u8(torch.from_numpy(img).to(gpu), ow, oh, name).cpu().numpy()
+        assert np.array_equal(got.reshape(ref.shape), ref), (case, w, h, ow, oh, c, name)
+
+
+def test_topk_random(gpu):
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(5)
+    for case in range(12):
+        N, d, Q = int(rng.integers(1, 5000)), int(rng.choice([64, 128, 512, 1024])), int(rng.integers(1, 40))
+        k = int(rng.choice([1, 5, 100, 128]))
+        corpus = rng.standard_normal((N, d)).astype(np.float32)
+        if rng.random() < 0.5:                      # duplicates -> ties
+            corpus[rng.integers(0, N, N // 3 + 1)] = corpus[rng.integers(0, N, N // 3 + 1)]
+        queries = rng.standard_normal((Q, d)).astype(np.float32)
+        D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(queries).to(gpu), k)
+        Do, Io = oret.cosine_topk(corpus, queries, k)
+        assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy(), Do), (case, N, d, Q, k)
