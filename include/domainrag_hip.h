@@ -165,7 +165,7 @@ int64_t drag_resnet_stem_style_workspace_bytes(int32_t B, int32_t H, int32_t W);
 int drag_resnet_stem_style_f32(const float* img, const float* conv_w, const float* bn_scale, const float* bn_shift,
                                float* out, int32_t B, int32_t H, int32_t W, float eps, void* workspace, void* stream);
 /* Pillow-exact 8-bit separable resample of interleaved HWC uint8 images (bit-identical to PIL.Image.resize for
- * BILINEAR / BICUBIC / LANCZOS).  Replaces the PIL resize inside openai-CLIP's `preprocess` (Resize(224, BICUBIC) +
+ * BILINEAR / BICUBIC / LANCZOS on modes L, RGB and RGBX; PIL premultiplies alpha for RGBA, which this does not).  Replaces the PIL resize inside openai-CLIP's `preprocess` (Resize(224, BICUBIC) +
  * CenterCrop; retrieval/clip100_resnet_style_all_shots.py:209,171,270-287) and SiglipImageProcessor's 384x384 BICUBIC
  * inside FluxPriorReduxPipeline (batch_generate_flux_kshot.py:459-465, outpainting_updown_sampling_redux.py:1237-1243).
  * The caller supplies Pillow's fixed-point tables (device int32): per output index `bounds` = (first source index,
