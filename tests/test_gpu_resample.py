@@ -74,3 +74,27 @@ def test_embedding_independent_of_where_the_resize_ran(gpu):
     host = model.encode_image(torch.stack([preprocess(im) for im in pil]))
     dev = model.encode_image(torch.stack([R.clip_preprocess_device(im, gpu) for im in pil]))
     assert torch.equal(host, dev)
+
+
+def test_resample_argument_errors(gpu):
+    """the C entry point refuses inconsistent descriptors instead of reading out of bounds"""
+    import ctypes
+    from domain_rag_amd import _lib
+    lib = _lib.load()
+    src = torch.zeros((1, 8, 8, 3), dtype=torch.uint8, device=gpu)
+    dst = torch.zeros((1, 4, 4, 3), dtype=torch.uint8, device=gpu)
+    tab = torch.zeros((4, 2), dtype=torch.int32, device=gpu)
+
+    def call(**kw):
+        a = _lib.ResampleArgs()
+        a.src, a.dst, a.batch, a.channels = src.data_ptr(), dst.data_ptr(), 1, 3
+        a.src_h, a.src_w, a.src_image_stride, a.src_row_stride = 8, 8, 192, 24
+        a.out_h, a.out_w, a.dst_image_stride, a.dst_row_stride = 4, 4, 48, 12
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return lib.drag_resample_u8(ctypes.byref(a), torch.cuda.current_stream().cuda_stream)
+    assert call(channels=5) != 0 and b"channels" in lib.drag_last_error()
+    assert call(kx=tab.data_ptr()) != 0                                   # weights without bounds
+    assert call(kx=tab.data_ptr(), bx=tab.data_ptr(), ksize_x=1, ky=tab.data_ptr(), by=tab.data_ptr(), ksize_y=1) != 0   # both passes, no tmp
+    assert call(src_col0=6) != 0 and b"window" in lib.drag_last_error()   # copy window 6..9 leaves the 8-wide source
+    assert call() == 0                                                    # plain 4x4 window copy is fine
