@@ -72,6 +72,40 @@ def clip_preprocess_device(pil_image, device="cuda", size: int = 224) -> torch.T
     return resample.clip_preprocess_u8(raw, size)
 
 
+def cv2_resize_linear_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """``cv2.resize(img, (out_w, out_h))`` (INTER_LINEAR) for uint8 HWC, restated from OpenCV's published algorithm
+    (imgproc/resize.cpp): half-pixel centres, two taps per axis, 11-bit fixed-point weights; horizontal pass into int32, vertical
+    pass ``((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2``.  PARITY UNPINNED: cv2 is not importable in the build container (and
+    opencv-python may route this call through IPP); what matters for the style statistics is that, like cv2 and unlike PIL's
+    BILINEAR, it does not low-pass when shrinking."""
+    h, w = img.shape[:2]
+    if (w, h) == (out_w, out_h):
+        return img.copy()
+
+    def axis(n_in, n_out):
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        return s, f
+
+    sx, fx = axis(w, out_w)
+    lo = sx < 0
+    fx[lo], sx[lo] = 0.0, 0
+    hi = sx >= w - 1
+    fx[hi], sx[hi] = 0.0, w - 1
+    a1 = np.rint(fx * 2048.0).astype(np.int64)
+    a0 = np.rint((1.0 - fx) * 2048.0).astype(np.int64)
+    sx1 = np.minimum(sx + 1, w - 1)
+    src = img.astype(np.int64)
+    rows = src[:, sx] * a0[None, :, None] + src[:, sx1] * a1[None, :, None]            # [h, out_w, c] int
+    sy, fy = axis(h, out_h)
+    b1 = np.rint(fy * 2048.0).astype(np.int64)
+    b0 = np.rint((1.0 - fy) * 2048.0).astype(np.int64)
+    y0, y1 = np.clip(sy, 0, h - 1), np.clip(sy + 1, 0, h - 1)
+    out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 # ------------------------------------------------------------------ CLIP
 class ClipImageModel:
     """``model`` half of ``clip.load``; only the image tower is on Domain-RAG's path."""
@@ -186,9 +220,9 @@ class StemStyle:
                     print(f"警告：无法读取图像 {image_path}")
                     return None
                 img = cv2.resize(cv2.cvtColor(img, cv2.COLOR_BGR2RGB), (256, 256))
-            except ImportError:   # no OpenCV in this image: PIL bilinear (resize kernels differ slightly from cv2)
-                from PIL import Image
-                img = np.asarray(Image.open(image_path).convert("RGB").resize((256, 256), Image.BILINEAR))
+            except ImportError:   # no OpenCV: same decode via PIL, and OpenCV's INTER_LINEAR restated (2 taps, NO antialiasing —
+                from PIL import Image   # PIL's BILINEAR widens its support when shrinking, which changes texture statistics)
+                img = cv2_resize_linear_u8(np.asarray(Image.open(image_path).convert("RGB")), 256, 256)
             x = torch.from_numpy(np.array(img, copy=True)).float().permute(2, 0, 1).unsqueeze(0) / 255.0
             return self(x)[0].cpu().numpy()
         except Exception as e:  # reference behaviour: log and skip

@@ -150,3 +150,28 @@ def test_randomised_sweeps_match_reference():
             continue
         m = H.outpaint_mask_array(c["W"], c["H"], c["bboxes"])
         assert int((m == 255).sum()) == c["white"] and hashlib.sha256(m.tobytes()).hexdigest() == c["sha256"], c
+
+
+def test_cv2_style_linear_resize_properties():
+    """the OpenCV INTER_LINEAR restatement used for the stem input (cv2 itself is not importable: unpinned): identity at equal
+    size, within 1 LSB of exact two-tap half-pixel bilinear interpolation, constant images stay constant, and — unlike
+    PIL's BILINEAR — no low-pass when shrinking (white noise keeps about twice the contrast)"""
+    from PIL import Image
+    from domain_rag_amd.retrieval import cv2_resize_linear_u8
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (60, 90, 3), dtype=np.uint8)
+    assert np.array_equal(cv2_resize_linear_u8(img, 90, 60), img)
+    assert np.all(cv2_resize_linear_u8(np.full((33, 47, 3), 201, np.uint8), 256, 256) == 201)
+    for (ow, oh) in [(256, 256), (45, 30), (200, 17), (90, 200)]:
+        h, w = img.shape[:2]
+        fx = (np.arange(ow) + 0.5) * w / ow - 0.5; fy = (np.arange(oh) + 0.5) * h / oh - 0.5
+        x0 = np.floor(fx).astype(int); ax = fx - x0; ax[(x0 < 0) | (x0 >= w - 1)] = 0; x0 = np.clip(x0, 0, w - 1); x1 = np.clip(x0 + 1, 0, w - 1)
+        y0f = np.floor(fy).astype(int); ay = fy - y0f; y0 = np.clip(y0f, 0, h - 1); y1 = np.clip(y0f + 1, 0, h - 1)
+        f = img.astype(np.float64)
+        r = f[:, x0] * (1 - ax)[None, :, None] + f[:, x1] * ax[None, :, None]
+        ref = r[y0] * (1 - ay)[:, None, None] + r[y1] * ay[:, None, None]
+        assert np.abs(cv2_resize_linear_u8(img, ow, oh).astype(np.float64) - ref).max() <= 1.0
+    noise = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)            # white noise: a 2-tap resize keeps ~2x PIL's contrast
+    ours = cv2_resize_linear_u8(noise, 256, 256)
+    pil = np.asarray(Image.fromarray(noise).resize((256, 256), Image.BILINEAR))
+    assert ours.std() > 40 and pil.std() < 30
