@@ -125,8 +125,8 @@ def resize_u8(img: torch.Tensor, out_w: int, out_h: int, filt: str = "bicubic", 
 
 def clip_resize_plan(w: int, h: int, size: int = 224):
     """(resized w, resized h, crop box) of torchvision Resize(size) + CenterCrop(size) as openai-CLIP composes them"""
-    s = size / min(w, h)
-    nw, nh = (size, max(size, int(round(h * s)))) if w <= h else (max(size, int(round(w * s))), size)
+    # torchvision Resize(int): the short side becomes `size`, the long one int(size * long / short) — TRUNCATED, not rounded
+    nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
     left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
     return nw, nh, (left, top, left + size, top + size)
 

@@ -52,8 +52,8 @@ def clip_preprocess(pil_image, size: int = 224) -> torch.Tensor:
     from PIL import Image
     img = pil_image.convert("RGB")
     w, h = img.size
-    s = size / min(w, h)
-    nw, nh = (size, max(size, int(round(h * s)))) if w <= h else (max(size, int(round(w * s))), size)
+    # torchvision Resize(int): the short side becomes `size`, the long one int(size * long / short) — TRUNCATED, not rounded
+    nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
     img = img.resize((nw, nh), Image.BICUBIC)
     left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
     img = img.crop((left, top, left + size, top + size))

@@ -20,7 +20,9 @@ def test_tables_equal_oracle(filt):
 
 def test_clip_resize_plan_matches_torchvision_rule():
     # torchvision Resize(int): shorter side -> size, longer = int(size * long / short) ... openai-CLIP then center-crops
-    assert resample.clip_resize_plan(640, 480) == (299, 224, (38, 0, 262, 224))
-    assert resample.clip_resize_plan(480, 640) == (224, 299, (0, 38, 224, 262))
+    # torchvision _compute_resized_output_size: new_long = int(size * long / short); CenterCrop offsets = int(round(d / 2.0))
+    assert resample.clip_resize_plan(640, 480) == (298, 224, (37, 0, 261, 224))          # int(298.67) = 298
+    assert resample.clip_resize_plan(480, 640) == (224, 298, (0, 37, 224, 261))
     assert resample.clip_resize_plan(224, 224) == (224, 224, (0, 0, 224, 224))
-    assert resample.clip_resize_plan(500, 375)[:2] == (299, 224)
+    assert resample.clip_resize_plan(500, 375)[:2] == (298, 224)                         # int(298.67)
+    assert resample.clip_resize_plan(640, 427) == (335, 224, (56, 0, 280, 224))          # int(335.74) = 335; round(55.5) = 56
