@@ -19,13 +19,14 @@ def flow_sigmas(num_inference_steps: int, image_seq_len: int, dynamic_shift: boo
     """sigmas (float32 [n+1], last = 0) and timesteps (= sigma*1000, float32 [n]).
     FLUX.1-dev / Fill-dev scheduler config: use_dynamic_shifting=True ->
     sigma' = e^mu / (e^mu + (1/sigma - 1)); FLUX.1-schnell: static shift=1.0 (identity)."""
-    sig = np.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps)
+    # set_timesteps casts the pipeline's float64 linspace to float32 FIRST and shifts in float32 (numpy keeps float32
+    # against python-float scalars), so the shifted sigmas are float32-evaluated, not float64 values rounded afterwards
+    sig = np.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps).astype(np.float32)
     if dynamic_shift:
         mu = calculate_shift(image_seq_len)
-        sig = math.exp(mu) / (math.exp(mu) + (1.0 / sig - 1.0))
+        sig = (math.exp(mu) / (math.exp(mu) + (1 / sig - 1) ** 1.0)).astype(np.float32)
     else:
-        sig = shift * sig / (1 + (shift - 1) * sig)
-    sig = sig.astype(np.float32)
+        sig = (shift * sig / (1 + (shift - 1) * sig)).astype(np.float32)
     ts = (sig * np.float32(1000.0)).astype(np.float32)
     return np.concatenate([sig, np.zeros(1, np.float32)]), ts
 

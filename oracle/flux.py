@@ -220,10 +220,11 @@ def flow_sigmas(num_steps: int, seq_len: int):
     use_dynamic_shifting (FLUX.1-dev scheduler config): sigma' = e^mu / (e^mu + (1/sigma - 1)); then 0 appended.
     Returns (sigmas fp32 [n+1], timesteps = sigma' * 1000 fp32 [n])."""
     import numpy as np
-    sig = np.linspace(1.0, 1.0 / num_steps, num_steps)
+    sig = np.linspace(1.0, 1.0 / num_steps, num_steps).astype(np.float32)      # the scheduler casts to float32 before shifting
     mu = calculate_shift(seq_len)
-    sig = math.exp(mu) / (math.exp(mu) + (1.0 / sig - 1.0))
-    sig = torch.from_numpy(sig).to(torch.float32)
+    sig = math.exp(mu) / (math.exp(mu) + (1 / sig - 1) ** 1.0)                  # float32 array against python floats: stays float32
+    assert sig.dtype == np.float32
+    sig = torch.from_numpy(sig)
     ts = sig * 1000.0
     return torch.cat([sig, torch.zeros(1)]), ts
 
