@@ -19,7 +19,7 @@ from . import ops, redux as redux_mod, vae as vae_mod, vit as vit_mod
 from .fill_pipeline import FluxFillHIP
 from .flux import FluxTransformerHIP, latent_image_ids
 from .flux_params import FluxConfig, init_params, load_safetensors_dir
-from .scheduler import flow_sigmas
+from .scheduler import flow_sigmas, model_timestep
 
 TINY = dict(flux=dict(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=256, pooled_projection_dim=64),
             vae=dict(layers_per_block=1), vit=dict(image_size=56, patch_size=14, hidden=192, heads=2, layers=1, intermediate=304),
@@ -142,7 +142,7 @@ class FluxTxt2ImgHIP:
         img_ids, txt_ids = latent_image_ids(h, w), torch.zeros(prompt_embeds.shape[1], 3)
         guidance = torch.full((B,), float(guidance_scale)) if self.tr.cfg.guidance_embeds else None
         for i in range(num_inference_steps):
-            t = torch.full((B,), float(timesteps[i]) / 1000.0)
+            t = torch.full((B,), model_timestep(timesteps[i]))
             fwd = self.tr.forward_graphed if self.use_graph else self.tr.forward
             v = fwd(lat, prompt_embeds, pooled, t, img_ids, txt_ids, guidance)
             ops.flow_euler_rows(lat, v, B * h * w, 64, 64, 64, float(sigmas[i + 1] - sigmas[i]))

@@ -19,7 +19,7 @@ import torch
 from . import ops, vae as vae_mod, vit as vit_mod, redux as redux_mod
 from .flux import FluxTransformerHIP, latent_image_ids
 from .flux_params import FluxConfig, init_params
-from .scheduler import flow_sigmas, strength_start
+from .scheduler import flow_sigmas, model_timestep, strength_start
 
 
 class FluxFillHIP:
@@ -69,7 +69,7 @@ class FluxFillHIP:
             ops.scale_noise_rows(hv, noise_tokens, B * Si, 64, C, 64, float(sigmas[t0]))
             guidance = torch.full((B,), float(guidance_scale))
             for i in range(t0, num_inference_steps):
-                t = torch.full((B,), float(timesteps[i]) / 1000.0)
+                t = torch.full((B,), model_timestep(timesteps[i]))
                 fwd = self.tr.forward_graphed if (self.use_graph and recorder is None) else self.tr.forward
                 v = fwd(hidden, prompt_embeds, pooled, t, self._img_ids, self._txt_ids, guidance)
                 ops.flow_euler_rows(hv, v, B * Si, 64, C, 64, float(sigmas[i + 1] - sigmas[i]))

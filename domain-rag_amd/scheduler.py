@@ -35,3 +35,12 @@ def strength_start(num_inference_steps: int, strength: float) -> int:
     """FluxFillPipeline.get_timesteps: index of the first step that is actually run."""
     init_timestep = min(num_inference_steps * strength, num_inference_steps)
     return int(max(num_inference_steps - init_timestep, 0))
+
+
+def model_timestep(t: float) -> float:
+    """what the pipelines hand to the transformer: ``timestep = t.expand(B).to(latents.dtype)`` (bf16) and then
+    ``timestep / 1000`` — a bf16 tensor divided by a scalar, so the quotient is rounded to bf16 again.  (The transformer
+    multiplies by 1000 in bf16 once more.)  Rounding t itself first matters: bf16(t / 1000) differs from
+    bf16(bf16(t) / 1000) for about a quarter of the timesteps of a 30 / 50-step schedule."""
+    import torch
+    return float(torch.tensor(float(t), dtype=torch.float32).to(torch.bfloat16) / 1000)

@@ -32,7 +32,7 @@ def fill_pipeline(tp, tcfg, vp, vae_kw, image_u8, mask_u8, prompt_embeds, pooled
     img_ids, txt_ids = oflux.latent_image_ids(h, w), torch.zeros(prompt_embeds.shape[1], 3)
     guidance = torch.full((B,), float(guidance_scale))
     for i in range(t0, num_inference_steps):
-        t = timesteps[i].expand(B) / 1000.0
+        t = (timesteps[i].expand(B).to(torch.bfloat16) / 1000).float()      # pipeline: t.to(latents.dtype), then / 1000 in bf16
         v = oflux.flux_forward(tp, tcfg, torch.cat([lat, cond], dim=2), cast(prompt_embeds), cast(pooled), t, img_ids, txt_ids,
                                guidance, time_dtype=torch.bfloat16)
         lat = oflux.euler_step(lat, v, sigmas[i], sigmas[i + 1])
@@ -52,7 +52,7 @@ def txt2img_pipeline(tp, tcfg, vp, vae_kw, prompt_embeds, pooled, guidance_scale
     img_ids, txt_ids = oflux.latent_image_ids(h, w), torch.zeros(prompt_embeds.shape[1], 3)
     guidance = torch.full((B,), float(guidance_scale)) if tcfg.guidance_embeds else None
     for i in range(num_inference_steps):
-        t = timesteps[i].expand(B) / 1000.0
+        t = (timesteps[i].expand(B).to(torch.bfloat16) / 1000).float()      # pipeline: t.to(latents.dtype), then / 1000 in bf16
         v = oflux.flux_forward(tp, tcfg, lat, prompt_embeds.to(dtype), pooled.to(dtype), t, img_ids, txt_ids, guidance,
                                time_dtype=torch.bfloat16)
         lat = oflux.euler_step(lat, v, sigmas[i], sigmas[i + 1])

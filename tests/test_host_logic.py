@@ -175,3 +175,21 @@ def test_cv2_style_linear_resize_properties():
     ours = cv2_resize_linear_u8(noise, 256, 256)
     pil = np.asarray(Image.fromarray(noise).resize((256, 256), Image.BILINEAR))
     assert ours.std() > 40 and pil.std() < 30
+
+
+def test_timestep_rounding_chain():
+    """the value the DiT finally embeds is bf16(bf16(bf16(t) / 1000) * 1000) — t is cast to the latents' dtype BEFORE the
+    pipeline divides by 1000, and the transformer multiplies back in bf16.  ``scheduler.model_timestep`` + the
+    transformer's own ``to(bf16) * 1000`` must reproduce that chain for every timestep of the schedules in use."""
+    import torch
+    from domain_rag_amd.scheduler import flow_sigmas, model_timestep
+    n_diff = 0
+    for n in (4, 20, 30, 50):
+        for seq in (1024, 4096, 5440, 16384):
+            for t in flow_sigmas(n, seq)[1]:
+                t32 = torch.tensor(float(t), dtype=torch.float32)
+                ref = (t32.to(torch.bfloat16) / 1000).to(torch.bfloat16) * 1000            # pipeline, then transformer
+                ours = torch.tensor(model_timestep(float(t))).to(torch.bfloat16) * 1000   # what FluxTransformerHIP._set_times does
+                assert float(ref) == float(ours)
+                n_diff += float(ref) != float((t32 / 1000).to(torch.bfloat16) * 1000)     # the naive chain is NOT the same
+    assert n_diff > 50
