@@ -106,18 +106,39 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
         info, bboxes, cats = found
         img_path = os.path.join(args.datasets_dir, dataset, "train", info["file_name"])
         original = Image.open(img_path).convert("RGB")
-        log.update(image_id=info["id"], categories=cats, category=cats[0] if cats else "unknown",
-                   original_image_size=list(original.size), bbox_coords_list=bboxes,
-                   bbox_image_sizes=[[c[2] - c[0], c[3] - c[1]] for c in (H.crop_box(b, *original.size) for b in bboxes)])
+        crops = [H.crop_box(b, *original.size) for b in bboxes]
+        log.update(image_id=info["id"] if info.get("id") else "unknown", categories=cats, category=cats[0] if cats else "unknown",
+                   original_resolution=list(original.size), original_image_size=list(original.size), bbox_coords_list=bboxes,
+                   bbox_image_sizes=[[c[2] - c[0], c[3] - c[1]] for c in crops])
         out_dir = os.path.join(f"./outpaint_hires/process_{process_id}", dataset, f"{shot}_shot", sample_id)
         os.makedirs(out_dir, exist_ok=True)
         orig_saved = os.path.join(out_dir, f"{prefix}_original.png")
         original.save(orig_saved)
+        bbox_saved = []                                   # every bbox crop next to the results (:1116-1131)
+        for i, c in enumerate(crops):
+            bp = os.path.join(out_dir, f"{prefix}_bbox{i + 1}_original.jpg")
+            try:
+                original.crop(c).save(bp)
+                bbox_saved.append(bp)
+            except Exception as e:
+                print(f"保存bbox图像{i + 1}失败: {str(e)}")
+                bbox_saved.append(None)
+        log["bbox_saved_paths"] = bbox_saved
         bgs = sorted(glob.glob(os.path.join(sample_dir, "generated_image*png")))
         if not bgs:
             raise RuntimeError(f"在 {sample_dir} 中找不到生成的背景图像")
         min_dim = 64 if args.tiny else H.UPSCALE_DIMENSION.get(dataset, args.min_dimension)
-        processed, up, down, wu, wd = H.process_image_resolution(original, min_dim, H.MAX_DIMENSION)
+        try:
+            processed, up, down, wu, wd = H.process_image_resolution(original, min_dim, H.MAX_DIMENSION)
+        except ValueError as e:
+            raise ValueError(f"样本 {sample_id} 处理失败: {str(e)}")
+        log.update(upscaled_resolution=list(processed.size), up_scale_factor=up, down_scale_factor=down, was_upscaled=wu,
+                   was_downscaled=wd, min_dimension_used=min_dim)
+        if wd:
+            processed.save(os.path.join(out_dir, f"{prefix}_downscaled_bg.png"))
+            log["downscaled_resolution"] = list(processed.size)
+        if wu:
+            processed.save(os.path.join(out_dir, f"{prefix}_upscaled_bg.png"))
         pb = H.scale_bboxes(bboxes, up, down, wu, wd)
         mask_img, _ = H.generate_outpaint_mask(processed, pb)
         strength = H.STRENGTH.get(dataset, H.DEFAULT_STRENGTH)

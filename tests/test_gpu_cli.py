@@ -78,11 +78,15 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
         prm = json.load(open(sd / f"{pre}_params_{r}.json"))
         assert prm["strength"] == 0.9 and prm["guidance_scale"] == 30.0 and prm["was_upscaled"] and prm["num_bbox"] == 1
         assert prm["processed_bbox_coords_list"] == [[int(c * prm["up_scale_factor"]) for c in [10, 8, 20, 16]]]
+        assert (sd / f"{pre}_bg_{r}_original.png").exists()
         m = np.asarray(Image.open(sd / f"{pre}_mask_{r}.png"))
         assert m.shape == (64, 96) and set(np.unique(m)) == {0, 255}
+    assert Image.open(sd / f"{pre}_bbox1_original.jpg").size == (20, 16) and Image.open(sd / f"{pre}_upscaled_bg.png").size == (96, 64)
+    assert (sd / f"{pre}_original.png").exists() and not (sd / f"{pre}_downscaled_bg.png").exists()
     res = json.load(open(root / "outpaint_hires" / "process_7" / ds / "1_shot" / "outpaint_results_1shot.json"))
     assert res["dataset"] == ds and res["shot_number"] == 1 and len(res["samples"]) == 2
     assert len(res["samples"][0]["outpainted_images"]) == 5 and res["samples"][0]["categories"] == ["Coleoptera"]
+    assert res["samples"][0]["bbox_saved_paths"][0].endswith(f"{pre}_bbox1_original.jpg") and res["samples"][0]["bbox_image_sizes"] == [[20, 16]]
     fin = root / "final_results" / "process_7" / "1_shot" / ds / "1_shot"
     assert len(list(fin.glob("*_final_result*.png"))) == 10
     # the backgrounds of a sample are composited as one batch; one at a time (like the reference) must give the same pixels
