@@ -60,7 +60,7 @@ def generate_ranked(engine: Engine, target_path, items, sdir, args, database):
     from PIL import Image
     ok = bad = 0
     try:
-        tgt_img = Image.open(target_path).convert("RGB")
+        tgt_img = H.load_image_rgb(target_path)
     except Exception as e:   # reference convention: log, continue
         print(f"生成图像时出错: {str(e)}")
         return 0, len(items)
@@ -69,7 +69,7 @@ def generate_ranked(engine: Engine, target_path, items, sdir, args, database):
     ready = []
     for sim, ref_path, rank in items:
         try:
-            ref_img = Image.open(ref_path).convert("RGB")
+            ref_img = H.load_image_rgb(ref_path)
             ready.append((sim, ref_path, rank, engine.prior_embeds([ref_img, tgt_img], PROMPT, [COCO_IMAGE_SCALE, TARGET_IMAGE_SCALE],
                                                                    [COCO_TEXT_SCALE, TARGET_TEXT_SCALE])))
         except Exception as e:

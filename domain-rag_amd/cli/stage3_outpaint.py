@@ -105,7 +105,7 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
             raise RuntimeError(f"找不到与样本ID {sample_id} 匹配的图像/注释")
         info, bboxes, cats = found
         img_path = os.path.join(args.datasets_dir, dataset, "train", info["file_name"])
-        original = Image.open(img_path).convert("RGB")
+        original = H.load_image_rgb(img_path)
         crops = [H.crop_box(b, *original.size) for b in bboxes]
         log.update(image_id=info["id"] if info.get("id") else "unknown", categories=cats, category=cats[0] if cats else "unknown",
                    original_resolution=list(original.size), original_image_size=list(original.size), bbox_coords_list=bboxes,
@@ -161,7 +161,7 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
             mask_path = os.path.join(out_dir, f"{prefix}_mask{suffix}.png")
             mask_img.save(mask_path)
             try:
-                bg = Image.open(bg_path).convert("RGB")
+                bg = H.load_image_rgb(bg_path)
             except Exception as e:
                 print(f"加载背景图像 {bg_path} 失败: {str(e)}")
                 continue

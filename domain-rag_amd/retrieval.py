@@ -222,7 +222,8 @@ class StemStyle:
                 img = cv2.resize(cv2.cvtColor(img, cv2.COLOR_BGR2RGB), (256, 256))
             except ImportError:   # no OpenCV: same decode via PIL, and OpenCV's INTER_LINEAR restated (2 taps, NO antialiasing —
                 from PIL import Image   # PIL's BILINEAR widens its support when shrinking, which changes texture statistics)
-                img = cv2_resize_linear_u8(np.asarray(Image.open(image_path).convert("RGB")), 256, 256)
+                from PIL import ImageOps                      # cv2.imread applies the EXIF orientation
+                img = cv2_resize_linear_u8(np.asarray(ImageOps.exif_transpose(Image.open(image_path)).convert("RGB")), 256, 256)
             x = torch.from_numpy(np.array(img, copy=True)).float().permute(2, 0, 1).unsqueeze(0) / 255.0
             return self(x)[0].cpu().numpy()
         except Exception as e:  # reference behaviour: log and skip

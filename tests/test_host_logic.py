@@ -193,3 +193,17 @@ def test_timestep_rounding_chain():
                 assert float(ref) == float(ours)
                 n_diff += float(ref) != float((t32 / 1000).to(torch.bfloat16) * 1000)     # the naive chain is NOT the same
     assert n_diff > 50
+
+
+def test_load_image_applies_exif_orientation(tmp_path):
+    """stages 2 / 3 open images with diffusers' load_image, which transposes by the EXIF orientation tag"""
+    from PIL import Image
+    from domain_rag_amd import hostlogic as H
+    arr = np.zeros((20, 30, 3), np.uint8); arr[:5] = 255            # bright top edge, 30 wide x 20 high
+    im = Image.fromarray(arr)
+    ex = im.getexif(); ex[0x0112] = 6                               # "rotate 90 CW to display"
+    im.save(tmp_path / "r.jpg", exif=ex, quality=95)
+    plain = np.asarray(Image.open(tmp_path / "r.jpg").convert("RGB"))
+    fixed = np.asarray(H.load_image_rgb(str(tmp_path / "r.jpg")))
+    assert plain.shape == (20, 30, 3) and fixed.shape == (30, 20, 3)
+    assert fixed[:, -5:].mean() > 200 and fixed[:, :10].mean() < 50      # the bright edge is now on the right
