@@ -142,21 +142,44 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
                     f"推理步数: {args.num_inference_steps}\n处理样本数: {len(names)}\n")
     rng = random.Random(args.fallback_seed)
     s, e = shard_bounds(len(names), world, rank)
-    ok = bad = 0
+    ok = bad = images = 0            # samples that produced at least one image / samples that produced none / images written
+    stamp = lambda: datetime.now().strftime("%Y-%m-%d %H:%M:%S")
     for name in names[s:e]:
         target = os.path.join(shot_dir, name + ".jpg")
         sdir = os.path.join(base, name)
         os.makedirs(sdir, exist_ok=True)
         try:
             top = H.top5_similar_images(results, name, dataset, shot, args.coco_dir, rng)
-        except ValueError as ex:
+            if not top:                                  # (:946-956)
+                print(f"跳过样本 {name}，因为找不到相似图像")
+                with open(os.path.join(sdir, "error.txt"), "w") as f:
+                    f.write(f"处理样本 {name} 时出错: 找不到相似图像\n时间: {stamp()}\n")
+                bad += 1
+                continue
+        except ValueError as ex:                         # NEU-DET / COCO finders have no random fallback (:957-973)
+            print(f"处理样本 {name} 时出错: {str(ex)}")
             with open(os.path.join(sdir, "error.txt"), "w") as f:
-                f.write(str(ex))
+                f.write(f"处理样本 {name} 时出错: {str(ex)}\n时间: {stamp()}\n")
             bad += 1
             continue
-        n_ok, n_bad = generate_ranked(engine, target, top, sdir, args, args.database)   # paths are already fixed up and checked
-        ok += n_ok
-        bad += n_bad
+        top = [t for t in top if t[2] <= 5]
+        n_ok, _ = generate_ranked(engine, target, top, sdir, args, args.database)   # paths are already fixed up and checked
+        images += n_ok
+        if n_ok:
+            ok += 1
+        else:                                            # (:1033-1044)
+            bad += 1
+            with open(os.path.join(sdir, "generation_failed.txt"), "w") as f:
+                f.write(f"生成样本 {name} 的图像失败\n时间: {stamp()}\n")
+                if top:
+                    f.write(f"找到了 {len(top)} 个相似图像，但生成全部失败\n")
+                    for sim, path, r in top:
+                        f.write(f"  - Rank {r}: {path} (相似度: {sim:.4f})\n")
+    # the closing summary (:1046-1056); the size statistics read ref_info{rank}.txt, which is never written under that name
+    # (the file is ref_inforank{r}_sim….txt), so the list stays empty in the reference too
+    with open(os.path.join(base, "batch_params.txt" if world == 1 else f"batch_params_rank{rank}.txt"), "a") as f:
+        f.write(f"成功处理样本数: {ok}\n失败处理样本数: {bad}\n总共生成图像数: {images}\n\n生成图像尺寸统计:\n\n完成时间: {stamp()}\n")
+    print(f"数据集 {dataset} {shot}-shot处理完成：成功 {ok} 个样本，失败 {bad} 个样本，总共生成 {images} 张图像")
     return ok, bad
 
 
@@ -183,8 +206,7 @@ def main(argv=None):
             ok, bad = process_dataset(engine, results, ds, shot, args, rank, world)
             tot_ok += ok
             tot_bad += bad
-            print(f"数据集 {ds} {shot}-shot: 成功 {ok}, 失败 {bad}")
-    print(f"处理完成: 成功生成 {tot_ok} 张图像, 失败 {tot_bad}")
+    print(f"处理完成: 成功 {tot_ok} 个样本, 失败 {tot_bad} 个样本")
     return 0
 
 

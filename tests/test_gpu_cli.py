@@ -64,6 +64,9 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
         assert im.size == (64, 64)
         assert (base / "beetle_01" / f"ref_inputrank{r}.jpg").exists()
     assert (base / "beetle_01" / "target_input.png").exists() and (base / "beetle_01" / "params.txt").exists() and (base / "batch_params.txt").exists()
+    bp = open(base / "batch_params.txt", encoding="utf-8").read()
+    assert "处理样本数: 2" in bp and "成功处理样本数: 2" in bp and "失败处理样本数: 0" in bp and "总共生成图像数: 10" in bp
+    assert not (base / "beetle_01" / "error.txt").exists() and not (base / "beetle_01" / "generation_failed.txt").exists()
 
     # ---- stage 3
     out = _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "7", "--dataset", ds, "--shot", "1", "--synthetic-weights", "--tiny",
