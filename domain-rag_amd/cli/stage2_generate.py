@@ -139,7 +139,8 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
         with open(os.path.join(base, "batch_params.txt"), "w") as f:
             f.write(f"数据集: {dataset} ({shot}-shot，使用检索结果)\nCOCO图像权重: {COCO_IMAGE_SCALE}\n目标图像权重: {TARGET_IMAGE_SCALE}\n"
                     f"COCO文本权重: {COCO_TEXT_SCALE}\n目标文本权重: {TARGET_TEXT_SCALE}\n提示词: {PROMPT}\n指导比例: {GUIDANCE}\n"
-                    f"推理步数: {args.num_inference_steps}\n处理样本数: {len(names)}\n")
+                    f"推理步数: {args.num_inference_steps}\n处理样本数: {len(names)}\n"
+                    f"为每个样本生成: 最多10张图像 (基于相似度最高的COCO图像)\n图像尺寸: 动态调整至与目标图像匹配 (保证是16的倍数)\n")
     rng = random.Random(args.fallback_seed)
     s, e = shard_bounds(len(names), world, rank)
     ok = bad = images = 0            # samples that produced at least one image / samples that produced none / images written
