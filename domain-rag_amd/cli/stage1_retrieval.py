@@ -17,7 +17,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import retrieval as R
+from .. import hostlogic as H, retrieval as R
 
 RESULTS_DIR = "./retrieval_results"
 LAMAINPAINT_DIR = "../lamainpaint"
@@ -45,6 +45,7 @@ def build_parser():
     p.add_argument("--clip-weights", type=str, default=None, help="openai CLIP ViT-B/32 state_dict (.pt); default: synthetic")
     p.add_argument("--resnet-weights", type=str, default=None, help="torchvision resnet50 state_dict (.pt); default: synthetic")
     p.add_argument("--embed-batch", type=int, default=256)
+    p.add_argument("--no-visuals", action="store_true", help="skip the per-query *_visual.jpg contact sheets")
     p.add_argument("--host-preprocess", action="store_true",
                    help="resize on the host with PIL like the reference (default: PIL-exact resize on the GPU; same bits)")
     p.add_argument("--style-cache", type=str, default=None,
@@ -176,6 +177,27 @@ def get_inpainted_images(lama_dir, dataset, shot):
     return s2i, {s: mapping.get(s, s) for s in s2i}
 
 
+def visualize_results(query_image_path, result_image_paths, output_path, cell=(300, 225)):
+    """the per-query contact sheet of the reference (:354-393): query + up to 11 results on a 3 x 4 grid with "Query Image" /
+    "Top k" captions.  Drawn with PIL (the reference uses matplotlib; the file is for eyeballing, nothing reads it)."""
+    from PIL import Image, ImageDraw
+    cw, ch = cell
+    sheet = Image.new("RGB", (4 * cw, 3 * (ch + 18)), "white")
+    draw = ImageDraw.Draw(sheet)
+    items = [("Query Image", query_image_path)] + [(f"Top {i + 1}", p) for i, p in enumerate(result_image_paths[:11])]
+    for k, (title, path) in enumerate(items):
+        try:
+            im = H.load_image_rgb(R.clean_image_path(path))
+            im.thumbnail((cw - 8, ch - 8))
+        except Exception as e:
+            print(f"可视化图像时出错 {path}: {e}")
+            continue
+        x0, y0 = (k % 4) * cw, (k // 4) * (ch + 18)
+        draw.text((x0 + 4, y0 + 2), title, fill="black")
+        sheet.paste(im, (x0 + (cw - im.width) // 2, y0 + 18 + (ch - im.height) // 2))
+    sheet.save(output_path, quality=85)
+
+
 def retrieve_dataset(args, dataset, shot, model, preprocess, stem, feats, paths, results_dir, lama_dir, style_cache):
     """ref :773-898"""
     from PIL import Image
@@ -213,6 +235,9 @@ def retrieve_dataset(args, dataset, shot, model, preprocess, stem, feats, paths,
                 continue
             with open(os.path.join(results_dir, f"{dataset}_{shot}_shot_{cat}_{s}_retrieval_results.json"), "w", encoding="utf-8") as f:
                 json.dump(final, f, indent=2, ensure_ascii=False)
+            if not args.no_visuals:
+                visualize_results(s2i[s], [r["image_path"] for r in final[:10]],
+                                  os.path.join(results_dir, f"{dataset}_{shot}_shot_{cat}_{s}_visual.jpg"))
             cat_res.append({"sample_id": s, "image_path": s2i[s], "category": cat, "similar_images": final})
         if cat_res:
             all_results.setdefault(cat, []).extend(cat_res)

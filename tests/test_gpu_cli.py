@@ -52,6 +52,7 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
     assert set(sims[0]) == {"rank", "similarity", "image_path", "source_dataset"} and sims[0]["source_dataset"] == "coco"
     assert np.load(rr / "coco_clip_features.npy").shape == (8, 512) and len(json.load(open(rr / "coco_image_paths.json"))) == 8
     assert (rr / f"{ds}_1_shot_beetle_01_beetle_01_retrieval_results.json").exists()
+    assert Image.open(rr / f"{ds}_1_shot_beetle_01_beetle_01_visual.jpg").size == (1200, 729)
     assert np.load(rr / f"{ds}_1_shot_inpainted_clip_features.npy").shape == (2, 512)
 
     # ---- stage 2
