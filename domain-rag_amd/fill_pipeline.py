@@ -70,9 +70,12 @@ class FluxFillHIP:
             guidance = torch.full((B,), float(guidance_scale))
             for i in range(t0, num_inference_steps):
                 t = torch.full((B,), model_timestep(timesteps[i]))
-                fwd = self.tr.forward_graphed if (self.use_graph and recorder is None) else self.tr.forward
+                timed = recorder is not None and (i - t0) % recorder.every == 0
+                ops.set_recorder(recorder if timed else None)
+                fwd = self.tr.forward_graphed if (self.use_graph and not timed) else self.tr.forward
                 v = fwd(hidden, prompt_embeds, pooled, t, self._img_ids, self._txt_ids, guidance)
                 ops.flow_euler_rows(hv, v, B * Si, 64, C, 64, float(sigmas[i + 1] - sigmas[i]))
+            ops.set_recorder(recorder)
             return self.vae.decode_tokens(hv, B, h, w, ld=C).clone()      # the decoder's buffer is reused by the next call
         finally:
             ops.set_recorder(None)

@@ -17,9 +17,13 @@ ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2, 3, 4
 
 
 class GemmRecorder:
-    """Per-launch timing of the GEMM kernel with events on the launch stream (bench.py's roofline)."""
+    """Per-launch timing of the GEMM kernel with events on the launch stream (bench.py's roofline).  ``every`` = n
+    samples the denoise loop: the GEMMs of every n-th DiT step are bracketed (all steps launch the same shapes), the
+    other steps run the way the product does (hipGraph replay, no events) so the timed region is not slowed by ~16k
+    event records."""
 
-    def __init__(self):
+    def __init__(self, every: int = 1):
+        self.every = max(1, int(every))
         self.events = []
         self.shapes = []
         self.is_conv = []

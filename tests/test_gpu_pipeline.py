@@ -106,3 +106,23 @@ def test_prior_outputs_do_not_alias(gpu):
     a0 = a.clone()
     b, pb = prior(bg[1:2], t5, pooled, [1.0], [1.0], group=1)
     assert torch.equal(a, a0) and not torch.equal(a, b) and a.data_ptr() != b.data_ptr() and pa.data_ptr() != pb.data_ptr()
+
+
+def test_sampled_roofline_recorder_does_not_change_the_pixels(gpu):
+    """bench.py brackets the GEMMs of every n-th denoise step with events and lets the other steps replay the hipGraph:
+    the mixed eager/replay batch must produce the bytes of the plain product run, and count the launches it says."""
+    from domain_rag_amd import fill_pipeline as fp, ops, vae, vit
+    from domain_rag_amd.flux_params import FluxConfig
+    cfg = FluxConfig(in_channels=384, num_layers=1, num_single_layers=2, num_attention_heads=2, joint_attention_dim=256,
+                     pooled_projection_dim=64)
+    job = fp.SyntheticFillJob(batch=2, res=64, denoise_steps=5, device=gpu, seed=7, cfg=cfg, vae_cfg=vae.VaeConfig(layers_per_block=1),
+                              vit_cfg=vit.VitConfig(image_size=56, patch_size=14, hidden=192, heads=2, layers=2, intermediate=304))
+    plain = job.run_batch().cpu()
+    rec_all, rec_2 = ops.GemmRecorder(), ops.GemmRecorder(every=2)
+    a = job.run_batch(recorder=rec_all).cpu()
+    b = job.run_batch(recorder=rec_2).cpu()
+    assert torch.equal(plain, a) and torch.equal(plain, b)
+    assert torch.equal(plain, job.run_batch().cpu())
+    n_all, n_2 = rec_all.totals()[2], rec_2.totals()[2]
+    per_step = (n_all - n_2) // 2                      # steps 1 and 3 of 0..4 are not bracketed at every=2
+    assert per_step > 0 and n_all - n_2 == 2 * per_step and (n_all - 5 * per_step) == (n_2 - 3 * per_step) > 0
