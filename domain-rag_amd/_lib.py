@@ -37,6 +37,13 @@ class ResampleArgs(ctypes.Structure):
                 ("tmp_row0", c_int), ("tmp_rows", c_int), ("src_col0", c_int), ("src_row0", c_int)]
 
 
+class Conv2dF32Args(ctypes.Structure):
+    """mirror of ``drag_conv2d_f32_args``"""
+    _fields_ = [(n, c_void_p) for n in ("x", "w", "y", "scale", "shift", "addend", "resid")] + \
+               [(n, c_int) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ld_add", "ld_res",
+                                     "KH", "KW", "stride", "pad", "pad_mode", "transposed", "act")]
+
+
 # name -> (restype, argtypes); every symbol include/domainrag_hip.h declares
 SIGNATURES = {
     "drag_version": (c_int, []),
@@ -72,6 +79,11 @@ SIGNATURES = {
     "drag_mask_pack_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "drag_flow_euler_rows_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     "drag_scale_noise_rows_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "drag_conv2d_f32": (c_int, [ctypes.POINTER(Conv2dF32Args), c_void_p]),
+    "drag_rfft2_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 3),
+    "drag_irfft2_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 3),
+    "drag_lama_prepare_u8": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "drag_lama_blend_u8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
 }
 
 _lib = None

@@ -375,3 +375,50 @@ def patchify_f32(img: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, P
     _need(img, torch.float32, "img")
     check(lib.drag_patchify_f32_nchw(_p(img), _p(out), B, H, W, P, ldo, _stream()), "drag_patchify_f32_nchw")
     return out
+
+
+# ---- LaMa stage (float32, NHWC) ------------------------------------------------------------------------------
+PAD_ZERO, PAD_REFLECT = 0, 1
+CONV_ACT_NONE, CONV_ACT_RELU, CONV_ACT_SIGMOID = 0, 1, 2
+
+
+def conv2d_f32(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, B: int, Hi: int, Wi: int, Ho: int, Wo: int, Cin: int, ldx: int,
+               ldy: int, stride: int = 1, pad: int = 0, pad_mode: int = PAD_ZERO, transposed: bool = False, act: int = CONV_ACT_NONE,
+               scale=None, shift=None, addend=None, ld_add: int = 0, resid=None, ld_res: int = 0) -> torch.Tensor:
+    """y = act((conv(x, w) + addend) * scale + shift) + resid on NHWC f32 views: ``x`` / ``y`` / ``addend`` / ``resid`` may be
+    channel slices of wider buffers (1-D or offset views; ld* = floats per pixel).  ``w`` is [Cout, KH, KW, Cin]."""
+    lib = _lib.load()
+    for t, n in ((x, "x"), (w, "w"), (y, "y")):
+        _need(t, torch.float32, "conv2d_f32." + n)
+    Cout, KH, KW, wc = w.shape
+    if wc != Cin or not w.is_contiguous():
+        raise ValueError("conv2d_f32.w must be contiguous [Cout, KH, KW, Cin]")
+    a = _lib.Conv2dF32Args()
+    a.x, a.w, a.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    a.scale = scale.data_ptr() if scale is not None else None
+    a.shift = shift.data_ptr() if shift is not None else None
+    a.addend = addend.data_ptr() if addend is not None else None
+    a.resid = resid.data_ptr() if resid is not None else None
+    a.B, a.Hi, a.Wi, a.Cin, a.ldx, a.Ho, a.Wo, a.Cout, a.ldy, a.ld_add, a.ld_res = B, Hi, Wi, Cin, ldx, Ho, Wo, Cout, ldy, ld_add, ld_res
+    a.KH, a.KW, a.stride, a.pad, a.pad_mode, a.transposed, a.act = KH, KW, stride, pad, pad_mode, int(transposed), act
+    check(lib.drag_conv2d_f32(ctypes.byref(a), _stream()), "drag_conv2d_f32")
+    return y
+
+
+def rfft2_f32(x, tmp, y, B, H, W, C, ldx, tw_w, tw_h):
+    check(_lib.load().drag_rfft2_f32(_p(x), _p(tmp), _p(y), B, H, W, C, ldx, _p(tw_w), _p(tw_h), _stream()), "drag_rfft2_f32")
+
+
+def irfft2_f32(f, tmp, y, add, B, H, W, C, ldy, ld_add, tw_w, tw_h):
+    check(_lib.load().drag_irfft2_f32(_p(f), _p(tmp), _p(y), _p(add), B, H, W, C, ldy, ld_add, _p(tw_w), _p(tw_h), _stream()),
+          "drag_irfft2_f32")
+
+
+def lama_prepare(img_u8, mask_u8, x, H, W, Hp, Wp):
+    _need(img_u8, torch.uint8, "lama_prepare.img"); _need(mask_u8, torch.uint8, "lama_prepare.mask")
+    check(_lib.load().drag_lama_prepare_u8(_p(img_u8), _p(mask_u8), _p(x), H, W, Hp, Wp, _stream()), "drag_lama_prepare_u8")
+
+
+def lama_blend(pred, ld, img_u8, mask_u8, out_u8, H, W, Hp, Wp):
+    check(_lib.load().drag_lama_blend_u8(_p(pred), ld, _p(img_u8), _p(mask_u8), _p(out_u8), H, W, Hp, Wp, _stream()),
+          "drag_lama_blend_u8")

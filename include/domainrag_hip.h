@@ -238,6 +238,45 @@ int drag_flow_euler_rows_bf16(void* x, const void* v, int64_t rows, int32_t cols
 int drag_scale_noise_rows_bf16(void* x, const void* noise, int64_t rows, int32_t cols, int32_t ldx, int32_t ldn,
                                float sigma, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * LaMa inpainting stage (lama_inpaint/lama_inpaint.py:172-215 -> simple_lama_inpainting.SimpleLama.__call__, un-vendored:
+ * prepare_img_and_mask, the big-lama FFCResNetGenerator, the blend of DefaultInpaintingTrainingModule.forward).
+ * float32 throughout like the reference; activations NHWC f32.
+ */
+#define DRAG_PAD_ZERO 0
+#define DRAG_PAD_REFLECT 1
+#define DRAG_CONV_ACT_NONE 0
+#define DRAG_CONV_ACT_RELU 1
+#define DRAG_CONV_ACT_SIGMOID 2
+typedef struct drag_conv2d_f32_args {
+  const float* x;      /* NHWC [B, Hi, Wi, ldx]; the Cin channels read start at x (pre-offset the pointer for a channel slice) */
+  const float* w;      /* [Cout, KH, KW, Cin] (nn.Conv2d weight permuted 0,2,3,1; nn.ConvTranspose2d weight permuted 1,2,3,0) */
+  float* y;            /* NHWC [B, Ho, Wo, ldy], Cout channels written from y */
+  const float* scale;  /* [Cout] or NULL (= 1): eval-mode BatchNorm gamma / sqrt(var + eps) */
+  const float* shift;  /* [Cout] or NULL (= 0): beta - mean * scale, or the conv bias */
+  const float* addend; /* NHWC [B, Ho, Wo, ld_add] added BEFORE scale/shift (the other FFC branch), or NULL */
+  const float* resid;  /* NHWC [B, Ho, Wo, ld_res] added AFTER the activation (FFCResnetBlock identity), or NULL */
+  int32_t B, Hi, Wi, Cin, ldx, Ho, Wo, Cout, ldy, ld_add, ld_res;
+  int32_t KH, KW, stride, pad, pad_mode, transposed, act;
+} drag_conv2d_f32_args;
+/* y = act((conv(x, w) + addend) * scale + shift) + resid.  transposed = 1: the gather form of nn.ConvTranspose2d
+ * (out[o] += in[i] * w[k] where o = i*stride - pad + k); Ho / Wo then carry the output_padding. */
+int drag_conv2d_f32(const drag_conv2d_f32_args* args, void* stream);
+/* torch.fft.rfftn(x, dim=(-2,-1), norm="ortho") of C maps x NHWC [B,H,W,ldx] -> y [B,H,W/2+1,2C] with channel 2c = real, 2c+1 =
+ * imaginary (FourierUnit's stacking).  tw_w / tw_h: float2 tables (cos, sin)(2 pi j / n) for n = W / H, float64-evaluated by the
+ * caller; tmp: B*H*(W/2+1)*2C floats. */
+int drag_rfft2_f32(const float* x, float* tmp, float* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                   const float* tw_w, const float* tw_h, void* stream);
+/* torch.fft.irfftn(f, s=(H,W), dim=(-2,-1), norm="ortho") of f [B,H,W/2+1,2C] -> y NHWC [B,H,W,ldy] (+ add [B,H,W,ld_add] or NULL) */
+int drag_irfft2_f32(const float* f, float* tmp, float* y, const float* add, int32_t B, int32_t H, int32_t W, int32_t C,
+                    int32_t ldy, int32_t ld_add, const float* tw_w, const float* tw_h, void* stream);
+/* prepare_img_and_mask + the model's input: uint8 RGB [H,W,3], uint8 mask [H,W] -> NHWC f32 [Hp,Wp,4] =
+ * (img/255 * (1-m), m), m = mask > 0, both padded bottom/right to (Hp,Wp) like np.pad(mode="symmetric") */
+int drag_lama_prepare_u8(const void* img, const void* mask, float* x, int32_t H, int32_t W, int32_t Hp, int32_t Wp, void* stream);
+/* m * pred + (1-m) * img/255 -> *255, clip, truncate -> uint8 RGB [Hp,Wp,3]; pred NHWC f32 [Hp,Wp,ld] */
+int drag_lama_blend_u8(const float* pred, int32_t ld, const void* img, const void* mask, void* out, int32_t H, int32_t W,
+                       int32_t Hp, int32_t Wp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
