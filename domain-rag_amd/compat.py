@@ -240,8 +240,15 @@ def _diffusers_module():
     return m
 
 
-def install(modules=("clip", "faiss", "diffusers")) -> None:
+def _simple_lama_module():
+    from . import lama
+    mod = types.ModuleType("simple_lama_inpainting")
+    mod.SimpleLama = lama.SimpleLama
+    return mod
+
+
+def install(modules=("clip", "faiss", "diffusers", "simple_lama_inpainting")) -> None:
     """register the HIP-backed stand-ins under the module names the reference scripts import"""
-    makers = {"clip": _clip_module, "faiss": _faiss_module, "diffusers": _diffusers_module}
+    makers = {"clip": _clip_module, "faiss": _faiss_module, "diffusers": _diffusers_module, "simple_lama_inpainting": _simple_lama_module}
     for name in modules:
         sys.modules[name] = makers[name]()
