@@ -8,11 +8,10 @@
 //                        core (v_mfma_f32_32x32x2_f32 = an fmaf chain): 64 pixels x 64 output channels per workgroup, 16
 //                        input channels of one tap per step through double-buffered LDS; BatchNorm (eval) as a per-channel
 //                        scale/shift, the FFC branch sum (addend), ReLU / sigmoid and the residual add in the epilogue.
-//   rfft2 / irfft2       torch.fft.rfftn / irfftn(norm="ortho") of the FourierUnit by direct summation against
-//                        float64-computed twiddle tables: map sizes are H/8 x W/8 of arbitrary (non power-of-two) size and the
-//                        whole transform is <3 % of the network's FLOPs, so four small VALU kernels (r2c along W, c2c along
-//                        H and back) with 4 outputs per thread are enough.  Channel order of the spectrum is the reference's
-//                        (2c = real, 2c+1 = imaginary).
+//   rfft2 / irfft2       torch.fft.rfftn / irfftn(norm="ortho") of the FourierUnit: map sizes are H/8 x W/8 of arbitrary (non
+//                        power-of-two) size, so each of the four passes (r2c along W, c2c along H and back) is a dense DFT
+//                        as a GEMM on the same f32 matrix core, its twiddle tiles gathered from a float64-computed n-entry
+//                        table (dft_mfma_kernel).  Channel order of the spectrum is the reference's (2c real, 2c+1 imaginary).
 //   lama_prepare / blend /255, symmetric pad to a multiple of 8, mask > 0, img*(1-m) | m ; m*pred + (1-m)*img, *255, clip, truncate.
 #include "drag_common.h"
 
@@ -139,103 +138,139 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// direct-summation DFTs.  tw_n[j] = (cos, sin)(2 pi j / n), j in [0, n).  TO = outputs per thread along the axis.
+// DFT passes as f32-MFMA GEMMs against twiddle tiles generated on the fly.  tw[j] = (cos, sin)(2 pi j / n), j in [0, n),
+// float64-evaluated by the caller; the element (i, k) of the n-point DFT matrix is tw[(i * k) mod n], so a thread that
+// fills 4 consecutive k of row i walks the table with an integer stride — no n x n matrices in memory.
+//
+//   P[i, col] = sum_k  a_k cos(2 pi i k / n) * X[k, col]        Q[i, col] = sum_k  a_k sin(2 pi i k / n) * X[k, col]
+//
+// X[k, col] = x[z * x_zs + k * x_ks + col] with `col` running over contiguous floats (channels, or interleaved complex
+// channels).  Per mode, with (re, im) = (even, odd) columns and `partner` the other column of the pair:
+//   R2C  real columns:                 out(i, col) = (P, -Q)                       [r2c along W]
+//   C2C  complex columns, sign s:      re = P_re + s Q_im,  im = P_im - s Q_re     [s = +1: e^{-i}, forward; -1 inverse]
+//   C2R  complex columns, a_k = 1|2:   out(i, col/2) = P_re - Q_im (+ add)         [c2r along W: DC / Nyquist imaginary parts drop]
+// Tile: 64 outputs x 64 columns per workgroup, 4 waves x (32x32 P and 32x32 Q accumulators), K-step 16.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int TO = 4;
+enum { DFT_R2C = 0, DFT_C2C = 1, DFT_C2R = 2 };
+constexpr int DT_M = 64, DT_N = 64, DT_K = 16, DT_LDA = DT_K + 4, DT_LDX = DT_N + 4;
 
-// real [B,H,W,ldx] (C channels) -> complex z [B,H,Wf,C] (float2), e^{-i}
-__global__ __launch_bounds__(256) void dft_w_r2c_kernel(const float* __restrict__ x, f32x2_t* __restrict__ z, const f32x2_t* __restrict__ tw,
-                                                        int W, int Wf, int C, int ldx) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int k0 = (blockIdx.y * 4 + threadIdx.y) * TO;
-  const long long row = blockIdx.z;   // b*H + h
-  if (c >= C || k0 >= Wf) return;
-  float re[TO], im[TO];
-  int idx[TO];
+struct DftK {
+  const float* x;
+  float* y;
+  const float* add;
+  const f32x2_t* tw;
+  int n;            // transform length (period of the twiddle table)
+  int M, K, N;      // outputs along the axis, contraction length, float columns
+  long long x_zs, x_ks, y_zs, y_is, add_zs, add_is;
+  float sgn, norm;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dft_mfma_kernel(DftK p) {
+  __shared__ __attribute__((aligned(16))) float Cs[2][DT_M][DT_LDA];
+  __shared__ __attribute__((aligned(16))) float Ss[2][DT_M][DT_LDA];
+  __shared__ __attribute__((aligned(16))) float Xs[2][DT_K][DT_LDX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int i0 = blockIdx.y * DT_M, c0 = blockIdx.x * DT_N;
+  const long long z = blockIdx.z;
+  // twiddle loader role: row ti, 4 consecutive k
+  const int ti = tid >> 2, tk = (tid & 3) * 4;
+  const int gi = i0 + ti;
+  const bool i_ok = gi < p.M;
+  const int im = i_ok ? gi % p.n : 0;
+  const int step16 = (int)(((long long)im * DT_K) % p.n);
+  int idx0 = (int)(((long long)im * tk) % p.n);      // (i * k) mod n at k = k0 + tk
+  // data loader role: row xk, 4 consecutive columns
+  const int xk = tid >> 4, xc = (tid & 15) * 4;
+  const bool c_ok = c0 + xc < p.N;
+  const float* xp = p.x + z * p.x_zs + c0 + xc;
+  const int nyq = (p.n & 1) ? -1 : p.n / 2;
+
+  f32x4_t rc, rs, rx;
+  auto fetch = [&](int k0) {
+    int idx = idx0;
 #pragma unroll
-  for (int t = 0; t < TO; ++t) re[t] = im[t] = 0.f, idx[t] = 0;
-  const float* xp = x + row * W * ldx + c;
-  for (int w = 0; w < W; ++w) {
-    const float v = xp[(long long)w * ldx];
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + tk + j;
+      f32x2_t t = (i_ok && k < p.K) ? p.tw[idx] : (f32x2_t){0.f, 0.f};
+      if (MODE == DFT_C2R) {
+        const bool edge = k == 0 || k == nyq;
+        t[0] *= edge ? 1.0f : 2.0f;
+        t[1] = edge ? 0.0f : 2.0f * t[1];
+      }
+      rc[j] = t[0];
+      rs[j] = t[1];
+      idx += im;
+      if (idx >= p.n) idx -= p.n;
+    }
+    idx0 += step16;
+    if (idx0 >= p.n) idx0 -= p.n;
+    rx = (c_ok && k0 + xk < p.K) ? *(const f32x4_t*)(xp + (long long)(k0 + xk) * p.x_ks) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  auto stash = [&](int buf) {
+    *(f32x4_t*)&Cs[buf][ti][tk] = rc;
+    *(f32x4_t*)&Ss[buf][ti][tk] = rs;
+    *(f32x4_t*)&Xs[buf][xk][xc] = rx;
+  };
+  f32x16_t P, Q;
 #pragma unroll
-    for (int t = 0; t < TO; ++t) {
-      const f32x2_t cs = tw[idx[t]];
-      re[t] = fmaf(v, cs[0], re[t]);
-      im[t] = fmaf(-v, cs[1], im[t]);
-      idx[t] += (k0 + t) % W;
-      if (idx[t] >= W) idx[t] -= W;
+  for (int r = 0; r < 16; ++r) P[r] = Q[r] = 0.f;
+  const int nsteps = (p.K + DT_K - 1) / DT_K;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int fi = lane & 31, fk = (lane >> 5) * 8;
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < nsteps;
+    if (more) fetch((s + 1) * DT_K);
+    const f32x4_t a0 = *(const f32x4_t*)&Cs[buf][wm * 32 + fi][fk], a1 = *(const f32x4_t*)&Cs[buf][wm * 32 + fi][fk + 4];
+    const f32x4_t s0 = *(const f32x4_t*)&Ss[buf][wm * 32 + fi][fk], s1 = *(const f32x4_t*)&Ss[buf][wm * 32 + fi][fk + 4];
+    float xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = Xs[buf][fk + j][wn * 32 + fi];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      P = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], xb[j], P, 0, 0, 0);
+      Q = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[j], xb[j], Q, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      P = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], xb[4 + j], P, 0, 0, 0);
+      Q = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[j], xb[4 + j], Q, 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+  }
+  // lane owns column col and 16 output rows; its pair partner (col ^ 1) sits in lane ^ 1 with the same rows
+  const int col = c0 + wn * 32 + (lane & 31);
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wm * 32 + (lane >> 5) * 4 + 8 * (r >> 2) + (r & 3);
+    const float pq = MODE == DFT_R2C ? 0.f : __shfl_xor(Q[r], 1, 64);
+    if (i >= p.M || col >= p.N) continue;
+    if (MODE == DFT_R2C) {
+      *(f32x2_t*)(p.y + z * p.y_zs + (long long)i * p.y_is + 2 * col) = (f32x2_t){P[r] * p.norm, -Q[r] * p.norm};
+    } else if (MODE == DFT_C2C) {
+      const float v = odd ? P[r] - p.sgn * pq : P[r] + p.sgn * pq;
+      p.y[z * p.y_zs + (long long)i * p.y_is + col] = v * p.norm;
+    } else {
+      if (odd) continue;
+      float v = (P[r] - pq) * p.norm;
+      if (p.add) v += p.add[z * p.add_zs + (long long)i * p.add_is + (col >> 1)];
+      p.y[z * p.y_zs + (long long)i * p.y_is + (col >> 1)] = v;
     }
   }
-#pragma unroll
-  for (int t = 0; t < TO; ++t)
-    if (k0 + t < Wf) z[(row * Wf + k0 + t) * C + c] = (f32x2_t){re[t], im[t]};
 }
 
-// complex [B,H,Wf,C] -> complex [B,H,Wf,C] along H; SIGN = -1 forward (e^{-i}), +1 inverse; result * norm
-template <int SIGN>
-__global__ __launch_bounds__(256) void dft_h_c2c_kernel(const f32x2_t* __restrict__ z, f32x2_t* __restrict__ y, const f32x2_t* __restrict__ tw,
-                                                        int H, int WfC, float norm) {
-  const int n = blockIdx.x * 64 + threadIdx.x;   // (kw, c)
-  const int k0 = (blockIdx.y * 4 + threadIdx.y) * TO;
-  const long long b = blockIdx.z;
-  if (n >= WfC || k0 >= H) return;
-  float re[TO], im[TO];
-  int idx[TO];
-#pragma unroll
-  for (int t = 0; t < TO; ++t) re[t] = im[t] = 0.f, idx[t] = 0;
-  const f32x2_t* zp = z + b * H * WfC + n;
-  for (int h = 0; h < H; ++h) {
-    const f32x2_t v = zp[(long long)h * WfC];
-#pragma unroll
-    for (int t = 0; t < TO; ++t) {
-      const f32x2_t cs = tw[idx[t]];
-      const float s = SIGN < 0 ? -cs[1] : cs[1];   // e^{SIGN i theta} = cos + i s
-      re[t] = fmaf(v[0], cs[0], fmaf(-v[1], s, re[t]));
-      im[t] = fmaf(v[0], s, fmaf(v[1], cs[0], im[t]));
-      idx[t] += (k0 + t) % H;
-      if (idx[t] >= H) idx[t] -= H;
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < TO; ++t)
-    if (k0 + t < H) y[(b * H + k0 + t) * WfC + n] = (f32x2_t){re[t] * norm, im[t] * norm};
-}
-
-// complex [B,H,Wf,C] -> real [B,H,W,ldy] (c2r along W: the imaginary parts of the DC and Nyquist bins do not contribute),
-// result * norm (+ add[B,H,W,ld_add])
-__global__ __launch_bounds__(256) void dft_w_c2r_kernel(const f32x2_t* __restrict__ z, float* __restrict__ y, const float* __restrict__ add,
-                                                        const f32x2_t* __restrict__ tw, int W, int Wf, int C, int ldy, int ld_add, float norm) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int w0 = (blockIdx.y * 4 + threadIdx.y) * TO;
-  const long long row = blockIdx.z;
-  if (c >= C || w0 >= W) return;
-  float acc[TO];
-  int idx[TO];
-  const f32x2_t* zp = z + row * Wf * C + c;
-  const float dc = zp[0][0];
-#pragma unroll
-  for (int t = 0; t < TO; ++t) acc[t] = dc, idx[t] = (w0 + t) % W;
-  const int nyq = (W & 1) ? -1 : W / 2;
-  for (int k = 1; k < Wf; ++k) {
-    const f32x2_t v = zp[(long long)k * C];
-    const float wk = k == nyq ? 1.0f : 2.0f;
-    const float vr = v[0] * wk, vi = k == nyq ? 0.0f : v[1] * wk;
-#pragma unroll
-    for (int t = 0; t < TO; ++t) {
-      const f32x2_t cs = tw[idx[t]];
-      acc[t] = fmaf(vr, cs[0], fmaf(-vi, cs[1], acc[t]));
-      idx[t] += (w0 + t) % W;
-      if (idx[t] >= W) idx[t] -= W;
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < TO; ++t)
-    if (w0 + t < W) {
-      const long long o = row * W + w0 + t;
-      float v = acc[t] * norm;
-      if (add) v += add[o * ld_add + c];
-      y[o * ldy + c] = v;
-    }
+template <int MODE>
+static int launch_dft(const DftK& k, long long Z, hipStream_t stream) {
+  dim3 grid((unsigned)((k.N + DT_N - 1) / DT_N), (unsigned)((k.M + DT_M - 1) / DT_M), (unsigned)Z);
+  hipLaunchKernelGGL(dft_mfma_kernel<MODE>, grid, dim3(256), 0, stream, k);
+  DRAG_LAUNCH_CHECK();
+  return 0;
 }
 
 __device__ __forceinline__ int sym_index(int i, int n) {   // numpy.pad(mode="symmetric"): ... c b a | a b c | c b a ...
@@ -310,34 +345,46 @@ extern "C" int drag_rfft2_f32(const float* x, float* tmp, float* y, int32_t B, i
                               const float* tw_w, const float* tw_h, void* stream) {
   DRAG_CHECK(x && tmp && y && tw_w && tw_h, "rfft2_f32: null pointer");
   DRAG_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C, "rfft2_f32: bad shape");
+  DRAG_CHECK(C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)tmp & 15) == 0 && ((uintptr_t)y & 15) == 0,
+             "rfft2_f32: channels and pixel stride must be multiples of 4 floats, pointers 16-byte aligned");
   DRAG_CHECK((long long)B * H <= 65535, "rfft2_f32: too many rows");
   const int Wf = W / 2 + 1;
-  const dim3 blk(64, 4);
-  hipLaunchKernelGGL(dft_w_r2c_kernel, dim3((C + 63) / 64, (Wf + 4 * TO - 1) / (4 * TO), B * H), blk, 0, (hipStream_t)stream, x,
-                     (f32x2_t*)tmp, (const f32x2_t*)tw_w, W, Wf, C, ldx);
-  DRAG_LAUNCH_CHECK();
-  const float norm = (float)(1.0 / sqrt((double)H * (double)W));
-  hipLaunchKernelGGL(dft_h_c2c_kernel<-1>, dim3((Wf * C + 63) / 64, (H + 4 * TO - 1) / (4 * TO), B), blk, 0, (hipStream_t)stream,
-                     (const f32x2_t*)tmp, (f32x2_t*)y, (const f32x2_t*)tw_h, H, Wf * C, norm);
-  DRAG_LAUNCH_CHECK();
-  return 0;
+  DftK k{};
+  // r2c along W: z = (b, h); X[w, c]; out tmp[z, kw, c] complex
+  k.x = x; k.y = tmp; k.add = nullptr; k.tw = (const f32x2_t*)tw_w; k.n = W;
+  k.M = Wf; k.K = W; k.N = C;
+  k.x_zs = (long long)W * ldx; k.x_ks = ldx; k.y_zs = (long long)Wf * 2 * C; k.y_is = 2 * C;
+  k.sgn = 1.f; k.norm = 1.f;
+  if (int rc = launch_dft<DFT_R2C>(k, (long long)B * H, (hipStream_t)stream)) return rc;
+  // c2c along H, e^{-i}: z = b; X[h, (kw, c, ri)]
+  k.x = tmp; k.y = y; k.tw = (const f32x2_t*)tw_h; k.n = H;
+  k.M = H; k.K = H; k.N = Wf * 2 * C;
+  k.x_zs = (long long)H * k.N; k.x_ks = k.N; k.y_zs = k.x_zs; k.y_is = k.N;
+  k.sgn = 1.f; k.norm = (float)(1.0 / sqrt((double)H * (double)W));
+  return launch_dft<DFT_C2C>(k, B, (hipStream_t)stream);
 }
 
 extern "C" int drag_irfft2_f32(const float* f, float* tmp, float* y, const float* add, int32_t B, int32_t H, int32_t W, int32_t C,
                                int32_t ldy, int32_t ld_add, const float* tw_w, const float* tw_h, void* stream) {
   DRAG_CHECK(f && tmp && y && tw_w && tw_h, "irfft2_f32: null pointer");
   DRAG_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && (!add || ld_add >= C), "irfft2_f32: bad shape");
+  DRAG_CHECK(C % 4 == 0 && ((uintptr_t)f & 15) == 0 && ((uintptr_t)tmp & 15) == 0,
+             "irfft2_f32: channels must be a multiple of 4 floats, spectrum pointers 16-byte aligned");
   DRAG_CHECK((long long)B * H <= 65535, "irfft2_f32: too many rows");
   const int Wf = W / 2 + 1;
-  const dim3 blk(64, 4);
-  hipLaunchKernelGGL(dft_h_c2c_kernel<1>, dim3((Wf * C + 63) / 64, (H + 4 * TO - 1) / (4 * TO), B), blk, 0, (hipStream_t)stream,
-                     (const f32x2_t*)f, (f32x2_t*)tmp, (const f32x2_t*)tw_h, H, Wf * C, 1.0f);
-  DRAG_LAUNCH_CHECK();
-  const float norm = (float)(1.0 / sqrt((double)H * (double)W));
-  hipLaunchKernelGGL(dft_w_c2r_kernel, dim3((C + 63) / 64, (W + 4 * TO - 1) / (4 * TO), B * H), blk, 0, (hipStream_t)stream,
-                     (const f32x2_t*)tmp, y, add, (const f32x2_t*)tw_w, W, Wf, C, ldy, ld_add, norm);
-  DRAG_LAUNCH_CHECK();
-  return 0;
+  DftK k{};
+  k.x = f; k.y = tmp; k.add = nullptr; k.tw = (const f32x2_t*)tw_h; k.n = H;
+  k.M = H; k.K = H; k.N = Wf * 2 * C;
+  k.x_zs = (long long)H * k.N; k.x_ks = k.N; k.y_zs = k.x_zs; k.y_is = k.N;
+  k.sgn = -1.f; k.norm = 1.f;
+  if (int rc = launch_dft<DFT_C2C>(k, B, (hipStream_t)stream)) return rc;
+  // c2r along W: z = (b, h); X[kw, (c, ri)]; out y[z, w, c]
+  k.x = tmp; k.y = y; k.add = add; k.tw = (const f32x2_t*)tw_w; k.n = W;
+  k.M = W; k.K = Wf; k.N = 2 * C;
+  k.x_zs = (long long)Wf * 2 * C; k.x_ks = 2 * C; k.y_zs = (long long)W * ldy; k.y_is = ldy;
+  k.add_zs = (long long)W * ld_add; k.add_is = ld_add;
+  k.sgn = 1.f; k.norm = (float)(1.0 / sqrt((double)H * (double)W));
+  return launch_dft<DFT_C2R>(k, (long long)B * H, (hipStream_t)stream);
 }
 
 extern "C" int drag_lama_prepare_u8(const void* img, const void* mask, float* x, int32_t H, int32_t W, int32_t Hp, int32_t Wp, void* stream) {
