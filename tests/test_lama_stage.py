@@ -157,3 +157,35 @@ def test_lama_needs_the_gpu():
     from domain_rag_amd import lama
     with pytest.raises(RuntimeError, match="no CPU path"):
         lama.LamaHIP(lama.LamaConfig(ngf=8, n_blocks=1), lama.init_params(lama.LamaConfig(ngf=8, n_blocks=1), 0), "cpu")
+
+
+def test_weight_files_load_through_both_containers(tmp_path):
+    """big-lama.pt is a TorchScript export whose parameters sit under some wrapper prefix; a training checkpoint keeps them
+    under ``generator.``.  Both must come back as the generator's own ``model.<i>.…`` names with the same values."""
+    import torch.nn as nn
+    from domain_rag_amd import lama
+    cfg = lama.LamaConfig(ngf=8, n_blocks=1)
+    p = lama.init_params(cfg, 0)
+    root = nn.Module()
+    for k, v in p.items():
+        parts = ("model.generator." + k).split(".")
+        m = root
+        for a in parts[:-1]:
+            if not hasattr(m, a):
+                m.add_module(a, nn.Module())
+            m = getattr(m, a)
+        if "running" in parts[-1]:
+            m.register_buffer(parts[-1], v.clone())
+        else:
+            m.register_parameter(parts[-1], nn.Parameter(v.clone()))
+    torch.jit.save(torch.jit.script(root), str(tmp_path / "big-lama.pt"))
+    sd = lama.load_state_dict(str(tmp_path / "big-lama.pt"))
+    assert set(sd) == set(p) and all(torch.equal(sd[k], p[k]) for k in p)
+    torch.save({"state_dict": {"generator." + k: v for k, v in p.items()}, "epoch": 3}, str(tmp_path / "best.ckpt"))
+    sd2 = lama.load_state_dict(str(tmp_path / "best.ckpt"))
+    assert set(sd2) == set(p) and all(torch.equal(sd2[k], p[k]) for k in p)
+    c = lama.config_from_state_dict(sd)
+    assert (c.ngf, c.n_down, c.n_blocks, c.ratio_g) == (8, 3, 1, 0.75)
+    torch.save({"state_dict": {"discriminator.x": torch.zeros(1)}}, str(tmp_path / "other.ckpt"))
+    with pytest.raises(RuntimeError, match="no FFCResNetGenerator parameters"):
+        lama.load_state_dict(str(tmp_path / "other.ckpt"))
