@@ -14,10 +14,11 @@
 //                        table (dft_mfma_kernel).  Channel order of the spectrum is the reference's (2c real, 2c+1 imaginary).
 //   lama_prepare / blend /255, symmetric pad to a multiple of 8, mask > 0, img*(1-m) | m ; m*pred + (1-m)*img, *255, clip, truncate.
 #include "drag_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int CT_M = 64, CT_N = 64, CT_K = 16, CT_LD = CT_K + 4;
+constexpr int CT_M = 64, CT_N = 64;
 
 struct ConvK {
   drag_conv2d_f32_args a;
@@ -40,7 +41,12 @@ __device__ __forceinline__ bool tap_coord(int o, int k, int n_in, int stride, in
   return i >= 0 && i < n_in;
 }
 
+// CT_K = input channels of one tap per step.  16 when many workgroups share a CU (they hide each other's load latency);
+// 64 for the low-resolution maps of the FFC blocks, where a CU holds one workgroup and the one-step-ahead prefetch must
+// cover the whole load latency by itself (4x the bytes in flight, 4x the MFMA work per barrier).
+template <int CT_K>
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
+  constexpr int CT_LD = CT_K + 4, NV = CT_K / 16;
   __shared__ __attribute__((aligned(16))) float As[2][CT_M][CT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][CT_N][CT_LD];
   const drag_conv2d_f32_args& a = p.a;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
   const int nsteps = taps * kchunks;
   const float* wrow = a.w + (long long)(n0 + (n_ok ? lr : 0)) * taps * a.Cin;
 
-  f32x4_t ra, rb;
+  f32x4_t ra[NV], rb[NV];
   int tap = 0, kc = 0;
   const float* arow = nullptr;
   bool a_ok = false;
@@ -77,10 +83,13 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
     arow = a.x + (((long long)ob * a.Hi + iy) * a.Wi + ix) * a.ldx;
   };
   auto fetch = [&]() {
-    const int c = kc * CT_K + lk;
-    const bool c_ok = c < a.Cin;
-    ra = (a_ok && c_ok) ? *(const f32x4_t*)(arow + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    rb = (n_ok && c_ok) ? *(const f32x4_t*)(wrow + (long long)tap * a.Cin + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = kc * CT_K + v * 16 + lk;
+      const bool c_ok = c < a.Cin;
+      ra[v] = (a_ok && c_ok) ? *(const f32x4_t*)(arow + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      rb[v] = (n_ok && c_ok) ? *(const f32x4_t*)(wrow + (long long)tap * a.Cin + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
   };
   auto advance = [&]() {
     if (++kc == kchunks) {
@@ -90,8 +99,11 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
     }
   };
   auto stash = [&](int buf) {
-    *(f32x4_t*)&As[buf][lr][lk] = ra;
-    *(f32x4_t*)&Bs[buf][lr][lk] = rb;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      *(f32x4_t*)&As[buf][lr][v * 16 + lk] = ra[v];
+      *(f32x4_t*)&Bs[buf][lr][v * 16 + lk] = rb[v];
+    }
   };
 
   f32x16_t acc;
@@ -109,12 +121,17 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
       advance();
       fetch();
     }
-    const f32x4_t a0 = *(const f32x4_t*)&As[buf][wm * 32 + fi][fk], a1 = *(const f32x4_t*)&As[buf][wm * 32 + fi][fk + 4];
-    const f32x4_t b0 = *(const f32x4_t*)&Bs[buf][wn * 32 + fi][fk], b1 = *(const f32x4_t*)&Bs[buf][wn * 32 + fi][fk + 4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc, 0, 0, 0);
+    for (int v = 0; v < NV; ++v) {
+      const float* ap = &As[buf][wm * 32 + fi][v * 16 + fk];
+      const float* bp = &Bs[buf][wn * 32 + fi][v * 16 + fk];
+      const f32x4_t a0 = *(const f32x4_t*)ap, a1 = *(const f32x4_t*)(ap + 4);
+      const f32x4_t b0 = *(const f32x4_t*)bp, b1 = *(const f32x4_t*)(bp + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc, 0, 0, 0);
+    }
     if (more) stash(buf ^ 1);
     __syncthreads();
   }
@@ -336,7 +353,12 @@ extern "C" int drag_conv2d_f32(const drag_conv2d_f32_args* a, void* stream) {
   k.a = *a;
   k.npix = (long long)a->B * a->Ho * a->Wo;
   dim3 grid((unsigned)((k.npix + CT_M - 1) / CT_M), (unsigned)((a->Cout + CT_N - 1) / CT_N));
-  hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+  // same k-order per output element in both instantiations (taps outer, channels ascending inside a tap): identical bits
+  static const bool force16 = getenv("DRAG_CONV_K16") != nullptr;
+  if (a->Cin % 64 == 0 && (long long)grid.x * grid.y < 1024 && !force16)
+    hipLaunchKernelGGL(conv2d_f32_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, k);
+  else
+    hipLaunchKernelGGL(conv2d_f32_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, k);
   DRAG_LAUNCH_CHECK();
   return 0;
 }
