@@ -44,6 +44,7 @@ def build_parser():
     p.add_argument("--tiny", action="store_true", help="test hook: tiny architectures, small images")
     p.add_argument("--num_inference_steps", type=int, default=STEPS)
     p.add_argument("--size", type=int, default=SIZE)
+    p.add_argument("--io_workers", type=int, default=4, help="background PNG encoder processes (0 = write inline like the reference)")
     p.add_argument("--ref_batch", type=int, default=8, help="references of one target generated per batch (1 = one at a time like the reference)")
     p.add_argument("--fallback-seed", type=int, default=None, help="seed the random-COCO fallback (reference: unseeded)")
     return p
@@ -90,7 +91,12 @@ def generate_ranked(engine: Engine, target_path, items, sdir, args, database):
         os.makedirs(sdir, exist_ok=True)
         for (similarity, ref_path, rank, _), arr in zip(chunk, imgs):
             try:
-                Image.fromarray(arr).save(os.path.join(sdir, f"generated_image_rank{rank}.png"))
+                img_path = os.path.join(sdir, f"generated_image_rank{rank}.png")
+                writer = getattr(args, "writer", None)
+                if writer is None:
+                    Image.fromarray(arr).save(img_path)
+                else:
+                    writer.save(Image.fromarray(arr), img_path)          # PNG encode off the generation thread
                 pf = os.path.join(sdir, "params.txt")
                 if not os.path.exists(pf):
                     with open(pf, "w") as f:
@@ -176,6 +182,9 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
                     f.write(f"找到了 {len(top)} 个相似图像，但生成全部失败\n")
                     for sim, path, r in top:
                         f.write(f"  - Rank {r}: {path} (相似度: {sim:.4f})\n")
+    for path, err in (args.writer.flush() if getattr(args, "writer", None) is not None else []):
+        print(f"生成图像时出错: 保存 {path} 失败: {err}")
+        images -= 1
     # the closing summary (:1046-1056); the size statistics read ref_info{rank}.txt, which is never written under that name
     # (the file is ref_inforank{r}_sim….txt), so the list stays empty in the reference too
     with open(os.path.join(base, "batch_params.txt" if world == 1 else f"batch_params_rank{rank}.txt"), "a") as f:
@@ -198,6 +207,8 @@ def main(argv=None):
         return 1
     with open(rf, encoding="utf-8") as f:
         results = json.load(f)
+    from ..io_pool import ImageWriter
+    args.writer = ImageWriter(args.io_workers)
     engine = Engine("dev", args.model_root, synthetic=args.synthetic_weights, tiny=args.tiny, device=torch.device("cuda", local))
     datasets = [args.dataset] if args.dataset else (DATASET_GROUPS[args.dataset_group] if args.dataset_group else list(results))
     tot_ok = tot_bad = 0
@@ -207,6 +218,7 @@ def main(argv=None):
             ok, bad = process_dataset(engine, results, ds, shot, args, rank, world)
             tot_ok += ok
             tot_bad += bad
+    args.writer.close()
     print(f"处理完成: 成功 {tot_ok} 个样本, 失败 {tot_bad} 个样本")
     return 0
 

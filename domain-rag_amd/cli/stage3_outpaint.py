@@ -27,6 +27,7 @@ import torch
 
 from .. import hostlogic as H
 from ..engine import Engine, generator_noise, pack_noise
+from ..io_pool import ImageWriter
 
 RESULT_DIR, DATASETS_DIR = "./result", "./datasets"
 
@@ -55,6 +56,7 @@ def build_parser():
     p.add_argument("--synthetic-weights", action="store_true")
     p.add_argument("--tiny", action="store_true", help="test hook: tiny architectures, min_dimension 64")
     p.add_argument("--num_inference_steps", type=int, default=H.NUM_INFERENCE_STEPS)
+    p.add_argument("--io_workers", type=int, default=4, help="background PNG encoder processes (0 = write inline like the reference)")
     p.add_argument("--bg_batch", type=int, default=8, help="backgrounds of one sample composited per batch (1 = one at a time like the reference)")
     return p
 
@@ -92,9 +94,10 @@ def parse_resume_log(path):
     return done, failed
 
 
-def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, process_id, rng):
-    """process_sample_hires (:872-1361)"""
+def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, process_id, rng, writer=None):
+    """process_sample_hires (:872-1361).  ``writer``: io_pool.ImageWriter for the large PNGs (None = write inline)"""
     from PIL import Image
+    save = (lambda im, path: im.save(path)) if writer is None else writer.save
     t0 = time.time()
     prefix = f"{dataset}_{sample_id}_{shot}shot"
     log = {"sample_id": sample_id, "sample_prefix": prefix, "status": "processing", "outpainted_images": [], "shot_number": shot}
@@ -113,7 +116,7 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
         out_dir = os.path.join(f"./outpaint_hires/process_{process_id}", dataset, f"{shot}_shot", sample_id)
         os.makedirs(out_dir, exist_ok=True)
         orig_saved = os.path.join(out_dir, f"{prefix}_original.png")
-        original.save(orig_saved)
+        save(original, orig_saved)
         bbox_saved = []                                   # every bbox crop next to the results (:1116-1131)
         for i, c in enumerate(crops):
             bp = os.path.join(out_dir, f"{prefix}_bbox{i + 1}_original.jpg")
@@ -135,10 +138,10 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
         log.update(upscaled_resolution=list(processed.size), up_scale_factor=up, down_scale_factor=down, was_upscaled=wu,
                    was_downscaled=wd, min_dimension_used=min_dim)
         if wd:
-            processed.save(os.path.join(out_dir, f"{prefix}_downscaled_bg.png"))
+            save(processed, os.path.join(out_dir, f"{prefix}_downscaled_bg.png"))
             log["downscaled_resolution"] = list(processed.size)
         if wu:
-            processed.save(os.path.join(out_dir, f"{prefix}_upscaled_bg.png"))
+            save(processed, os.path.join(out_dir, f"{prefix}_upscaled_bg.png"))
         pb = H.scale_bboxes(bboxes, up, down, wu, wd)
         mask_img, _ = H.generate_outpaint_mask(processed, pb)
         strength = H.STRENGTH.get(dataset, H.DEFAULT_STRENGTH)
@@ -186,10 +189,10 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
                 bg_idx, bg_path, name, suffix, mask_path, bg_saved, seed = (jb[k] for k in ("bg_idx", "bg_path", "name", "suffix", "mask_path", "bg_saved", "seed"))
                 result = Image.fromarray(arr)
                 hires_path = os.path.join(out_dir, f"{prefix}_hires_result{suffix}.png")
-                result.save(hires_path)
+                save(result, hires_path)
                 final = H.downscale_image(result, up) if wu else (H.upscale_image(result, 1.0 / down) if wd else result)
                 final_path = os.path.join(out_dir, f"{prefix}_final_result{suffix}.png")
-                final.save(final_path)
+                save(final, final_path)
                 params = {"categories": cats, "image_scale": 1.0, "prompt_scale": 1.0, "image_prompt_scale": ips,
                           "guidance_scale": guidance, "num_inference_steps": args.num_inference_steps, "strength": strength,
                           "redux_prompt": prompt, "seed": seed, "process_id": process_id, "shot_number": shot, "bg_index": bg_idx,
@@ -244,6 +247,7 @@ def run_rank(args, datasets, process_id, rank, world, gpu_process_id=None):
     torch.cuda.set_device(local)
     engine = Engine("fill", args.model_root, synthetic=args.synthetic_weights, tiny=args.tiny, device=torch.device("cuda", local))
     rng = random.Random(None if args.seed is None else args.seed + rank)
+    writer = ImageWriter(args.io_workers)
     done, failed = parse_resume_log(args.log_file) if (args.resume or args.failed_only) else (set(), set())
     outs = {}
     for ds in datasets:
@@ -256,7 +260,14 @@ def run_rank(args, datasets, process_id, rank, world, gpu_process_id=None):
         elif args.resume:
             ids = [s for s in ids if s not in done]
         mine = H.split_samples_for_gpus(ids, world)[rank] if world > 1 else ids
-        logs = [process_sample(engine, args, ds, s, sdirs[s], args.shot, gpu_process_id or process_id, rng) for s in mine]
+        logs = [process_sample(engine, args, ds, s, sdirs[s], args.shot, gpu_process_id or process_id, rng, writer) for s in mine]
+        # the PNGs of the last samples may still be encoding: wait, and turn a failed write into a failed sample
+        for path, err in writer.flush():
+            print(f"保存图像失败 {path}: {err}")
+            for lg in logs:
+                if lg["status"] == "completed" and os.path.join(ds, f"{args.shot}_shot", lg["sample_id"]) in path:
+                    lg["status"], lg["error"] = "error", f"{path}: {err}"
+                    print(f"样本 {lg['sample_id']} 处理失败，耗时 {lg.get('process_time_seconds', 0):.2f} 秒")
         res = H.formatted_result_json(ds, logs, args.shot, gpu_process_id or process_id)
         if gpu_process_id:
             res["gpu_process_id"] = gpu_process_id
@@ -265,6 +276,7 @@ def run_rank(args, datasets, process_id, rank, world, gpu_process_id=None):
         with open(os.path.join(out_dir, f"outpaint_results_{args.shot}shot.json"), "w", encoding="utf-8") as f:
             json.dump(res, f, indent=2, ensure_ascii=False)
         outs[ds] = res
+    writer.close()
     return outs
 
 

@@ -113,3 +113,31 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
     # worker 0 draws its seeds from args.seed + 0 like the single-process run: same pixels for its samples
     sd9 = root / "outpaint_hires" / "process_9_gpu0" / ds / "1_shot" / "beetle_01"
     assert np.array_equal(np.asarray(Image.open(sd / f"{pre}_hires_result_1.png")), np.asarray(Image.open(sd9 / f"{pre}_hires_result_1.png")))
+
+
+def test_stage3_background_writer_matches_inline_files(gpu, tmp_path):
+    """--io_workers 0 (Image.save on the generation thread, the reference's pattern) and the default background encoder
+    processes must leave byte-identical PNGs"""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    root = tmp_path
+    ds, name = "DIOR", "plane_7"
+    (root / "datasets" / ds / "annotations").mkdir(parents=True); (root / "datasets" / ds / "train").mkdir(parents=True)
+    Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)).save(root / "datasets" / ds / "train" / f"{name}.jpg")
+    json.dump({"images": [{"id": 1, "file_name": f"{name}.jpg", "width": 56, "height": 40}],
+               "annotations": [{"id": 1, "image_id": 1, "bbox": [8, 6, 20, 14], "category_id": 1}], "categories": [{"id": 1, "name": "airplane"}]},
+              open(root / "datasets" / ds / "annotations" / "1_shot.json", "w"))
+    sdir = root / "result" / f"{ds}_1shot_retrieval" / "results_x" / name
+    sdir.mkdir(parents=True)
+    for r in (1, 2):
+        Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(sdir / f"generated_image_rank{r}.png")
+    Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)).save(sdir / "target_input.png")
+    common = ["--dataset", ds, "--shot", "1", "--synthetic-weights", "--tiny", "--num_inference_steps", "2", "--seed", "5"]
+    _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "a"] + common + ["--io_workers", "0"], cwd=root)
+    _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "b"] + common, cwd=root)
+    da, db = (root / "outpaint_hires" / f"process_{p}" / ds / "1_shot" / name for p in "ab")
+    pngs = sorted(f for f in os.listdir(da) if f.endswith(".png"))
+    assert len(pngs) >= 8 and pngs == sorted(f for f in os.listdir(db) if f.endswith(".png"))
+    for f in pngs:
+        assert (da / f).read_bytes() == (db / f).read_bytes(), f
+    assert len(list((root / "final_results" / "process_b" / "1_shot" / ds / "1_shot").glob("*_final_result*.png"))) == 2
