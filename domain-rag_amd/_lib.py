@@ -83,6 +83,11 @@ SIGNATURES = {
     "drag_rfft2_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 3),
     "drag_irfft2_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 3),
     "drag_lama_prepare_u8": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "drag_vit_prepare_u8": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
+    "drag_vit_prepare_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "drag_layernorm_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int64, c_int64, c_float, c_void_p]),
+    "drag_clip_embed_ln_f32": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_float, c_void_p]),
+    "drag_attention_small_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     "drag_lama_blend_u8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
 }
 

@@ -42,6 +42,8 @@ def build_parser():
     p.add_argument("--lamainpaint-dir", type=str, default=None)
     p.add_argument("--force-recompute-inpainted", action="store_true")
     # additions (not in the reference)
+    p.add_argument("--clip-precision", choices=["fp32", "bf16"], default=None,
+                   help="arithmetic of the CLIP tower: fp32 (default; what openai-CLIP computes on its CPU path) or the faster bf16 MFMA tower")
     p.add_argument("--clip-weights", type=str, default=None, help="openai CLIP ViT-B/32 state_dict (.pt); default: synthetic")
     p.add_argument("--resnet-weights", type=str, default=None, help="torchvision resnet50 state_dict (.pt); default: synthetic")
     p.add_argument("--embed-batch", type=int, default=256)
@@ -260,7 +262,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
     print(f"使用设备: {device}")
-    model, preprocess = R.load_clip("ViT-B/32", device, weights=args.clip_weights)
+    model, preprocess = R.load_clip("ViT-B/32", device, weights=args.clip_weights, precision=args.clip_precision)
     if not args.host_preprocess:
         preprocess = R.load_clip_device_preprocess(device)
     stem = R.StemStyle(torch.load(args.resnet_weights, map_location="cpu") if args.resnet_weights else None, device)

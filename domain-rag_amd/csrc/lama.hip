@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
     v = v * sc + sh;
     if (a.act == DRAG_CONV_ACT_RELU) v = fmaxf(v, 0.f);
     else if (a.act == DRAG_CONV_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    else if (a.act == DRAG_CONV_ACT_QUICK_GELU) v = v * (1.0f / (1.0f + expf(-1.702f * v)));
     if (a.resid) v += a.resid[m * a.ld_res + co];
     a.y[m * a.ldy + co] = v;
   }

@@ -379,7 +379,7 @@ def patchify_f32(img: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, P
 
 # ---- LaMa stage (float32, NHWC) ------------------------------------------------------------------------------
 PAD_ZERO, PAD_REFLECT = 0, 1
-CONV_ACT_NONE, CONV_ACT_RELU, CONV_ACT_SIGMOID = 0, 1, 2
+CONV_ACT_NONE, CONV_ACT_RELU, CONV_ACT_SIGMOID, CONV_ACT_QUICK_GELU = 0, 1, 2, 3
 
 
 def conv2d_f32(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, B: int, Hi: int, Wi: int, Ho: int, Wo: int, Cin: int, ldx: int,
@@ -422,3 +422,37 @@ def lama_prepare(img_u8, mask_u8, x, H, W, Hp, Wp):
 def lama_blend(pred, ld, img_u8, mask_u8, out_u8, H, W, Hp, Wp):
     check(_lib.load().drag_lama_blend_u8(_p(pred), ld, _p(img_u8), _p(mask_u8), _p(out_u8), H, W, Hp, Wp, _stream()),
           "drag_lama_blend_u8")
+
+
+# ---- float32 CLIP tower ------------------------------------------------------------------------------------
+def linear_f32(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor, M: int, *, ldx: int, ldy: int, bias=None, act: int = CONV_ACT_NONE,
+               resid=None, ld_res: int = 0) -> torch.Tensor:
+    """y[m, :N] = act(x[m, :K] @ w.T + bias) + resid on the f32 matrix core (a 1x1 convolution over M "pixels"); w [N, K]"""
+    N, K = w.shape
+    return conv2d_f32(x, w.view(N, 1, 1, K), y, B=1, Hi=1, Wi=M, Ho=1, Wo=M, Cin=K, ldx=ldx, ldy=ldy, act=act, shift=bias,
+                      resid=resid, ld_res=ld_res)
+
+
+def vit_prepare(img: torch.Tensor, out: torch.Tensor, mean, std) -> None:
+    """uint8 [B,S,S,3] or normalised float [B,3,S,S] -> NHWC f32 [B,S,S,4] (4th channel 0)"""
+    lib = _lib.load()
+    if img.dtype == torch.uint8:
+        m, s = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+        check(lib.drag_vit_prepare_u8(_p(img), _p(out), img.numel() // 3, m, s, _stream()), "drag_vit_prepare_u8")
+    else:
+        _need(img, torch.float32, "vit_prepare.img")
+        B = img.shape[0]
+        check(lib.drag_vit_prepare_f32(_p(img), _p(out), B, img.numel() // (3 * B), _stream()), "drag_vit_prepare_f32")
+
+
+def layernorm_f32(x, y, gamma, beta, rows: int, D: int, eps: float, ldx: int | None = None, ldy: int | None = None) -> None:
+    check(_lib.load().drag_layernorm_f32(_p(x), _p(y), _p(gamma), _p(beta), rows, D, ldx or D, ldy or D, eps, _stream()), "drag_layernorm_f32")
+
+
+def clip_embed_ln(emb, cls, pos, gamma, beta, x, B: int, T: int, D: int, eps: float) -> None:
+    check(_lib.load().drag_clip_embed_ln_f32(_p(emb), _p(cls), _p(pos), _p(gamma), _p(beta), _p(x), B, T, D, eps, _stream()),
+          "drag_clip_embed_ln_f32")
+
+
+def attention_small_f32(qkv, out, B: int, T: int, H: int, hd: int, ld: int, ldo: int, scale: float) -> None:
+    check(_lib.load().drag_attention_small_f32(_p(qkv), _p(out), B, T, H, hd, ld, ldo, scale, _stream()), "drag_attention_small_f32")

@@ -16,12 +16,13 @@ the global row order, so top-k indices equal the single-GPU result bit-for-bit.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
 
 from . import ops
-from .vit import VitConfig, VitHIP, init_generic_params, openai_clip_to_generic
+from .vit import ClipVitF32HIP, VitConfig, VitHIP, init_generic_params, openai_clip_to_generic
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -110,7 +111,7 @@ def cv2_resize_linear_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
 class ClipImageModel:
     """``model`` half of ``clip.load``; only the image tower is on Domain-RAG's path."""
 
-    def __init__(self, vit: VitHIP):
+    def __init__(self, vit: "VitHIP | ClipVitF32HIP"):
         self.visual = vit
         self.device = vit.dev
 
@@ -123,9 +124,15 @@ class ClipImageModel:
         return ops.l2_normalize_(self.encode_image(image).clone())
 
 
-def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None = None, seed: int = 0):
+def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None = None, seed: int = 0, precision: str | None = None):
     """(model, preprocess).  ``weights``: an openai-CLIP state_dict (or a path to one saved with torch.save);
-    None -> seeded synthetic weights of the ViT-B/32 architecture (no checkpoints offline)."""
+    None -> seeded synthetic weights of the ViT-B/32 architecture (no checkpoints offline).
+    ``precision``: "fp32" (default; $DRAG_CLIP_PRECISION overrides) — the arithmetic openai-CLIP uses on its CPU path and at
+    least the precision of its fp16 CUDA path; "bf16" — the bf16 MFMA tower (≈4x the throughput, embeddings ≈1e-2 away from
+    the fp32 values, so near-ties among the top-k can order differently than the reference's)."""
+    precision = precision or os.environ.get("DRAG_CLIP_PRECISION", "fp32")
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("precision must be fp32 or bf16")
     if name != "ViT-B/32":
         raise ValueError("Domain-RAG uses CLIP ViT-B/32 only")
     cfg = VitConfig.clip_vit_b32()
@@ -140,7 +147,8 @@ def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None 
         g = openai_clip_to_generic(weights, cfg)
     else:
         g = init_generic_params(cfg, seed, device=device if str(device) != "cpu" else "cpu")
-    return ClipImageModel(VitHIP(cfg, g, device)), clip_preprocess
+    tower = ClipVitF32HIP(cfg, g, device) if precision == "fp32" else VitHIP(cfg, g, device)
+    return ClipImageModel(tower), clip_preprocess
 
 
 def load_clip_device_preprocess(device="cuda"):

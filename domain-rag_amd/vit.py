@@ -235,3 +235,85 @@ class VitHIP:
         return ws["out"].view(B, T, D)          # a view of the workspace: valid until the next call (the Redux prior consumes it at once)
 
     __call__ = forward
+
+
+class ClipVitF32HIP:
+    """CLIP's ``VisionTransformer`` in float32 on the GPU (csrc/vit_f32.hip + the f32-MFMA conv kernel): the arithmetic
+    openai-CLIP itself uses on its CPU path (``clip.load`` calls ``model.float()`` there; on CUDA it keeps fp16 weights).
+    Patch embedding = stride-P convolution over an NHWC frame with a zero 4th channel, every Linear a 1x1 convolution with
+    bias / QuickGELU / residual in its epilogue, LayerNorm two-pass in fp32, attention per (image, head) in LDS.
+    Takes the same generic parameter dict as VitHIP; class-token models with tokens <= 64 and head_dim <= 64 (ViT-B/32)."""
+
+    def __init__(self, cfg: VitConfig, g: dict, device="cuda"):
+        self.cfg, self.dev = cfg, torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("ClipVitF32HIP needs a GPU device (domain-rag_amd has no CPU path)")
+        D, H, P = cfg.hidden, cfg.heads, cfg.patch_size
+        if not cfg.cls_token or not cfg.proj_dim or cfg.tokens > 64 or D // H > 64 or D > 1024 or D % 4 or cfg.intermediate % 4:
+            raise ValueError("ClipVitF32HIP covers CLIP-style towers with <= 64 tokens and head_dim <= 64 (ViT-B/32)")
+        if cfg.act != ops.ACT_QUICK_GELU:
+            raise ValueError("ClipVitF32HIP implements openai-CLIP's QuickGELU MLP")
+        self.hd = D // H
+
+        def dv(t):
+            return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+        wp = torch.zeros((D, P, P, 4), dtype=torch.float32, device=self.dev)          # conv1.weight [D,3,P,P] -> [D,P,P,4]
+        wp[..., :3] = dv(g["patch.weight"]).view(D, 3, P, P).permute(0, 2, 3, 1)
+        self.w_patch = wp
+        self.cls, self.pos = dv(g["cls"]), dv(g["pos"])
+        self.ln_pre = (dv(g["ln_pre.weight"]), dv(g["ln_pre.bias"]))
+        self.ln_post = (dv(g["ln_post.weight"]), dv(g["ln_post.bias"]))
+        self.proj = dv(g["proj"]).t().contiguous()                                    # [proj_dim, D]
+        self.layers = []
+        for i in range(cfg.layers):
+            self.layers.append(dict(
+                ln1=(dv(g[f"l{i}.ln1.weight"]), dv(g[f"l{i}.ln1.bias"])), ln2=(dv(g[f"l{i}.ln2.weight"]), dv(g[f"l{i}.ln2.bias"])),
+                wqkv=torch.cat([dv(g[f"l{i}.{n}.weight"]) for n in "qkv"], 0).contiguous(),
+                bqkv=torch.cat([dv(g[f"l{i}.{n}.bias"]) for n in "qkv"], 0).contiguous(),
+                wo=dv(g[f"l{i}.o.weight"]), bo=dv(g[f"l{i}.o.bias"]),
+                w1=dv(g[f"l{i}.fc1.weight"]), b1=dv(g[f"l{i}.fc1.bias"]), w2=dv(g[f"l{i}.fc2.weight"]), b2=dv(g[f"l{i}.fc2.bias"])))
+        self._ws_B, self._ws = None, None
+
+    def _workspace(self, B):
+        if self._ws_B != B:
+            cfg = self.cfg
+            T, D, S = cfg.tokens, cfg.hidden, cfg.image_size
+            f = dict(dtype=torch.float32, device=self.dev)
+            self._ws = dict(frame=torch.empty((B, S, S, 4), **f), emb=torch.empty((B * (T - 1), D), **f), x=torch.empty((B * T, D), **f),
+                            nrm=torch.empty((B * T, D), **f), qkv=torch.empty((B * T, 3 * D), **f), att=torch.empty((B * T, D), **f),
+                            hid=torch.empty((B * T, cfg.intermediate), **f), pooled=torch.empty((B, D), **f))
+            self._ws_B = B
+        return self._ws
+
+    def forward(self, img: torch.Tensor) -> torch.Tensor:
+        """uint8 RGB [B,S,S,3] or normalised float [B,3,S,S] (``preprocess`` output) -> fp32 [B, proj_dim] (encode_image)"""
+        cfg = self.cfg
+        B, S, P = img.shape[0], cfg.image_size, cfg.patch_size
+        T, D, H, F = cfg.tokens, cfg.hidden, cfg.heads, cfg.intermediate
+        if img.dtype == torch.uint8:
+            if tuple(img.shape[1:]) != (S, S, 3):
+                raise ValueError(f"expected uint8 [B,{S},{S},3]")
+        elif tuple(img.shape[1:]) != (3, S, S):
+            raise ValueError(f"expected float [B,3,{S},{S}]")
+        ws = self._workspace(B)
+        x, nrm, qkv, att, hid = ws["x"], ws["nrm"], ws["qkv"], ws["att"], ws["hid"]
+        ops.vit_prepare(img.contiguous() if img.dtype == torch.uint8 else img.float().contiguous(), ws["frame"], cfg.mean, cfg.std)
+        gp = S // P
+        ops.conv2d_f32(ws["frame"], self.w_patch, ws["emb"], B=B, Hi=S, Wi=S, Ho=gp, Wo=gp, Cin=4, ldx=4, ldy=D, stride=P)
+        ops.clip_embed_ln(ws["emb"], self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], x, B, T, D, cfg.ln_eps)
+        M = B * T
+        scale = 1.0 / math.sqrt(self.hd)
+        for L in self.layers:
+            ops.layernorm_f32(x, nrm, L["ln1"][0], L["ln1"][1], M, D, cfg.ln_eps)
+            ops.linear_f32(nrm, L["wqkv"], qkv, M, ldx=D, ldy=3 * D, bias=L["bqkv"])
+            ops.attention_small_f32(qkv, att, B, T, H, self.hd, 3 * D, D, scale)
+            ops.linear_f32(att, L["wo"], x, M, ldx=D, ldy=D, bias=L["bo"], resid=x, ld_res=D)
+            ops.layernorm_f32(x, nrm, L["ln2"][0], L["ln2"][1], M, D, cfg.ln_eps)
+            ops.linear_f32(nrm, L["w1"], hid, M, ldx=D, ldy=F, bias=L["b1"], act=ops.CONV_ACT_QUICK_GELU)
+            ops.linear_f32(hid, L["w2"], x, M, ldx=F, ldy=D, bias=L["b2"], resid=x, ld_res=D)
+        ops.layernorm_f32(x, ws["pooled"], self.ln_post[0], self.ln_post[1], B, D, cfg.ln_eps, ldx=T * D, ldy=D)
+        out = torch.empty((B, cfg.proj_dim), dtype=torch.float32, device=self.dev)
+        return ops.linear_f32(ws["pooled"], self.proj, out, B, ldx=D, ldy=cfg.proj_dim)
+
+    __call__ = forward

@@ -248,6 +248,7 @@ int drag_scale_noise_rows_bf16(void* x, const void* noise, int64_t rows, int32_t
 #define DRAG_CONV_ACT_NONE 0
 #define DRAG_CONV_ACT_RELU 1
 #define DRAG_CONV_ACT_SIGMOID 2
+#define DRAG_CONV_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x), openai-CLIP's QuickGELU */
 typedef struct drag_conv2d_f32_args {
   const float* x;      /* NHWC [B, Hi, Wi, ldx]; the Cin channels read start at x (pre-offset the pointer for a channel slice) */
   const float* w;      /* [Cout, KH, KW, Cin] (nn.Conv2d weight permuted 0,2,3,1; nn.ConvTranspose2d weight permuted 1,2,3,0) */
@@ -276,6 +277,27 @@ int drag_lama_prepare_u8(const void* img, const void* mask, float* x, int32_t H,
 /* m * pred + (1-m) * img/255 -> *255, clip, truncate -> uint8 RGB [Hp,Wp,3]; pred NHWC f32 [Hp,Wp,ld] */
 int drag_lama_blend_u8(const float* pred, int32_t ld, const void* img, const void* mask, void* out, int32_t H, int32_t W,
                        int32_t Hp, int32_t Wp, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * float32 CLIP ViT-B/32 image tower (clip.model.VisionTransformer.forward, openai/CLIP@dcba3cb, un-vendored; reached through
+ * model.encode_image at retrieval/clip100_resnet_style_all_shots.py:171,284,337,948).  openai-CLIP computes in fp32 on the CPU
+ * and fp16 on CUDA; this path is fp32 on the GPU.  Matrix products run on drag_conv2d_f32 (patch embedding = stride-P conv,
+ * Linear = 1x1 conv); these are the remaining pieces.
+ */
+/* uint8 RGB pixels [npix,3] -> NHWC f32 [npix,4]: ((u/255 - mean)/std, 0)  (ToTensor + Normalize, two IEEE divisions) */
+int drag_vit_prepare_u8(const void* img, float* out, int64_t npix, const float* mean3, const float* std3, void* stream);
+/* normalised float NCHW [B,3,hw] (what clip's `preprocess` returns) -> NHWC f32 [B*hw,4] */
+int drag_vit_prepare_f32(const float* img, float* out, int32_t B, int64_t hw, void* stream);
+/* y[r,:D] = LayerNorm(x[r,:D]) * gamma + beta, rows at strides ldx / ldy (floats); D <= 1024 */
+int drag_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int32_t D, int64_t ldx,
+                       int64_t ldy, float eps, void* stream);
+/* x[b,0] = ln_pre(class_embedding + pos[0]); x[b,1+p] = ln_pre(emb[b,p] + pos[1+p]); emb [B,T-1,D], x [B,T,D] */
+int drag_clip_embed_ln_f32(const float* emb, const float* cls, const float* pos, const float* gamma, const float* beta, float* x,
+                           int32_t B, int32_t T, int32_t D, float eps, void* stream);
+/* out[b,t,h*hd:(h+1)*hd] = softmax(q k^T * scale) v per (image, head); qkv rows [B*T, ld] = (q | k | v), each H*head_dim wide;
+ * T <= 64, head_dim <= 64 */
+int drag_attention_small_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t head_dim, int32_t ld,
+                             int32_t ldo, float scale, void* stream);
 
 #ifdef __cplusplus
 }

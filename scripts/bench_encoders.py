@@ -11,11 +11,12 @@ def bench(fn, iters=5, warm=2):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-model, _ = R.load_clip("ViT-B/32", dev)
-for B in (64, 256, 1024):
+for prec in ("fp32", "bf16"):
+  model, _ = R.load_clip("ViT-B/32", dev, precision=prec)
+  for B in (64, 256, 1024):
     img = torch.randint(0, 256, (B, 224, 224, 3), device=dev, dtype=torch.uint8)
     ms = bench(lambda: model.embed_normalized(img))
-    print(f"CLIP ViT-B/32 embed B={B}: {ms:.2f} ms  {B/ms*1e3:.0f} img/s  {8.82e9*B/ms/1e9:.0f} TF/s (118287 images -> {118287/(B/ms*1e3):.1f} s)", flush=True)
+    print(f"CLIP ViT-B/32 {prec} embed B={B}: {ms:.2f} ms  {B/ms*1e3:.0f} img/s  {8.82e9*B/ms/1e9:.0f} TF/s (118287 images -> {118287/(B/ms*1e3):.1f} s)", flush=True)
 cfg = vit.VitConfig.siglip_so400m()
 sg = vit.VitHIP(cfg, vit.init_generic_params(cfg, 0, device=dev), dev)
 for B in (8, 32):

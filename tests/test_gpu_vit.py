@@ -78,3 +78,70 @@ def test_clip_embedding_is_independent_of_batch_history(gpu):
     again = model.encode_image(x[:1]).clone()
     small = model.encode_image(x[:7]).clone()
     assert torch.equal(first, again) and torch.equal(first[0], batch[0]) and torch.equal(small, batch[:7])
+
+
+CLIP_MEAN, CLIP_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+
+
+def test_clip_f32_tower_small_config_vs_transformers(gpu):
+    """the float32 tower against upstream transformers' CLIPVisionModelWithProjection in float32 with shared weights;
+    stated tolerance 2e-5 of the embedding scale (accumulation order only)"""
+    from domain_rag_amd import vit
+    from oracle import vit as ov
+    cfg = vit.VitConfig(image_size=96, patch_size=32, hidden=128, heads=2, layers=2, intermediate=512, act=3, ln_eps=1e-5,
+                        cls_token=True, patch_bias=False, proj_dim=64, mean=CLIP_MEAN, std=CLIP_STD)
+    g = vit.init_generic_params(cfg, 2, dtype=torch.float32)
+    img = (torch.rand(5, 96, 96, 3, generator=torch.Generator().manual_seed(1)) * 255).to(torch.uint8)
+    px = ov.normalize_u8(img, cfg.mean, cfg.std)
+    ref = ov.clip_image_embeds(g, 96, 32, 128, 2, 2, 512, 64, px, torch.float32)
+    tower = vit.ClipVitF32HIP(cfg, g, gpu)
+    out = tower(img.to(gpu))
+    assert out.dtype == torch.float32 and out.shape == (5, 64)
+    assert _rel(out, ref) < 2e-5, _rel(out, ref)
+    # clip's `preprocess` output (normalised float NCHW, possibly on the CPU) is the other accepted input: same bits
+    out2 = tower(px.to(gpu))
+    assert torch.equal(out, out2)
+    with pytest.raises(ValueError):
+        vit.ClipVitF32HIP(vit.VitConfig.siglip_so400m(), g, gpu)
+
+
+def test_clip_f32_vit_b32_vs_transformers_and_same_topk(gpu):
+    """the real ViT-B/32 architecture (seeded weights): embeddings within 1e-4 of the float32 upstream model, and the
+    ranking of a small corpus identical to the one computed from the upstream embeddings"""
+    from domain_rag_amd import ops, retrieval as R, vit
+    from oracle import retrieval as oret, vit as ov
+    cfg = vit.VitConfig.clip_vit_b32()
+    g = vit.init_generic_params(cfg, 7, dtype=torch.float32)
+    gen = torch.Generator().manual_seed(3)
+    base = torch.rand(40, 7, 7, 3, generator=gen)                      # low-frequency pictures, distinct per image
+    img = (torch.nn.functional.interpolate(base.permute(0, 3, 1, 2), size=224, mode="bilinear").permute(0, 2, 3, 1) * 255).to(torch.uint8)
+    px = ov.normalize_u8(img, cfg.mean, cfg.std)
+    ref = ov.clip_image_embeds(g, 224, 32, 768, 12, 12, 3072, 512, px, torch.float32)
+    model = R.ClipImageModel(vit.ClipVitF32HIP(cfg, g, gpu))
+    out = model.encode_image(img.to(gpu))
+    e = _rel(out, ref)
+    assert e < 1e-4, e
+    feats = ops.l2_normalize_(out.clone()).cpu().numpy()
+    rfeats = (ref / ref.norm(dim=-1, keepdim=True)).numpy()
+    D, I = oret.cosine_topk(feats[8:], feats[:8], 20)
+    Dr, Ir = oret.cosine_topk(rfeats[8:], rfeats[:8], 20)
+    import numpy as np
+    assert np.array_equal(I, Ir) and np.abs(D - Dr).max() < 1e-5
+    # the bf16 tower on the same weights sits two orders of magnitude further away (the deviation the fp32 default removes)
+    eb = _rel(vit.VitHIP(cfg, g, gpu)(img.to(gpu)), ref)
+    assert eb > 20 * e
+
+
+def test_load_clip_precision_switch(gpu, monkeypatch):
+    from domain_rag_amd import retrieval as R, vit
+    m32, _ = R.load_clip("ViT-B/32", device=gpu)
+    assert isinstance(m32.visual, vit.ClipVitF32HIP)
+    mbf, _ = R.load_clip("ViT-B/32", device=gpu, precision="bf16")
+    assert isinstance(mbf.visual, vit.VitHIP)
+    monkeypatch.setenv("DRAG_CLIP_PRECISION", "bf16")
+    assert isinstance(R.load_clip("ViT-B/32", device=gpu)[0].visual, vit.VitHIP)
+    x = torch.randint(0, 256, (3, 224, 224, 3), generator=torch.Generator().manual_seed(0), dtype=torch.uint8).to(gpu)
+    a, b = m32.encode_image(x), mbf.encode_image(x)                      # same seeded weights: same embeddings up to bf16 error
+    assert _rel(b, a) < 3e-2
+    with pytest.raises(ValueError):
+        R.load_clip("ViT-B/32", device=gpu, precision="fp16")
