@@ -46,3 +46,26 @@ def test_missing_library_fails_loudly(monkeypatch, built_lib):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdomainrag_hip.so")
     with pytest.raises(RuntimeError, match="no CPU"):
         _lib.load()
+
+
+def test_f32_stage_entry_points_validate_before_launch(built_lib):
+    """LaMa / float32-CLIP entry points reject bad arguments with a message and no launch (checkable without a GPU)"""
+    import ctypes
+    from domain_rag_amd import _lib
+    a = _lib.Conv2dF32Args()
+    assert built_lib.drag_conv2d_f32(ctypes.byref(a), None) != 0 and b"null" in built_lib.drag_last_error()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    a.x = a.w = a.y = p.value
+    a.B, a.Hi, a.Wi, a.Cin, a.ldx, a.Ho, a.Wo, a.Cout, a.ldy = 1, 4, 4, 6, 6, 4, 4, 8, 8
+    a.KH = a.KW = 3; a.stride = 1; a.pad = 1
+    assert built_lib.drag_conv2d_f32(ctypes.byref(a), None) != 0 and b"multiples of 4" in built_lib.drag_last_error()
+    a.Cin = a.ldx = 8; a.Ho = 5
+    assert built_lib.drag_conv2d_f32(ctypes.byref(a), None) != 0 and b"output size" in built_lib.drag_last_error()
+    a.Ho = 4; a.pad_mode = 1; a.transposed = 1
+    assert built_lib.drag_conv2d_f32(ctypes.byref(a), None) != 0 and b"transposed" in built_lib.drag_last_error()
+    assert built_lib.drag_rfft2_f32(p, p, p, 1, 4, 4, 6, 6, p, p, None) != 0 and b"multiples of 4" in built_lib.drag_last_error()
+    assert built_lib.drag_irfft2_f32(p, p, p, None, 1, 4, 4, 8, 4, 0, p, p, None) != 0 and b"bad shape" in built_lib.drag_last_error()
+    assert built_lib.drag_attention_small_f32(p, p, 1, 65, 2, 64, 384, 128, 0.125, None) != 0 and b"T <= 64" in built_lib.drag_last_error()
+    assert built_lib.drag_layernorm_f32(p, p, p, p, 4, 2048, 2048, 2048, 1e-5, None) != 0 and b"D <= 1024" in built_lib.drag_last_error()
+    assert built_lib.drag_lama_prepare_u8(p, p, p, 8, 8, 4, 8, None) != 0 and b"bad shape" in built_lib.drag_last_error()
