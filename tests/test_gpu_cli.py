@@ -1,4 +1,4 @@
-"""The three stage CLIs end to end on a synthetic mini-dataset (tiny architectures, seeded synthetic weights):
+"""The stage CLIs (LaMa -> retrieval -> generation -> outpainting) end to end on a synthetic mini-dataset (tiny architectures, seeded synthetic weights):
 file tree + JSON schemas of the reference's stage boundaries."""
 import json
 import os
@@ -16,7 +16,7 @@ def _run(mod, args, cwd, env_extra=None):
     env = dict(os.environ, PYTHONPATH=ROOT, DRAG_TIMESTAMP="20260101_000000", **(env_extra or {}))
     r = subprocess.run([sys.executable, "-m", mod] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return r.stdout
+    return r.stdout + (r.stderr if mod.endswith("stage0_lama") else "")        # stage 0 logs through `logging` (stderr)
 
 
 def test_three_stages_on_mini_dataset(gpu, tmp_path):
@@ -27,18 +27,23 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
     for i in range(8):
         Image.fromarray(rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)).save(root / "retrieval" / "coco" / "train2017" / f"{i:06d}.jpg")
     ds = "ArTaxOr"
-    (root / "lamainpaint" / ds / "1_shot").mkdir(parents=True)
+    (root / "lama_inpaint").mkdir()
     (root / "datasets" / ds / "annotations").mkdir(parents=True)
     (root / "datasets" / ds / "train").mkdir(parents=True)
     images, anns = [], []
     for i, name in enumerate(["beetle_01", "moth_02"]):
         arr = rng.integers(0, 256, (48, 72, 3), dtype=np.uint8)
-        Image.fromarray(arr).save(root / "lamainpaint" / ds / "1_shot" / f"{name}.jpg")
         Image.fromarray(arr).save(root / "datasets" / ds / "train" / f"{name}.jpg")
         images.append({"id": i + 1, "file_name": f"{name}.jpg", "width": 72, "height": 48})
         anns.append({"id": i + 1, "image_id": i + 1, "bbox": [10 + i, 8, 20, 16], "category_id": 1})
     json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "Coleoptera"}]},
               open(root / "datasets" / ds / "annotations" / "1_shot.json", "w"))
+
+    # ---- stage 0 (run from ./lama_inpaint like inapint.sh): the object-free k-shot images stages 1 and 2 read
+    out0 = _run("domain_rag_amd.cli.stage0_lama", ["--datasets", ds, "--shots", "1", "--synthetic-weights", "--tiny"], cwd=root / "lama_inpaint")
+    assert "成功处理 2 个图像, 错误 0 个" in out0
+    for name in ("beetle_01", "moth_02"):
+        assert Image.open(root / "lamainpaint" / ds / "1_shot" / f"{name}.jpg").size == (72, 48)
 
     # ---- stage 1 (run from ./retrieval like domainrag.sh)
     _run("domain_rag_amd.cli.stage1_retrieval", ["--datasets", ds, "--shots", "1", "--coco-dir", "./coco", "--clip-top-k", "6",
