@@ -18,7 +18,6 @@
 
 namespace {
 
-constexpr int CT_M = 64, CT_N = 64;
 
 struct ConvK {
   drag_conv2d_f32_args a;
@@ -44,52 +43,66 @@ __device__ __forceinline__ bool tap_coord(int o, int k, int n_in, int stride, in
 // CT_K = input channels of one tap per step.  16 when many workgroups share a CU (they hide each other's load latency);
 // 64 for the low-resolution maps of the FFC blocks, where a CU holds one workgroup and the one-step-ahead prefetch must
 // cover the whole load latency by itself (4x the bytes in flight, 4x the MFMA work per barrier).
-template <int CT_K>
+// TM = tile edge in units of 64: 64x64 (one 32x32 accumulator per wave) or, for launches large enough to still fill the chip,
+// 128x128 (2x2 accumulators per wave: half the global / LDS bytes per flop, 4x the MFMA work per barrier).
+// Every instantiation adds the products of one output element in the same order (taps outer, channels ascending): same bits.
+template <int CT_K, int TM>
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
-  constexpr int CT_LD = CT_K + 4, NV = CT_K / 16;
-  __shared__ __attribute__((aligned(16))) float As[2][CT_M][CT_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][CT_N][CT_LD];
+  constexpr int CT_LD = CT_K + 4, NV = CT_K / 16, TILE = 64 * TM;
+  __shared__ __attribute__((aligned(16))) float As[2][TILE][CT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TILE][CT_LD];
   const drag_conv2d_f32_args& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const long long m0 = (long long)blockIdx.x * CT_M;
-  const int n0 = blockIdx.y * CT_N;
-  // loader role: one float4 of A and one of B per step
+  const long long m0 = (long long)blockIdx.x * TILE;
+  const int n0 = blockIdx.y * TILE;
+  // loader role: TM float4 of A and TM of B per 16 channels (rows lr, lr + 64)
   const int lr = tid >> 2, lk = (tid & 3) * 4;
-  const long long lm = m0 + lr;
-  const bool m_ok = lm < p.npix;
-  int ob = 0, oy = 0, ox = 0;
-  if (m_ok) {
-    ox = (int)(lm % a.Wo);
-    const long long t = lm / a.Wo;
-    oy = (int)(t % a.Ho);
-    ob = (int)(t / a.Ho);
-  }
-  const bool n_ok = n0 + lr < a.Cout;
+  bool m_ok[TM], n_ok[TM];
+  int ob[TM], oy[TM], ox[TM];
+  const float* wrow[TM];
   const int taps = a.KH * a.KW;
+#pragma unroll
+  for (int u = 0; u < TM; ++u) {
+    const long long lm = m0 + lr + 64 * u;
+    m_ok[u] = lm < p.npix;
+    ob[u] = oy[u] = ox[u] = 0;
+    if (m_ok[u]) {
+      ox[u] = (int)(lm % a.Wo);
+      const long long t = lm / a.Wo;
+      oy[u] = (int)(t % a.Ho);
+      ob[u] = (int)(t / a.Ho);
+    }
+    n_ok[u] = n0 + lr + 64 * u < a.Cout;
+    wrow[u] = a.w + (long long)(n_ok[u] ? n0 + lr + 64 * u : 0) * taps * a.Cin;
+  }
   const int kchunks = (a.Cin + CT_K - 1) / CT_K;
   const int nsteps = taps * kchunks;
-  const float* wrow = a.w + (long long)(n0 + (n_ok ? lr : 0)) * taps * a.Cin;
 
-  f32x4_t ra[NV], rb[NV];
+  f32x4_t ra[TM][NV], rb[TM][NV];
   int tap = 0, kc = 0;
-  const float* arow = nullptr;
-  bool a_ok = false;
+  const float* arow[TM];
+  bool a_ok[TM];
   auto set_tap = [&]() {
-    int iy = 0, ix = 0;
     const int ky = tap / a.KW, kx = tap - ky * a.KW;
-    a_ok = m_ok && tap_coord(oy, ky, a.Hi, a.stride, a.pad, a.pad_mode, a.transposed, iy) &&
-           tap_coord(ox, kx, a.Wi, a.stride, a.pad, a.pad_mode, a.transposed, ix);
-    arow = a.x + (((long long)ob * a.Hi + iy) * a.Wi + ix) * a.ldx;
+#pragma unroll
+    for (int u = 0; u < TM; ++u) {
+      int iy = 0, ix = 0;
+      a_ok[u] = m_ok[u] && tap_coord(oy[u], ky, a.Hi, a.stride, a.pad, a.pad_mode, a.transposed, iy) &&
+                tap_coord(ox[u], kx, a.Wi, a.stride, a.pad, a.pad_mode, a.transposed, ix);
+      arow[u] = a.x + (((long long)ob[u] * a.Hi + iy) * a.Wi + ix) * a.ldx;
+    }
   };
   auto fetch = [&]() {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int c = kc * CT_K + v * 16 + lk;
-      const bool c_ok = c < a.Cin;
-      ra[v] = (a_ok && c_ok) ? *(const f32x4_t*)(arow + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      rb[v] = (n_ok && c_ok) ? *(const f32x4_t*)(wrow + (long long)tap * a.Cin + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int u = 0; u < TM; ++u)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = kc * CT_K + v * 16 + lk;
+        const bool c_ok = c < a.Cin;
+        ra[u][v] = (a_ok[u] && c_ok) ? *(const f32x4_t*)(arow[u] + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        rb[u][v] = (n_ok[u] && c_ok) ? *(const f32x4_t*)(wrow[u] + (long long)tap * a.Cin + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
   };
   auto advance = [&]() {
     if (++kc == kchunks) {
@@ -100,15 +113,21 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      *(f32x4_t*)&As[buf][lr][v * 16 + lk] = ra[v];
-      *(f32x4_t*)&Bs[buf][lr][v * 16 + lk] = rb[v];
-    }
+    for (int u = 0; u < TM; ++u)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        *(f32x4_t*)&As[buf][lr + 64 * u][v * 16 + lk] = ra[u][v];
+        *(f32x4_t*)&Bs[buf][lr + 64 * u][v * 16 + lk] = rb[u][v];
+      }
   };
 
-  f32x16_t acc;
+  f32x16_t acc[TM][TM];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   set_tap();
   fetch();
   stash(0);
@@ -123,35 +142,49 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const float* ap = &As[buf][wm * 32 + fi][v * 16 + fk];
-      const float* bp = &Bs[buf][wn * 32 + fi][v * 16 + fk];
-      const f32x4_t a0 = *(const f32x4_t*)ap, a1 = *(const f32x4_t*)(ap + 4);
-      const f32x4_t b0 = *(const f32x4_t*)bp, b1 = *(const f32x4_t*)(bp + 4);
+      f32x4_t af[TM][2], bf[TM][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc, 0, 0, 0);
+      for (int i = 0; i < TM; ++i) {
+        const float* ap = &As[buf][(wm * TM + i) * 32 + fi][v * 16 + fk];
+        const float* bp = &Bs[buf][(wn * TM + i) * 32 + fi][v * 16 + fk];
+        af[i][0] = *(const f32x4_t*)ap; af[i][1] = *(const f32x4_t*)(ap + 4);
+        bf[i][0] = *(const f32x4_t*)bp; bf[i][1] = *(const f32x4_t*)(bp + 4);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc, 0, 0, 0);
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TM; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][h][j], bf[n][h][j], acc[i][n], 0, 0, 0);
     }
     if (more) stash(buf ^ 1);
     __syncthreads();
   }
 
-  // epilogue: lane owns output channel co and 16 pixel rows of the wave's 32x32 block
-  const int co = n0 + wn * 32 + (lane & 31);
-  if (co >= a.Cout) return;
-  const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
+  // epilogue: per 32x32 block a lane owns one output channel and 16 pixel rows
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const long long m = m0 + wm * 32 + (lane >> 5) * 4 + 8 * (r >> 2) + (r & 3);
-    if (m >= p.npix) continue;
-    float v = acc[r];
-    if (a.addend) v += a.addend[m * a.ld_add + co];
-    v = v * sc + sh;
-    if (a.act == DRAG_CONV_ACT_RELU) v = fmaxf(v, 0.f);
-    else if (a.act == DRAG_CONV_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-    else if (a.act == DRAG_CONV_ACT_QUICK_GELU) v = v * (1.0f / (1.0f + expf(-1.702f * v)));
-    if (a.resid) v += a.resid[m * a.ld_res + co];
-    a.y[m * a.ldy + co] = v;
+  for (int n = 0; n < TM; ++n) {
+    const int co = n0 + (wn * TM + n) * 32 + (lane & 31);
+    if (co >= a.Cout) continue;
+    const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + (wm * TM + i) * 32 + (lane >> 5) * 4 + 8 * (r >> 2) + (r & 3);
+        if (m >= p.npix) continue;
+        float v = acc[i][n][r];
+        if (a.addend) v += a.addend[m * a.ld_add + co];
+        v = v * sc + sh;
+        if (a.act == DRAG_CONV_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (a.act == DRAG_CONV_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        else if (a.act == DRAG_CONV_ACT_QUICK_GELU) v = v * (1.0f / (1.0f + expf(-1.702f * v)));
+        if (a.resid) v += a.resid[m * a.ld_res + co];
+        a.y[m * a.ldy + co] = v;
+      }
   }
 }
 
@@ -353,13 +386,24 @@ extern "C" int drag_conv2d_f32(const drag_conv2d_f32_args* a, void* stream) {
   ConvK k;
   k.a = *a;
   k.npix = (long long)a->B * a->Ho * a->Wo;
-  dim3 grid((unsigned)((k.npix + CT_M - 1) / CT_M), (unsigned)((a->Cout + CT_N - 1) / CT_N));
-  // same k-order per output element in both instantiations (taps outer, channels ascending inside a tap): identical bits
-  static const bool force16 = getenv("DRAG_CONV_K16") != nullptr;
-  if (a->Cin % 64 == 0 && (long long)grid.x * grid.y < 1024 && !force16)
-    hipLaunchKernelGGL(conv2d_f32_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, k);
-  else
-    hipLaunchKernelGGL(conv2d_f32_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, k);
+  // tile policy (speed only — every instantiation produces the same bits): 128x128 tiles when that still launches >= 2
+  // workgroups per CU, else 64x64 with 16-channel steps, or 64-channel steps when even those leave CUs with one workgroup
+  static const char* force = getenv("DRAG_CONV_TILE");            // "64x16" | "64x64" | "128" (tests, ablations)
+  const long long g128 = ((k.npix + 127) / 128) * ((a->Cout + 127) / 128);
+  const long long g64 = ((k.npix + 63) / 64) * ((a->Cout + 63) / 64);
+  int pick = (a->Cout >= 128 && g128 >= 512) ? 2 : ((a->Cin % 64 == 0 && g64 < 1024) ? 1 : 0);
+  if (force) pick = force[0] == '1' ? 2 : (force[3] == '6' ? 1 : 0);
+  if (pick == 1 && a->Cin % 64 != 0) pick = 0;
+  if (pick == 2) {
+    dim3 grid((unsigned)((k.npix + 127) / 128), (unsigned)((a->Cout + 127) / 128));
+    hipLaunchKernelGGL((conv2d_f32_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, k);
+  } else {
+    dim3 grid((unsigned)((k.npix + 63) / 64), (unsigned)((a->Cout + 63) / 64));
+    if (pick == 1)
+      hipLaunchKernelGGL((conv2d_f32_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    else
+      hipLaunchKernelGGL((conv2d_f32_kernel<16, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
+  }
   DRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -11,8 +11,8 @@
 //   clip_embed_ln_kernel    x[b,0] = class_embedding, x[b,1+p] = patch embedding; + positional_embedding; ln_pre
 //   layernorm_f32_kernel    one wave per row, two-pass mean / variance in fp32, affine; strided rows (ln_post reads x[:,0])
 //   attn_small_f32_kernel   softmax(q k^T / sqrt(d)) v for short sequences (T <= 64 keys, head_dim <= 64): one workgroup per
-//                           (image, head), K and V in LDS, one wave per query: lane j scores key j, wave-wide softmax, lane d
-//                           accumulates output column d
+//                           (image, head), one wave per query: lane j scores key j from its register-resident key row,
+//                           wave-wide softmax, lane d accumulates output column d from its register-resident value column
 #include "drag_common.h"
 
 namespace {
@@ -95,41 +95,43 @@ __global__ __launch_bounds__(256) void clip_embed_ln_kernel(const float* __restr
   }
 }
 
-// qkv rows [B*T, ld] with q at column h*hd, k at D + h*hd, v at 2D + h*hd; out rows [B*T, ldo] column h*hd
+// the value lane `src` holds, as a wave-uniform (scalar) operand
+__device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
+// qkv rows [B*T, ld] with q at column h*hd, k at D + h*hd, v at 2D + h*hd; out rows [B*T, ldo] column h*hd.
+// Everything a wave needs for its queries lives in registers: lane j keeps key row j (64 floats) and lane d keeps value
+// column d (64 floats, zero beyond T), loaded once per (image, head).  Per query the q element / the probability of key j is
+// made wave-uniform with v_readlane and fed to v_fmac as a scalar operand — no LDS traffic and no shuffles in the loops.
 __global__ __launch_bounds__(256) void attn_small_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int H, int hd, int ld,
                                                              int ldo, float scale) {
-  __shared__ float Ks[64][65];
-  __shared__ float Vs[64][65];
-  __shared__ float Qs[4][64];
   const int h = blockIdx.x, bi = blockIdx.y;
   const int D = H * hd;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* base = qkv + (long long)bi * T * ld + h * hd;
-  for (int i = tid; i < T * hd; i += 256) {
-    const int t = i / hd, d = i - t * hd;
-    Ks[t][d] = base[(long long)t * ld + D + d];
-    Vs[t][d] = base[(long long)t * ld + 2 * D + d];
-  }
-  __syncthreads();
-  for (int t = wave; t < T; t += 4) {
-    if (lane < hd) Qs[wave][lane] = base[(long long)t * ld + lane];
-    __builtin_amdgcn_wave_barrier();
-    float s = -INFINITY;
-    if (lane < T) {
-      float a = 0.f;
-      for (int d = 0; d < hd; ++d) a = fmaf(Qs[wave][d], Ks[lane][d], a);
-      s = a * scale;
+  float krow[64], vcol[64];
+  {
+    const float* kp = base + (long long)(lane < T ? lane : 0) * ld + D;
+#pragma unroll
+    for (int d4 = 0; d4 < 16; ++d4) {
+      const f32x4_t k4 = (lane < T && d4 * 4 < hd) ? *(const f32x4_t*)(kp + d4 * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      krow[d4 * 4] = k4[0]; krow[d4 * 4 + 1] = k4[1]; krow[d4 * 4 + 2] = k4[2]; krow[d4 * 4 + 3] = k4[3];
     }
+#pragma unroll
+    for (int j = 0; j < 64; ++j) vcol[j] = (j < T && lane < hd) ? base[(long long)j * ld + 2 * D + lane] : 0.f;
+  }
+  for (int t = wave; t < T; t += 4) {
+    const float q = lane < hd ? base[(long long)t * ld + lane] : 0.f;
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) a = fmaf(bcast(q, d), krow[d], a);
+    const float s = lane < T ? a * scale : -INFINITY;
     const float m = wave_max(s);
     const float e = lane < T ? expf(s - m) : 0.f;
     const float p = e / wave_sum(e);
     float o = 0.f;
-    for (int j = 0; j < T; ++j) {
-      const float pj = __shfl(p, j, 64);
-      if (lane < hd) o = fmaf(pj, Vs[j][lane], o);
-    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j) o = fmaf(bcast(p, j), vcol[j], o);
     if (lane < hd) out[((long long)bi * T + t) * ldo + h * hd + lane] = o;
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -177,6 +179,7 @@ extern "C" int drag_attention_small_f32(const float* qkv, float* out, int32_t B,
   DRAG_CHECK(qkv && out, "attention_small_f32: null pointer");
   DRAG_CHECK(B > 0 && B <= 65535 && H > 0 && T > 0 && T <= 64 && head_dim > 0 && head_dim <= 64, "attention_small_f32: needs T <= 64, head_dim <= 64");
   DRAG_CHECK(ld >= 3 * H * head_dim && ldo >= H * head_dim, "attention_small_f32: row strides");
+  DRAG_CHECK(head_dim % 4 == 0 && ld % 4 == 0 && ((uintptr_t)qkv & 15) == 0, "attention_small_f32: head_dim and row stride must be multiples of 4 floats");
   hipLaunchKernelGGL(attn_small_f32_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, qkv, out, T, H, head_dim, ld, ldo, scale);
   DRAG_LAUNCH_CHECK();
   return 0;

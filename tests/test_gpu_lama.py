@@ -254,19 +254,22 @@ def test_reference_style_import_through_compat(gpu, monkeypatch):
                 sys.modules[k] = v
 
 
-def test_conv_k_step_variants_give_the_same_bits(gpu):
-    """the conv picks a 64-channel K-step when few workgroups are launched and a 16-channel one otherwise; both walk the taps
-    and channels in the same order, so a pixel's value must not depend on how many images share the launch"""
+def test_conv_tile_variants_give_the_same_bits(gpu):
+    """the conv picks its tile by launch size (64x64 with 64-channel steps for a handful of workgroups, 64x64 with 16-channel
+    steps, 128x128 for big launches with >= 128 output channels); all walk the taps and channels in the same order, so a
+    pixel's value must not depend on how many images share the launch"""
     from domain_rag_amd import ops
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 16, 16, 128, generator=g).to(gpu)
-    w = (torch.randn(64, 3, 3, 128, generator=g) * 0.1).to(gpu)
-    y1 = torch.empty(1, 16, 16, 64, device=gpu)
-    geo = dict(Hi=16, Wi=16, Ho=16, Wo=16, Cin=128, ldx=128, ldy=64, pad=1, pad_mode=ops.PAD_REFLECT)
-    ops.conv2d_f32(x, w, y1, B=1, **geo)                                 # 4 workgroups -> 64-channel steps
+    geo = dict(Hi=16, Wi=16, Ho=16, Wo=16, Cin=128, ldx=128, pad=1, pad_mode=ops.PAD_REFLECT)
     xb = x.expand(300, 16, 16, 128).contiguous()
-    yb = torch.empty(300, 16, 16, 64, device=gpu)
-    ops.conv2d_f32(xb, w, yb, B=300, **geo)                              # 1200 workgroups -> 16-channel steps
-    assert torch.equal(yb[0], y1[0]) and torch.equal(yb[299], y1[0])
-    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2), (1,) * 4, mode="reflect"), w.permute(0, 3, 1, 2))
-    assert (y1.permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    for cout in (64, 160):          # 64: 4 workgroups (64-ch steps) vs 1200 (16-ch steps); 160: 12 (64-ch steps) vs 600x2 tiles of 128x128
+        w = (torch.randn(cout, 3, 3, 128, generator=g) * 0.1).to(gpu)
+        sc, sh = torch.randn(cout, generator=g).to(gpu), torch.randn(cout, generator=g).to(gpu)
+        y1 = torch.empty(1, 16, 16, cout, device=gpu)
+        ops.conv2d_f32(x, w, y1, B=1, ldy=cout, scale=sc, shift=sh, act=ops.CONV_ACT_RELU, **geo)
+        yb = torch.empty(300, 16, 16, cout, device=gpu)
+        ops.conv2d_f32(xb, w, yb, B=300, ldy=cout, scale=sc, shift=sh, act=ops.CONV_ACT_RELU, **geo)
+        assert torch.equal(yb[0], y1[0]) and torch.equal(yb[299], y1[0]) and torch.equal(yb[150], y1[0])
+        ref = F.relu(F.conv2d(F.pad(x.permute(0, 3, 1, 2), (1,) * 4, mode="reflect"), w.permute(0, 3, 1, 2)) * sc[None, :, None, None] + sh[None, :, None, None])
+        assert (y1.permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5 * ref.abs().max().item()

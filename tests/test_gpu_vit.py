@@ -145,3 +145,18 @@ def test_load_clip_precision_switch(gpu, monkeypatch):
     assert _rel(b, a) < 3e-2
     with pytest.raises(ValueError):
         R.load_clip("ViT-B/32", device=gpu, precision="fp16")
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(5, 10, 2, 64), (3, 50, 12, 64), (2, 64, 2, 32), (1, 1, 1, 64), (2, 17, 3, 48)])
+def test_attention_small_f32_vs_torch(gpu, B, T, H, hd):
+    import math
+    from domain_rag_amd import ops
+    D = H * hd
+    qkv = torch.randn(B * T, 3 * D, generator=torch.Generator().manual_seed(T)).to(gpu)
+    out = torch.full((B * T, D + 4), 9.0, device=gpu)
+    ops.attention_small_f32(qkv, out, B, T, H, hd, 3 * D, D + 4, 1 / math.sqrt(hd))
+    q, k, v = (qkv[:, i * D:(i + 1) * D].view(B, T, H, hd).permute(0, 2, 1, 3).double() for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ v).permute(0, 2, 1, 3).reshape(B * T, D)
+    assert (out[:, :D].double() - ref).abs().max().item() < 2e-6 and torch.all(out[:, D:] == 9.0)
+    with pytest.raises(RuntimeError, match="T <= 64"):
+        ops.attention_small_f32(qkv, out, 1, 65, 1, 64, 192, 64, 1.0)
