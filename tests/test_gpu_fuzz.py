@@ -109,3 +109,84 @@ def test_topk_random(gpu):
         D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(queries).to(gpu), k)
         Do, Io = oret.cosine_topk(corpus, queries, k)
         assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy(), Do), (case, N, d, Q, k)
+
+
+def test_conv2d_f32_random_geometry(gpu):
+    """float32 implicit-GEMM conv vs torch over random kernel sizes, strides, paddings, channel slices and epilogues
+    (tolerance 3e-5 of the output scale: accumulation order only)"""
+    import torch.nn.functional as F
+    from domain_rag_amd import ops
+    rng = np.random.default_rng(77)
+    g = torch.Generator().manual_seed(5)
+    for case in range(48):
+        k = int(rng.choice([1, 3, 5, 7]))
+        stride = int(rng.choice([1, 1, 2, 3]))
+        transposed = bool(k == 3 and stride == 2 and rng.random() < 0.6)
+        mode = "zero" if transposed else str(rng.choice(["zero", "reflect"]))
+        pad = int(rng.integers(0, k // 2 + 1)) if not transposed else 1
+        B = int(rng.integers(1, 4))
+        H, W = (int(rng.integers(max(pad + 1, k), 40)) for _ in range(2))
+        Cin = 4 * int(rng.integers(1, 40))
+        Cout = int(rng.choice([1, 3, 31, 32, 33, 64, 65, 100, 128, 130, 200]))
+        x = torch.randn(B, Cin, H, W, generator=g)
+        if transposed:
+            w = torch.randn(Cin, Cout, k, k, generator=g) * 0.1
+            ref = F.conv_transpose2d(x, w, stride=stride, padding=pad, output_padding=stride - 1)
+            wk = w.permute(1, 2, 3, 0).contiguous()
+        else:
+            w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+            xp = F.pad(x, (pad,) * 4, mode="reflect") if (mode == "reflect" and pad) else F.pad(x, (pad,) * 4)
+            ref = F.conv2d(xp, w, stride=stride)
+            wk = w.permute(0, 2, 3, 1).contiguous()
+        Ho, Wo = ref.shape[2:]
+        use = {n: bool(rng.random() < 0.5) for n in ("scale", "shift", "addend", "resid")}
+        act = int(rng.choice([0, 1, 2, 3]))
+        scale, shift = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+        addend, resid = torch.randn(B, Ho, Wo, Cout + 3, generator=g), torch.randn(B, Ho, Wo, Cout + 1, generator=g)
+        want = ref.permute(0, 2, 3, 1)
+        if use["addend"]:
+            want = want + addend[..., :Cout]
+        if use["scale"]:
+            want = want * scale
+        if use["shift"]:
+            want = want + shift
+        want = [want, F.relu(want), torch.sigmoid(want), want * torch.sigmoid(1.702 * want)][act]
+        if use["resid"]:
+            want = want + resid[..., :Cout]
+        off = 4 * int(rng.integers(0, 3))
+        ldx = Cin + off + 4 * int(rng.integers(0, 3))
+        xb = torch.randn(B, H, W, ldx, generator=g)
+        xb[..., off:off + Cin] = x.permute(0, 2, 3, 1)
+        yo = int(rng.integers(0, 5))
+        ldy = Cout + yo + int(rng.integers(0, 4))
+        yd = torch.full((B, Ho, Wo, ldy), 5.0, device=gpu)
+        ops.conv2d_f32(xb.to(gpu).view(-1)[off:], wk.to(gpu), yd.view(-1)[yo:], B=B, Hi=H, Wi=W, Ho=Ho, Wo=Wo, Cin=Cin, ldx=ldx, ldy=ldy,
+                       stride=stride, pad=pad, pad_mode=ops.PAD_REFLECT if mode == "reflect" else ops.PAD_ZERO, transposed=transposed, act=act,
+                       scale=scale.to(gpu) if use["scale"] else None, shift=shift.to(gpu) if use["shift"] else None,
+                       addend=addend.to(gpu) if use["addend"] else None, ld_add=Cout + 3,
+                       resid=resid.to(gpu) if use["resid"] else None, ld_res=Cout + 1)
+        got = yd.cpu()
+        desc = (case, k, stride, pad, mode, transposed, B, H, W, Cin, Cout, act, use)
+        assert torch.all(got[..., :yo] == 5.0) and torch.all(got[..., yo + Cout:] == 5.0), desc
+        err = (got[..., yo:yo + Cout] - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        assert err < 3e-5, (err, desc)
+
+
+def test_rfft2_random_sizes_roundtrip_and_reference(gpu):
+    from domain_rag_amd import lama, ops
+    rng = np.random.default_rng(3)
+    g = torch.Generator().manual_seed(8)
+    for case in range(16):
+        B, H, W, C = int(rng.integers(1, 3)), int(rng.integers(1, 90)), int(rng.integers(1, 90)), 4 * int(rng.integers(1, 20))
+        Wf = W // 2 + 1
+        x = torch.randn(B, H, W, C, generator=g)
+        tw_w, tw_h = lama._twiddles(W, gpu), lama._twiddles(H, gpu)
+        tmp, f = torch.empty(B, H, Wf, 2 * C, device=gpu), torch.empty(B, H, Wf, 2 * C, device=gpu)
+        xd = x.to(gpu)
+        ops.rfft2_f32(xd, tmp, f, B, H, W, C, C, tw_w, tw_h)
+        ref = torch.fft.rfftn(x.permute(0, 3, 1, 2).double(), dim=(-2, -1), norm="ortho")
+        ref_il = torch.stack((ref.real, ref.imag), dim=-1).permute(0, 2, 3, 1, 4).reshape(B, H, Wf, 2 * C)
+        assert (f.cpu().double() - ref_il).abs().max().item() < 3e-5 * ref_il.abs().max().item(), (B, H, W, C)
+        back = torch.empty(B, H, W, C, device=gpu)
+        ops.irfft2_f32(f, tmp, back, None, B, H, W, C, C, 0, tw_w, tw_h)
+        assert (back.cpu() - x).abs().max().item() < 3e-5 * x.abs().max().item(), (B, H, W, C)     # irfft2(rfft2(x)) == x
