@@ -117,3 +117,101 @@ class ImageWriter:
         ws, self._w = self._w, []
         for w in ws:
             w.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# corpus decoding for stage 1: JPEG decode + CLIP's Resize(224, BICUBIC) + CenterCrop(224) in worker processes.
+# The reference does this on one CPU thread, one image per model call (retrieval/…:270-287); a thread pool scales poorly
+# (the main thread still pays one upload + resize launch per image).  Workers return the 224x224x3 uint8 crop (150 KB), the
+# parent only stacks batches.  The crop is PIL's own BICUBIC — the bytes the GPU resample kernel reproduces — so the
+# embeddings do not depend on which route an image took.
+# ---------------------------------------------------------------------------------------------------------------------
+_DECODER = r"""
+import pickle, sys
+from PIL import Image
+inp, out = sys.stdin.buffer, sys.stdout.buffer
+size = int(sys.argv[1])
+while True:
+    try:
+        idx, path = pickle.load(inp)
+    except EOFError:
+        break
+    try:
+        img = Image.open(path).convert("RGB")
+        w, h = img.size
+        nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)       # torchvision Resize(int) truncates
+        img = img.resize((nw, nh), Image.BICUBIC)
+        left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+        msg = (idx, True, img.crop((left, top, left + size, top + size)).tobytes())
+    except Exception as e:
+        msg = (idx, False, str(e))
+    pickle.dump(msg, out, protocol=pickle.HIGHEST_PROTOCOL); out.flush()
+"""
+
+
+class ClipDecodePool:
+    """``for idx, ok, payload in pool.run(paths)``: payload = bytes of the uint8 [size,size,3] crop, or the error text.
+    Results come back in path order; ``ahead`` bounds the images in flight per worker."""
+
+    def __init__(self, workers: int, size: int = 224, ahead: int = 8):
+        self.size, self.ahead = size, ahead
+        self.procs = [subprocess.Popen([sys.executable, "-c", _DECODER, str(size)], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+                      for _ in range(max(1, workers))]
+
+    def run(self, paths):
+        n, W = len(paths), len(self.procs)
+        # image k goes to worker k % W; each worker answers in order
+        results: dict = {}
+        lock = threading.Lock()
+        have = threading.Condition(lock)
+        taken = [0]                                      # images the consumer has already been handed
+
+        def feed(wi):                                    # one feeder + one reader thread per worker (blocking pipe I/O)
+            p = self.procs[wi]
+            for k in range(wi, n, W):
+                with have:
+                    while k - taken[0] > self.ahead * W:
+                        have.wait()
+                try:
+                    pickle.dump((k, paths[k]), p.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+                    p.stdin.flush()
+                except Exception:                        # worker gone: its reader reports the remaining images as failed
+                    return
+
+        def read(wi):
+            p = self.procs[wi]
+            for _ in range(wi, n, W):
+                try:
+                    msg = pickle.load(p.stdout)
+                except Exception as e:                   # worker died: fail its remaining images, keep the run going
+                    with have:
+                        for k in range(wi, n, W):
+                            results.setdefault(k, (k, False, f"decoder process failed: {e!r}"))
+                        have.notify_all()
+                    return
+                with have:
+                    results[msg[0]] = msg
+                    have.notify_all()
+
+        threads = [threading.Thread(target=f, args=(wi,), daemon=True) for wi in range(W) for f in (feed, read)]
+        for t in threads:
+            t.start()
+        for k in range(n):
+            with have:
+                while k not in results:
+                    have.wait()
+                msg = results.pop(k)
+                taken[0] = k + 1
+                have.notify_all()
+            yield msg
+        for t in threads:
+            t.join(timeout=5)
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+        self.procs = []

@@ -327,11 +327,14 @@ def allgather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tenso
     return torch.cat(parts, 0)
 
 
-def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list[str], batch: int = 256, decode_workers: int | None = None):
+def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list[str], batch: int = 256, decode_workers: int | None = None,
+                            decode_procs: int = 0):
     """compute_coco_clip_features (ref :236-298), batched and rank-sharded.  Returns (features float32 [n,512]
     numpy in path order, valid_paths).  Unreadable images are skipped like the reference (:290-292).
-    File decoding (PIL releases the GIL while it decodes) runs ``decode_workers`` images ahead on a thread pool; the
-    GPU work (resize when ``preprocess`` is the device one, embedding) stays on this thread, in path order."""
+    ``decode_procs`` > 0: JPEG decode + CLIP's bicubic resize / centre crop run in that many worker processes
+    (io_pool.ClipDecodePool; PIL's own resize — the bytes the GPU resample kernel reproduces, so the embeddings are the same)
+    and this thread only stacks uint8 batches.  Otherwise file decoding runs ``decode_workers`` images ahead on a thread pool
+    and ``preprocess`` (host PIL, or the device resize) is applied here, in path order."""
     import collections
     import concurrent.futures as cf
     import os as _os
@@ -357,23 +360,39 @@ def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list
         img.load()
         return img
 
-    workers = decode_workers if decode_workers is not None else min(16, _os.cpu_count() or 1)
     mine = image_paths[s:e]
-    with cf.ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
-        pending: collections.deque = collections.deque()
-        nxt = 0
-        for j, p in enumerate(mine):
-            while nxt < len(mine) and len(pending) < 4 * max(1, workers):
-                pending.append(pool.submit(decode, mine[nxt])); nxt += 1
-            fut = pending.popleft()
-            try:
-                buf.append(preprocess(fut.result()))
+    if decode_procs > 0:
+        from .io_pool import ClipDecodePool
+        pool = ClipDecodePool(decode_procs, 224)
+        try:
+            for j, good, payload in pool.run([clean_image_path(p) for p in mine]):
+                if not good:
+                    print(f"处理图像 {mine[j]} 时出错: {payload}")
+                    continue
+                buf.append(torch.frombuffer(bytearray(payload), dtype=torch.uint8).view(224, 224, 3))
                 idxs.append(j)
-            except Exception as ex:
-                print(f"处理图像 {p} 时出错: {ex}")
-            if len(buf) == batch:
-                flush()
-    flush()
+                if len(buf) == batch:
+                    flush()
+        finally:
+            pool.close()
+        flush()
+    else:
+        workers = decode_workers if decode_workers is not None else min(16, _os.cpu_count() or 1)
+        with cf.ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            pending: collections.deque = collections.deque()
+            nxt = 0
+            for j, p in enumerate(mine):
+                while nxt < len(mine) and len(pending) < 4 * max(1, workers):
+                    pending.append(pool.submit(decode, mine[nxt])); nxt += 1
+                fut = pending.popleft()
+                try:
+                    buf.append(preprocess(fut.result()))
+                    idxs.append(j)
+                except Exception as ex:
+                    print(f"处理图像 {p} 时出错: {ex}")
+                if len(buf) == batch:
+                    flush()
+        flush()
     allf = allgather_rows(torch.cat([feats, ok], 1), len(image_paths))
     keep = allf[:, 512] > 0.5
     valid = [p for p, k in zip(image_paths, keep.cpu().tolist()) if k]

@@ -27,6 +27,11 @@ def ref_loop(paths):
     return np.stack(out)
 ref_loop(paths[:32])
 t0 = time.perf_counter(); a = ref_loop(paths[:500]); t_ref = (time.perf_counter() - t0) / 500
+for procs in (8, 32):
+    R.compute_corpus_features(model, None, paths[:64], 256, decode_procs=procs)
+    t0 = time.perf_counter(); b, valid = R.compute_corpus_features(model, None, paths, 256, decode_procs=procs); t_new = (time.perf_counter() - t0) / N
+    print(f"decode_procs={procs}: {1/t_new:.0f} img/s ({t_new*1e3:.2f} ms/img) vs reference-shaped loop {1/t_ref:.0f} img/s: {t_ref/t_new:.1f}x; "
+          f"embeddings bit-identical: {np.array_equal(a, b[:500])}", flush=True)
 for workers in (1, 16):
     R.compute_corpus_features(model, R.load_clip_device_preprocess(dev), paths[:64], 256, decode_workers=workers)
     t0 = time.perf_counter(); b, valid = R.compute_corpus_features(model, R.load_clip_device_preprocess(dev), paths, 256, decode_workers=workers); t_new = (time.perf_counter() - t0) / N

@@ -89,3 +89,25 @@ def test_first_stage_plumbing_matches_reference(gpu):
     assert R.clip_first_stage_retrieval(q, feats, gg["paths"], top_k=100, device=gpu) == gg["out_k100"]
     assert R.clip_first_stage_retrieval(q, feats, gg["paths"], top_k=3, device=gpu) == gg["out_k3"]
     assert R.clip_first_stage_retrieval(q, {"none": None}, {"none": None}, top_k=3, device=gpu) == gg["out_nothing"]
+
+
+def test_corpus_features_same_bits_through_decode_processes(gpu, tmp_path):
+    """thread-pool decode + GPU resize, thread-pool decode + host preprocess, and worker-process decode + PIL resize must give
+    the same embeddings, skip the same unreadable files and keep the path order"""
+    import numpy as np
+    from PIL import Image
+    from domain_rag_amd import retrieval as R
+    rng = np.random.default_rng(4)
+    paths = []
+    for i, (h, w) in enumerate([(480, 640), (640, 480), (224, 224), (225, 300), (97, 61), (333, 777)] * 4):
+        p = tmp_path / f"{i:03d}.jpg"
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p, quality=92)
+        paths.append(str(p))
+    (tmp_path / "bad.jpg").write_bytes(b"junk")
+    paths.insert(7, str(tmp_path / "bad.jpg"))
+    model, host_pre = R.load_clip("ViT-B/32", device=gpu)
+    a, va = R.compute_corpus_features(model, R.load_clip_device_preprocess(gpu), paths, batch=16, decode_workers=4)
+    b, vb = R.compute_corpus_features(model, host_pre, paths, batch=5, decode_workers=2)
+    c, vc = R.compute_corpus_features(model, None, paths, batch=7, decode_procs=3)
+    assert va == vb == vc == [p for p in paths if "bad" not in p] and a.shape == (24, 512)
+    assert np.array_equal(a, b) and np.array_equal(a, c)

@@ -70,3 +70,43 @@ def test_inline_mode_and_returns_before_the_encode(tmp_path):
         assert (tmp_path / "bg.png").read_bytes() == (tmp_path / "ref.png").read_bytes()
     finally:
         w.close()
+
+
+def test_clip_decode_pool_matches_host_preprocess(tmp_path):
+    """worker processes return exactly the uint8 crop the host-side clip preprocess resizes to, in path order; unreadable
+    files come back as failures at their position"""
+    import torch
+    from domain_rag_amd import retrieval as R
+    from domain_rag_amd.io_pool import ClipDecodePool
+    rng = np.random.default_rng(2)
+    paths = []
+    for i, (h, w) in enumerate([(480, 640), (640, 480), (224, 224), (225, 300), (300, 224), (97, 61), (1000, 224), (333, 777)] * 3):
+        p = tmp_path / f"{i:03d}.{'png' if i % 3 else 'jpg'}"
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+    paths.insert(5, str(tmp_path / "missing.jpg"))
+    (tmp_path / "broken.jpg").write_bytes(b"not an image")
+    paths.insert(11, str(tmp_path / "broken.jpg"))
+    gray = tmp_path / "gray.png"
+    Image.fromarray(rng.integers(0, 256, (260, 310), dtype=np.uint8)).save(gray)       # L mode -> convert("RGB")
+    paths.append(str(gray))
+    pool = ClipDecodePool(3)
+    try:
+        got = list(pool.run(paths))
+    finally:
+        pool.close()
+    assert [g[0] for g in got] == list(range(len(paths)))
+    for (k, ok, payload), p in zip(got, paths):
+        if "missing" in p or "broken" in p:
+            assert not ok and isinstance(payload, str) and payload
+            continue
+        assert ok and len(payload) == 224 * 224 * 3
+        x = R.clip_preprocess(Image.open(p))                                       # float CHW, normalised
+        u8 = torch.frombuffer(bytearray(payload), dtype=torch.uint8).view(224, 224, 3)
+        back = ((u8.float().div(255.0) - torch.tensor(R.CLIP_MEAN)) / torch.tensor(R.CLIP_STD)).permute(2, 0, 1)
+        assert torch.equal(back, x), p
+    pool2 = ClipDecodePool(2)
+    try:
+        assert list(pool2.run([])) == []
+    finally:
+        pool2.close()
