@@ -160,50 +160,34 @@ class ClipDecodePool:
 
     def run(self, paths):
         n, W = len(paths), len(self.procs)
-        # image k goes to worker k % W; each worker answers in order
-        results: dict = {}
-        lock = threading.Lock()
-        have = threading.Condition(lock)
-        taken = [0]                                      # images the consumer has already been handed
+        # image k goes to worker k % W and each worker answers in order, so the consumer reads the W bounded result queues
+        # round-robin; back-pressure is the queue bound -> the reader stops reading -> the worker blocks on its stdout pipe
+        outq = [queue.Queue(maxsize=self.ahead) for _ in range(W)]
 
-        def feed(wi):                                    # one feeder + one reader thread per worker (blocking pipe I/O)
+        def feed(wi):                                    # blocking pipe writes (tiny messages)
             p = self.procs[wi]
-            for k in range(wi, n, W):
-                with have:
-                    while k - taken[0] > self.ahead * W:
-                        have.wait()
-                try:
+            try:
+                for k in range(wi, n, W):
                     pickle.dump((k, paths[k]), p.stdin, protocol=pickle.HIGHEST_PROTOCOL)
                     p.stdin.flush()
-                except Exception:                        # worker gone: its reader reports the remaining images as failed
-                    return
+            except Exception:                            # worker gone: its reader reports the remaining images as failed
+                return
 
         def read(wi):
             p = self.procs[wi]
-            for _ in range(wi, n, W):
+            for k in range(wi, n, W):
                 try:
                     msg = pickle.load(p.stdout)
                 except Exception as e:                   # worker died: fail its remaining images, keep the run going
-                    with have:
-                        for k in range(wi, n, W):
-                            results.setdefault(k, (k, False, f"decoder process failed: {e!r}"))
-                        have.notify_all()
-                    return
-                with have:
-                    results[msg[0]] = msg
-                    have.notify_all()
+                    msg = (k, False, f"decoder process failed: {e!r}")
+                outq[wi].put(msg)
 
         threads = [threading.Thread(target=f, args=(wi,), daemon=True) for wi in range(W) for f in (feed, read)]
         for t in threads:
             t.start()
         for k in range(n):
-            with have:
-                while k not in results:
-                    have.wait()
-                msg = results.pop(k)
-                taken[0] = k + 1
-                have.notify_all()
-            yield msg
+            msg = outq[k % W].get()
+            yield (k, msg[1], msg[2])
         for t in threads:
             t.join(timeout=5)
 
