@@ -363,19 +363,41 @@ def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list
     mine = image_paths[s:e]
     if decode_procs > 0:
         from .io_pool import ClipDecodePool
+        # batches are assembled with plain memcpys into two pinned staging buffers (torch.stack of 256 CPU tensors spins up
+        # the whole OpenMP pool on a many-core host and starves the decoders: 6.4 k -> 1.1 k img/s) and uploaded asynchronously
+        pin = [torch.empty((batch, 224, 224, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        pin_np = [t.numpy() for t in pin]
+        busy = [None, None]
+        cur, fill, rows = 0, 0, []
+
+        def launch(n):
+            x = pin[cur][:n].to(model.device, non_blocking=True)
+            emb = model.embed_normalized(x)
+            ii = torch.tensor(rows, device=model.device)
+            feats[ii] = emb
+            ok[ii] = 1.0
+            busy[cur] = torch.cuda.Event()
+            busy[cur].record()
+
         pool = ClipDecodePool(decode_procs, 224)
         try:
             for j, good, payload in pool.run([clean_image_path(p) for p in mine]):
                 if not good:
                     print(f"处理图像 {mine[j]} 时出错: {payload}")
                     continue
-                buf.append(torch.frombuffer(bytearray(payload), dtype=torch.uint8).view(224, 224, 3))
-                idxs.append(j)
-                if len(buf) == batch:
-                    flush()
+                pin_np[cur][fill] = np.frombuffer(payload, dtype=np.uint8).reshape(224, 224, 3)
+                rows.append(j)
+                fill += 1
+                if fill == batch:
+                    launch(fill)
+                    cur, fill, rows = cur ^ 1, 0, []
+                    if busy[cur] is not None:
+                        busy[cur].synchronize()          # the upload that last used this staging buffer has finished
         finally:
             pool.close()
-        flush()
+        if fill:
+            launch(fill)
+        torch.cuda.synchronize()
     else:
         workers = decode_workers if decode_workers is not None else min(16, _os.cpu_count() or 1)
         with cf.ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
