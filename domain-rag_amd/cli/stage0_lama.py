@@ -17,8 +17,6 @@ import time
 from collections import defaultdict
 from datetime import datetime
 
-import numpy as np
-
 from .. import hostlogic as H
 
 

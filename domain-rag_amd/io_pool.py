@@ -1,4 +1,5 @@
-"""Background PNG / JPEG encoding for the stage CLIs.
+"""Image I/O off the generation thread for the stage CLIs: background PNG / JPEG encoding (ImageWriter) and corpus decoding
+(ClipDecodePool, below).
 
 A 1365x1024 PNG costs ~0.3 s of zlib on one core and Pillow holds the GIL while it runs, so the reference's pattern —
 generate, ``image.save(...)``, generate — leaves the GPU idle for 10–35 % of a stage-3 sample (2 large PNGs per composite,
@@ -91,7 +92,6 @@ class ImageWriter:
         self.n, self.depth = max(0, int(workers)), depth
         self._w: list[_Worker] = []
         self._next = 0
-        self._inline_errors: list = []
         atexit.register(self.close)
 
     def save(self, image, path: str, **kw) -> None:
