@@ -369,7 +369,12 @@ extern "C" int drag_conv2d_f32(const drag_conv2d_f32_args* a, void* stream) {
   DRAG_CHECK(a->B > 0 && a->Ho > 0 && a->Wo > 0 && a->Hi > 0 && a->Wi > 0 && a->Cin > 0 && a->Cout > 0, "conv2d_f32: empty shape");
   DRAG_CHECK(a->Cin % 4 == 0 && a->ldx % 4 == 0 && ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->w & 15) == 0,
              "conv2d_f32: input channels and pixel stride must be multiples of 4 floats, pointers 16-byte aligned");
-  DRAG_CHECK(a->ldx >= a->Cin && a->ldy >= a->Cout, "conv2d_f32: pixel stride smaller than the channel count");
+  // ldx < Cin = "packed row" reads: a pixel's Cin floats run on into its right-hand neighbours (KW taps x channels of an NHWC
+  // row are contiguous), which turns a KH x KW x C kernel into KH x 1 x (KW*C) with no padded channel groups; the caller
+  // guarantees the last read of a row stays inside it
+  const bool packed_row = a->ldx < a->Cin && a->KW == 1 && a->pad == 0 && !a->transposed &&
+                          (long long)(a->Wo - 1) * a->stride * a->ldx + a->Cin <= (long long)a->Wi * a->ldx;
+  DRAG_CHECK((a->ldx >= a->Cin || packed_row) && a->ldy >= a->Cout, "conv2d_f32: pixel stride smaller than the channel count");
   DRAG_CHECK(a->KH >= 1 && a->KW >= 1 && a->stride >= 1 && a->pad >= 0, "conv2d_f32: bad kernel geometry");
   DRAG_CHECK(a->pad_mode == DRAG_PAD_ZERO || a->pad_mode == DRAG_PAD_REFLECT, "conv2d_f32: unknown padding mode");
   DRAG_CHECK(!(a->transposed && a->pad_mode == DRAG_PAD_REFLECT), "conv2d_f32: a transposed convolution pads with zeros");

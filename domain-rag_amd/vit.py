@@ -260,7 +260,8 @@ class ClipVitF32HIP:
 
         wp = torch.zeros((D, P, P, 4), dtype=torch.float32, device=self.dev)          # conv1.weight [D,3,P,P] -> [D,P,P,4]
         wp[..., :3] = dv(g["patch.weight"]).view(D, 3, P, P).permute(0, 2, 3, 1)
-        self.w_patch = wp
+        # the P pixels x 4 channels of a patch row are contiguous in the NHWC frame: a P x 1 kernel over 4P "channels"
+        self.w_patch = wp.view(D, P, 1, 4 * P)
         self.cls, self.pos = dv(g["cls"]), dv(g["pos"])
         self.ln_pre = (dv(g["ln_pre.weight"]), dv(g["ln_pre.bias"]))
         self.ln_post = (dv(g["ln_post.weight"]), dv(g["ln_post.bias"]))
@@ -300,7 +301,7 @@ class ClipVitF32HIP:
         x, nrm, qkv, att, hid = ws["x"], ws["nrm"], ws["qkv"], ws["att"], ws["hid"]
         ops.vit_prepare(img.contiguous() if img.dtype == torch.uint8 else img.float().contiguous(), ws["frame"], cfg.mean, cfg.std)
         gp = S // P
-        ops.conv2d_f32(ws["frame"], self.w_patch, ws["emb"], B=B, Hi=S, Wi=S, Ho=gp, Wo=gp, Cin=4, ldx=4, ldy=D, stride=P)
+        ops.conv2d_f32(ws["frame"], self.w_patch, ws["emb"], B=B, Hi=S, Wi=S, Ho=gp, Wo=gp, Cin=4 * P, ldx=4, ldy=D, stride=P)
         ops.clip_embed_ln(ws["emb"], self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], x, B, T, D, cfg.ln_eps)
         M = B * T
         scale = 1.0 / math.sqrt(self.hd)

@@ -250,7 +250,9 @@ int drag_scale_noise_rows_bf16(void* x, const void* noise, int64_t rows, int32_t
 #define DRAG_CONV_ACT_SIGMOID 2
 #define DRAG_CONV_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x), openai-CLIP's QuickGELU */
 typedef struct drag_conv2d_f32_args {
-  const float* x;      /* NHWC [B, Hi, Wi, ldx]; the Cin channels read start at x (pre-offset the pointer for a channel slice) */
+  const float* x;      /* NHWC [B, Hi, Wi, ldx]; the Cin channels read start at x (pre-offset the pointer for a channel slice).
+                          ldx < Cin is allowed for KW = 1, pad = 0: the read runs on into the next pixels of the row ("packed row":
+                          a KH x KW x C kernel given as KH x 1 x (KW*C)) */
   const float* w;      /* [Cout, KH, KW, Cin] (nn.Conv2d weight permuted 0,2,3,1; nn.ConvTranspose2d weight permuted 1,2,3,0) */
   float* y;            /* NHWC [B, Ho, Wo, ldy], Cout channels written from y */
   const float* scale;  /* [Cout] or NULL (= 1): eval-mode BatchNorm gamma / sqrt(var + eps) */
