@@ -146,3 +146,35 @@ def test_stage3_background_writer_matches_inline_files(gpu, tmp_path):
     for f in pngs:
         assert (da / f).read_bytes() == (db / f).read_bytes(), f
     assert len(list((root / "final_results" / "process_b" / "1_shot" / ds / "1_shot").glob("*_final_result*.png"))) == 2
+
+
+def test_stage3_downscale_branch(gpu, tmp_path):
+    """an original wider than the 2800-px cap: processed at 2800 wide, composited, scaled back up (outpainting_…:403-458,480-498);
+    the params / manifest record the down-scale and no *_upscaled_bg.png is written"""
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    root = tmp_path
+    ds, name = "DIOR", "wide_1"
+    (root / "datasets" / ds / "annotations").mkdir(parents=True); (root / "datasets" / ds / "train").mkdir(parents=True)
+    W, H = 2900, 420
+    Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(root / "datasets" / ds / "train" / f"{name}.jpg")
+    json.dump({"images": [{"id": 1, "file_name": f"{name}.jpg", "width": W, "height": H}],
+               "annotations": [{"id": 1, "image_id": 1, "bbox": [1000, 100, 600, 200], "category_id": 1}], "categories": [{"id": 1, "name": "ship"}]},
+              open(root / "datasets" / ds / "annotations" / "1_shot.json", "w"))
+    sdir = root / "result" / f"{ds}_1shot_retrieval" / "results_x" / name
+    sdir.mkdir(parents=True)
+    Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(sdir / "generated_image_rank1.png")
+    out = _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "d", "--dataset", ds, "--shot", "1", "--synthetic-weights", "--tiny",
+                                                       "--num_inference_steps", "2", "--seed", "5"], cwd=root)
+    assert f"样本 {name} 处理完成" in out
+    sd = root / "outpaint_hires" / "process_d" / ds / "1_shot" / name
+    pre = f"{ds}_{name}_1shot"
+    prm = json.load(open(sd / f"{pre}_params_1.json"))
+    assert prm["was_downscaled"] and not prm["was_upscaled"] and abs(prm["down_scale_factor"] - 2800 / 2900) < 1e-12
+    assert prm["processed_resolution"] == {"width": 2800, "height": int(420 * (2800 / 2900))}
+    assert prm["processed_bbox_coords_list"] == [[int(v * prm["down_scale_factor"]) for v in [1000, 100, 600, 200]]]
+    assert Image.open(sd / f"{pre}_downscaled_bg.png").size == (2800, 405) and not (sd / f"{pre}_upscaled_bg.png").exists()
+    hires = Image.open(sd / f"{pre}_hires_result_1.png").size
+    assert hires == (2800, 400)                                                   # multiples of 16 inside the Fill pipeline
+    fw, fh = Image.open(sd / f"{pre}_final_result_1.png").size                      # scaled back by 1 / down_scale_factor
+    assert abs(fw - 2900) <= 1 and abs(fh - int(400 / prm["down_scale_factor"])) <= 1
