@@ -273,3 +273,27 @@ def test_conv_tile_variants_give_the_same_bits(gpu):
         assert torch.equal(yb[0], y1[0]) and torch.equal(yb[299], y1[0]) and torch.equal(yb[150], y1[0])
         ref = F.relu(F.conv2d(F.pad(x.permute(0, 3, 1, 2), (1,) * 4, mode="reflect"), w.permute(0, 3, 1, 2)) * sc[None, :, None, None] + sh[None, :, None, None])
         assert (y1.permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+def test_full_config_frame_properties(gpu):
+    """size-independent properties at a real frame size (640x480, big-lama configuration), where the CPU oracle is slow: an empty
+    mask returns the padded input untouched, kept pixels are the input's whatever the hole, the hole is repainted, and the
+    result does not depend on what the hole contained (the generator only ever sees img * (1 - mask))"""
+    from domain_rag_amd import lama
+    cfg = lama.LamaConfig()
+    net = lama.LamaHIP(cfg, lama.init_params(cfg, seed=4), gpu)
+    img, mask = _image_and_mask(477, 635, 6)
+    Hp, Wp = 480, 640
+    padded = np.pad(img, ((0, Hp - 477), (0, Wp - 635), (0, 0)), mode="symmetric")
+    dev = lambda a: torch.from_numpy(a).to(gpu)
+    empty = net(dev(img), dev(np.zeros_like(mask))).cpu().numpy()
+    assert empty.shape == (Hp, Wp, 3) and np.array_equal(empty, padded)
+    out = net(dev(img), dev(mask)).cpu().numpy()
+    m = np.pad(mask, ((0, Hp - 477), (0, Wp - 635)), mode="symmetric") > 0
+    assert np.array_equal(out[~m], padded[~m]) and (out[m] != padded[m]).mean() > 0.9
+    scribbled = img.copy()
+    scribbled[mask > 0] = 255 - scribbled[mask > 0]
+    out2 = net(dev(scribbled), dev(mask)).cpu().numpy()
+    assert np.array_equal(out2[m], out[m])
+    full = net(dev(img), dev(np.full_like(mask, 255))).cpu().numpy()          # everything is hole: pure generator output
+    assert full.shape == (Hp, Wp, 3) and full.std() > 1
