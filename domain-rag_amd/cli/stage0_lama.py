@@ -49,76 +49,81 @@ def build_parser():
     return p
 
 
-def process_dataset(dataset_name, shot_count, logger, simple_lama, rank: int = 0, world: int = 1):
-    """process_dataset (:78-224) -> (processed, errors).  ``simple_lama`` is the model object: (PIL RGB, PIL L) -> PIL."""
-    from PIL import Image
-    logger.info(f"开始处理数据集: {dataset_name}, {shot_count}-shot")
-    dataset_path = os.path.join("../datasets", dataset_name)
-    if not os.path.exists(dataset_path):
-        logger.error(f"数据集路径不存在: {dataset_path}")
-        return 0, 0
-    train_images_dir = os.path.join(dataset_path, "train")
-    if not os.path.exists(train_images_dir):
-        logger.error(f"训练图像目录不存在: {train_images_dir}")
-        return 0, 0
-    annotation_file = os.path.join(dataset_path, "annotations", f"{shot_count}_shot.json")
-    output_dir = H.lama_output_dir(dataset_name, shot_count)
-    os.makedirs(output_dir, exist_ok=True)
-    logger.info(f"输出目录: {output_dir}")
-    try:
-        with open(annotation_file, "r") as f:
-            data = json.load(f)
-        logger.info(f"成功加载注释文件 {annotation_file}")
-    except Exception as e:
-        logger.error(f"无法加载注释文件 {annotation_file}: {e}")
-        return 0, 0
-    info_of = {im["id"]: {"file_name": im["file_name"], "width": im["width"], "height": im["height"]} for im in data.get("images", [])}
+def _annotation_index(annotation_file):
+    """-> (image_id -> {file_name, width, height}, image_id -> [annotations] in file order, category_id -> name)"""
+    with open(annotation_file, "r") as f:
+        data = json.load(f)
+    info_of = {im["id"]: {k: im[k] for k in ("file_name", "width", "height")} for im in data.get("images", [])}
     anns_of = defaultdict(list)
     for ann in data.get("annotations", []):
         anns_of[ann["image_id"]].append(ann)
     names = {c["id"]: c["name"] for c in data.get("categories", [])}
-    logger.info(f"找到 {len(info_of)} 个图像和 {len(data.get('annotations', []))} 个注释")
-    logger.info(f"共有 {len(anns_of)} 个不同的图像需要处理")
+    return info_of, anns_of, names, len(data.get("annotations", []))
+
+
+def _inpaint_one(simple_lama, image_path, info, boxes):
+    """one image of the loop (:159-215): RGB, annotated size (PIL's default bicubic resize if the file differs), union mask"""
+    from PIL import Image
+    image = Image.open(image_path)
+    if image.mode != "RGB":
+        image = image.convert("RGB")
+    size = (info["width"], info["height"])
+    if image.size != size:
+        image = image.resize(size)
+    mask = Image.fromarray(H.inpaint_mask_array(size[0], size[1], boxes), mode="L")
+    return simple_lama(image, mask)
+
+
+def process_dataset(dataset_name, shot_count, logger, simple_lama, rank: int = 0, world: int = 1):
+    """process_dataset (:78-224) -> (processed, errors).  ``simple_lama`` is the model object: (PIL RGB, PIL L) -> PIL."""
+    logger.info(f"数据集 {dataset_name} / {shot_count}-shot: 开始")
+    dataset_path = os.path.join("../datasets", dataset_name)
+    train_images_dir = os.path.join(dataset_path, "train")
+    for need, what in ((dataset_path, "数据集目录"), (train_images_dir, "训练图像目录")):
+        if not os.path.exists(need):
+            logger.error(f"{what}不存在: {need}")
+            return 0, 0
+    annotation_file = os.path.join(dataset_path, "annotations", f"{shot_count}_shot.json")
+    output_dir = H.lama_output_dir(dataset_name, shot_count)
+    os.makedirs(output_dir, exist_ok=True)
+    logger.info(f"结果写入 {output_dir}")
+    try:
+        info_of, anns_of, names, n_ann = _annotation_index(annotation_file)
+    except Exception as e:
+        logger.error(f"读取注释文件 {annotation_file} 失败: {e}")
+        return 0, 0
+    logger.info(f"注释文件 {annotation_file}: {len(info_of)} 个图像, {n_ann} 个注释, {len(anns_of)} 个图像带有bbox")
     work = list(anns_of.items())                                  # annotation order (dict insertion), like the reference's loop
     if world > 1:
         work = H.split_samples_for_gpus(work, world)[rank]
-    processed = errors = multi = 0
+    done = failed = multi = 0
     for image_id, anns in work:
-        if image_id not in info_of:
-            logger.warning(f"警告: 找不到图像ID {image_id} 的信息")
+        info = info_of.get(image_id)
+        if info is None:
+            logger.warning(f"注释引用了未知的图像ID {image_id}, 跳过")
             continue
-        info = info_of[image_id]
         image_path = os.path.join(train_images_dir, info["file_name"])
         if len(anns) > 1:
             multi += 1
             cats = ", ".join("{}(ID:{})".format(names.get(a["category_id"], "未知类别 {}".format(a["category_id"])), a["category_id"]) for a in anns)
-            logger.info(f"处理多bbox图像: {info['file_name']}, bbox数量: {len(anns)}, 类别: {cats}")
+            logger.info(f"多bbox图像 {info['file_name']}: {len(anns)} 个bbox, 类别: {cats}")
         try:
-            image = Image.open(image_path)
-            if image.mode != "RGB":
-                image = image.convert("RGB")
-            if image.width != info["width"] or image.height != info["height"]:
-                image = image.resize((info["width"], info["height"]))        # PIL default filter (bicubic), :167
-            mask = Image.fromarray(H.inpaint_mask_array(info["width"], info["height"], [a["bbox"] for a in anns]), mode="L")
-            result = simple_lama(image, mask)
+            result = _inpaint_one(simple_lama, image_path, info, [a["bbox"] for a in anns])
             out_name = os.path.join(output_dir, info["file_name"])
             os.makedirs(os.path.dirname(out_name), exist_ok=True)
             result.save(out_name)
-            processed += 1
+            done += 1
         except Exception as e:                                     # reference convention: log, count, continue
-            logger.error(f"处理图像 {image_path} 时出错: {e}")
-            errors += 1
-    logger.info(f"完成数据集 {dataset_name} {shot_count}-shot 的处理: 成功处理 {processed} 个图像, 错误 {errors} 个")
-    logger.info(f"其中处理了 {multi} 个有多个bbox的图像")
-    return processed, errors
+            logger.error(f"图像 {image_path} 处理失败: {e}")
+            failed += 1
+    logger.info(f"数据集 {dataset_name} / {shot_count}-shot: 完成 {done} 个图像, 失败 {failed} 个, 其中多bbox图像 {multi} 个")
+    return done, failed
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
     logger = setup_logger()
-    logger.info("LaMa Inpainting开始执行")
-    logger.info(f"将处理以下数据集: {', '.join(args.datasets)}")
-    logger.info(f"将处理以下shot数量: {', '.join(args.shots)}")
+    logger.info(f"LaMa stage: 数据集 {', '.join(args.datasets)}; shots {', '.join(args.shots)}")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
@@ -130,22 +135,18 @@ def main(argv=None):
         os.environ["LAMA_MODEL"] = args.lama_model
     from ..lama import SimpleLama
     simple_lama = SimpleLama()                                     # once, not per dataset (:104) — same outputs
-    start = time.time()
-    total_ok = total_bad = 0
+    t_start = time.time()
+    totals = [0, 0]
     for ds in args.datasets:
         for shot in args.shots:
             try:
-                ok, bad = process_dataset(ds, shot, logger, simple_lama, rank, world)
-                total_ok += ok
-                total_bad += bad
+                for i, v in enumerate(process_dataset(ds, shot, logger, simple_lama, rank, world)):
+                    totals[i] += v
             except Exception as e:
-                logger.error(f"处理数据集 {ds} {shot}-shot 时发生错误: {e}")
-    total = time.time() - start
-    hours, rem = divmod(total, 3600)
-    minutes, seconds = divmod(rem, 60)
-    logger.info(f"所有数据集处理完成: 成功处理 {total_ok} 个图像, 错误 {total_bad} 个")
-    logger.info(f"总运行时间: {int(hours)}小时 {int(minutes)}分钟 {seconds:.2f}秒")
-    return total_ok, total_bad
+                logger.error(f"数据集 {ds} / {shot}-shot 中断: {e}")
+    elapsed = time.time() - t_start
+    logger.info(f"全部完成: {totals[0]} 个图像成功, {totals[1]} 个失败, 用时 {int(elapsed // 3600)}:{int(elapsed % 3600 // 60):02d}:{elapsed % 60:05.2f}")
+    return tuple(totals)
 
 
 if __name__ == "__main__":

@@ -41,7 +41,7 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
 
     # ---- stage 0 (run from ./lama_inpaint like inapint.sh): the object-free k-shot images stages 1 and 2 read
     out0 = _run("domain_rag_amd.cli.stage0_lama", ["--datasets", ds, "--shots", "1", "--synthetic-weights", "--tiny"], cwd=root / "lama_inpaint")
-    assert "成功处理 2 个图像, 错误 0 个" in out0
+    assert "完成 2 个图像, 失败 0 个" in out0
     for name in ("beetle_01", "moth_02"):
         assert Image.open(root / "lamainpaint" / ds / "1_shot" / f"{name}.jpg").size == (72, 48)
 

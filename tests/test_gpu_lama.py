@@ -217,7 +217,7 @@ def test_stage0_cli_on_mini_dataset(gpu, tmp_path):
 
     log = run()
     out = tmp_path / "lamainpaint" / "NEU_DET" / "1_shot"
-    assert "成功处理 3 个图像, 错误 0 个" in log and "处理多bbox图像: a.png, bbox数量: 2" in log and "数据集路径不存在: ../datasets/missing_ds" in log
+    assert "完成 3 个图像, 失败 0 个" in log and "多bbox图像 a.png: 2 个bbox" in log and "数据集目录不存在: ../datasets/missing_ds" in log
     assert (tmp_path / "lamainpaint" / "logs" / "lama_inpaint_20260101_000000.log").exists()
     assert Image.open(out / "a.png").size == (56, 40) and Image.open(out / "b.jpg").size == (56, 40) and Image.open(out / "c.png").size == (64, 64)
     from domain_rag_amd import hostlogic as H
