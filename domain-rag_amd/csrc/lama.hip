@@ -189,6 +189,88 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Convolutions with <= 4 output channels (the generator's last layer: 64 -> 3, 7x7).  On the matrix core their N dimension
+// would be padded 3 -> 64 (95 % of the MFMA work wasted: 4.5 of the 25 ms of a 1024x768 frame); here one thread owns one
+// output pixel and all its channels on the VALU: a (16+KH-1) x (16+KW-1) pixel patch of 16 input channels is staged in LDS
+// per step (each input pixel is fetched ~1.9x instead of KH*KW times) next to the step's weights, which every lane reads
+// at the same address (LDS broadcast).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SC_T = 16, SC_KMAX = 7, SC_C = 16, SC_LD = SC_C + 4, SC_P = SC_T + SC_KMAX - 1;
+
+template <int NCO>
+__global__ __launch_bounds__(256) void conv_small_cout_f32_kernel(ConvK p) {
+  __shared__ __attribute__((aligned(16))) float tile[SC_P][SC_P][SC_LD];
+  __shared__ __attribute__((aligned(16))) float wl[NCO][SC_KMAX * SC_KMAX][SC_C];
+  const drag_conv2d_f32_args& a = p.a;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ox0 = blockIdx.x * SC_T, oy0 = blockIdx.y * SC_T, b = blockIdx.z;
+  const int ph = SC_T + a.KH - 1, pw = SC_T + a.KW - 1;
+  const float* xb = a.x + (long long)b * a.Hi * a.Wi * a.ldx;
+  float acc[NCO];
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
+  const int taps = a.KH * a.KW;
+  for (int c0 = 0; c0 < a.Cin; c0 += SC_C) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ph * pw * (SC_C / 4); i += 256) {
+      const int c4 = i & 3, pix = i >> 2;
+      const int py = pix / pw, px = pix - py * pw;
+      int iy = oy0 + py - a.pad, ix = ox0 + px - a.pad;
+      bool ok = true;
+      if (a.pad_mode == DRAG_PAD_REFLECT) {
+        // patch pixels beyond the last output row / column of a ragged block may reflect twice: clamp, they are never used
+        if (iy < 0) iy = -iy;
+        if (iy >= a.Hi) iy = 2 * a.Hi - 2 - iy;
+        if (ix < 0) ix = -ix;
+        if (ix >= a.Wi) ix = 2 * a.Wi - 2 - ix;
+        iy = min(max(iy, 0), a.Hi - 1);
+        ix = min(max(ix, 0), a.Wi - 1);
+      } else {
+        ok = iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+      }
+      const f32x4_t v = ok ? *(const f32x4_t*)(xb + ((long long)iy * a.Wi + ix) * a.ldx + c0 + c4 * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      *(f32x4_t*)&tile[py][px][c4 * 4] = v;
+    }
+    for (int i = threadIdx.x; i < NCO * taps * (SC_C / 4); i += 256) {     // this chunk's weights: read back as LDS broadcasts
+      const int c4 = i & 3, t = (i >> 2) % taps, co = (i >> 2) / taps;
+      *(f32x4_t*)&wl[co][t][c4 * 4] = co < a.Cout ? *(const f32x4_t*)(a.w + ((long long)co * taps + t) * a.Cin + c0 + c4 * 4)
+                                                   : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    for (int t = 0; t < taps; ++t) {
+      const int ky = t / a.KW, kx = t - ky * a.KW;
+#pragma unroll
+      for (int c4 = 0; c4 < SC_C / 4; ++c4) {
+        const f32x4_t v = *(const f32x4_t*)&tile[ty + ky][tx + kx][c4 * 4];
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) {
+          const f32x4_t w4 = *(const f32x4_t*)&wl[co][t][c4 * 4];
+          acc[co] = fmaf(v[0], w4[0], acc[co]);
+          acc[co] = fmaf(v[1], w4[1], acc[co]);
+          acc[co] = fmaf(v[2], w4[2], acc[co]);
+          acc[co] = fmaf(v[3], w4[3], acc[co]);
+        }
+      }
+    }
+  }
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy >= a.Ho || ox >= a.Wo) return;
+  const long long m = ((long long)b * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) {
+    if (co >= a.Cout) break;
+    float v = acc[co];
+    if (a.addend) v += a.addend[m * a.ld_add + co];
+    v = v * (a.scale ? a.scale[co] : 1.0f) + (a.shift ? a.shift[co] : 0.0f);
+    if (a.act == DRAG_CONV_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (a.act == DRAG_CONV_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    else if (a.act == DRAG_CONV_ACT_QUICK_GELU) v = v * (1.0f / (1.0f + expf(-1.702f * v)));
+    if (a.resid) v += a.resid[m * a.ld_res + co];
+    a.y[m * a.ldy + co] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // DFT passes as f32-MFMA GEMMs against twiddle tiles generated on the fly.  tw[j] = (cos, sin)(2 pi j / n), j in [0, n),
 // float64-evaluated by the caller; the element (i, k) of the n-point DFT matrix is tw[(i * k) mod n], so a thread that
 // fills 4 consecutive k of row i walks the table with an integer stride — no n x n matrices in memory.
@@ -391,6 +473,17 @@ extern "C" int drag_conv2d_f32(const drag_conv2d_f32_args* a, void* stream) {
   ConvK k;
   k.a = *a;
   k.npix = (long long)a->B * a->Ho * a->Wo;
+  static const bool no_small = getenv("DRAG_CONV_NO_SMALL_COUT") != nullptr;
+  if (a->Cout <= 4 && a->stride == 1 && !a->transposed && a->KH <= SC_KMAX && a->KW <= SC_KMAX && a->Cin % SC_C == 0 && a->ldx >= a->Cin &&
+      a->B <= 65535 && !no_small) {
+    dim3 grid((unsigned)((a->Wo + SC_T - 1) / SC_T), (unsigned)((a->Ho + SC_T - 1) / SC_T), (unsigned)a->B);
+    if (a->Cout == 1)
+      hipLaunchKernelGGL(conv_small_cout_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    else
+      hipLaunchKernelGGL(conv_small_cout_f32_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    DRAG_LAUNCH_CHECK();
+    return 0;
+  }
   // tile policy (speed only — every instantiation produces the same bits): 128x128 tiles when that still launches >= 2
   // workgroups per CU, else 64x64 with 16-channel steps, or 64-channel steps when even those leave CUs with one workgroup
   static const char* force = getenv("DRAG_CONV_TILE");            // "64x16" | "64x64" | "128" (tests, ablations)
