@@ -12,6 +12,6 @@ restatements (flux.py, vae.py, redux.py, fill.py, stem.py, topk.c, lama.py) are 
 (cited per function).
 PINNED parts: resize.py is checked bit-for-bit against PIL itself (tests/test_oracle_resize.py); vit.py drives the
 `transformers` CLIP / SigLIP vision modules that ARE importable here (version 5.x, not the pinned 4.46.3) with shared
-weights; the host logic is checked against goldens captured from the imported reference scripts
+weights; stem.py's conv/bn/relu/pool equals transformers' ResNetEmbeddings (the same ResNet-50 stem) bit for bit; the host logic is checked against goldens captured from the imported reference scripts
 (tests/golden/make_host_goldens.py, make_stage2_goldens.py, make_stage1_goldens.py, make_lama_goldens.py).  DESIGN.md lists the status row by row.
 """

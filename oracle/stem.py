@@ -1,7 +1,8 @@
 """oracle/stem.py — CPU restatement of ResNetEncoder + calc_mean_std + compute_resnet_features' tensor math
 (retrieval/clip100_resnet_style_all_shots.py:51-74,197-200).  TEST INFRASTRUCTURE ONLY.
 torchvision (resnet50 IMAGENET1K_V1) is not installed here: the stem is restated with torch.nn.functional from
-its published definition (conv1 7x7/2 pad 3 no bias, BatchNorm2d eval eps 1e-5, ReLU, MaxPool 3x3/2 pad 1).
+its published definition (conv1 7x7/2 pad 3 no bias, BatchNorm2d eval eps 1e-5, ReLU, MaxPool 3x3/2 pad 1) and checked, bit
+for bit, against `transformers`' ResNetEmbeddings — the same stem, importable here (tests/test_host_logic.py).
 ``calc_mean_std`` follows the reference line by line (unbiased var + eps, then sqrt)."""
 import torch
 import torch.nn.functional as F

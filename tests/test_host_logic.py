@@ -207,3 +207,26 @@ def test_load_image_applies_exif_orientation(tmp_path):
     fixed = np.asarray(H.load_image_rgb(str(tmp_path / "r.jpg")))
     assert plain.shape == (20, 30, 3) and fixed.shape == (30, 20, 3)
     assert fixed[:, -5:].mean() > 200 and fixed[:, :10].mean() < 50      # the bright edge is now on the right
+
+
+def test_stem_restatement_matches_upstream_resnet_embeddings():
+    """torchvision is not installable here, but `transformers` ships the same ResNet-50 stem (microsoft/resnet-50 is a port of
+    the torchvision weights): Conv 7x7/2 pad 3 no bias -> BatchNorm(eps 1e-5) -> ReLU -> MaxPool 3x3/2 pad 1.  The oracle's
+    functional restatement must equal that upstream module on shared random weights, bit for bit."""
+    import torch
+    from transformers import ResNetConfig
+    from transformers.models.resnet.modeling_resnet import ResNetEmbeddings
+    from oracle import stem as ostem
+    g = torch.Generator().manual_seed(0)
+    st = {"conv1.weight": torch.randn(64, 3, 7, 7, generator=g) * 0.1, "bn1.weight": torch.rand(64, generator=g) + 0.5,
+          "bn1.bias": torch.randn(64, generator=g) * 0.1, "bn1.running_mean": torch.randn(64, generator=g) * 0.1,
+          "bn1.running_var": torch.rand(64, generator=g) + 0.5}
+    m = ResNetEmbeddings(ResNetConfig()).eval()
+    conv, bn = m.embedder.convolution, m.embedder.normalization
+    assert (conv.kernel_size, conv.stride, conv.padding, conv.bias, bn.eps) == ((7, 7), (2, 2), (3, 3), None, 1e-5)
+    with torch.no_grad():
+        conv.weight.copy_(st["conv1.weight"]); bn.weight.copy_(st["bn1.weight"]); bn.bias.copy_(st["bn1.bias"])
+        bn.running_mean.copy_(st["bn1.running_mean"]); bn.running_var.copy_(st["bn1.running_var"])
+        for shape in ((1, 3, 256, 256), (2, 3, 97, 131)):
+            x = torch.rand(shape, generator=g)
+            assert torch.equal(m(x), ostem.stem(x, st))
