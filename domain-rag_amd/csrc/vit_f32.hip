@@ -11,7 +11,7 @@
 //   clip_embed_ln_kernel    x[b,0] = class_embedding, x[b,1+p] = patch embedding; + positional_embedding; ln_pre
 //   layernorm_f32_kernel    one wave per row, two-pass mean / variance in fp32, affine; strided rows (ln_post reads x[:,0])
 //   attn_small_f32_kernel   softmax(q k^T / sqrt(d)) v for short sequences (T <= 64 keys, head_dim <= 64): one workgroup per
-//                           (image, head), one wave per query: lane j scores key j from its register-resident key row,
+//                           (image, head), K / V staged once through LDS, one wave per query: lane j scores key j from its register-resident key row,
 //                           wave-wide softmax, lane d accumulates output column d from its register-resident value column
 #include "drag_common.h"
 
@@ -108,17 +108,24 @@ __global__ __launch_bounds__(256) void attn_small_f32_kernel(const float* __rest
   const int D = H * hd;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* base = qkv + (long long)bi * T * ld + h * hd;
-  float krow[64], vcol[64];
-  {
-    const float* kp = base + (long long)(lane < T ? lane : 0) * ld + D;
-#pragma unroll
-    for (int d4 = 0; d4 < 16; ++d4) {
-      const f32x4_t k4 = (lane < T && d4 * 4 < hd) ? *(const f32x4_t*)(kp + d4 * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      krow[d4 * 4] = k4[0]; krow[d4 * 4 + 1] = k4[1]; krow[d4 * 4 + 2] = k4[2]; krow[d4 * 4 + 3] = k4[3];
-    }
-#pragma unroll
-    for (int j = 0; j < 64; ++j) vcol[j] = (j < T && lane < hd) ? base[(long long)j * ld + 2 * D + lane] : 0.f;
+  // K and V of this (image, head) pass through LDS once per workgroup (coalesced 16-byte loads; one copy instead of one per
+  // wave), then every wave fills its registers from there: lane j <- key row j, lane d <- value column d
+  __shared__ float Ks[64][65];
+  __shared__ float Vs[64][64];
+  const int hq = hd >> 2;
+  for (int i = threadIdx.x; i < T * hq; i += 256) {
+    const int t = i / hq, d4 = (i - t * hq) * 4;
+    const f32x4_t k4 = *(const f32x4_t*)(base + (long long)t * ld + D + d4);
+    const f32x4_t v4 = *(const f32x4_t*)(base + (long long)t * ld + 2 * D + d4);
+    Ks[t][d4] = k4[0]; Ks[t][d4 + 1] = k4[1]; Ks[t][d4 + 2] = k4[2]; Ks[t][d4 + 3] = k4[3];
+    *(f32x4_t*)&Vs[t][d4] = v4;
   }
+  __syncthreads();
+  float krow[64], vcol[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) krow[d] = (lane < T && d < hd) ? Ks[lane][d] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) vcol[j] = (j < T && lane < hd) ? Vs[j][lane] : 0.f;
   for (int t = wave; t < T; t += 4) {
     const float q = lane < hd ? base[(long long)t * ld + lane] : 0.f;
     float a = 0.f;
