@@ -60,6 +60,7 @@ SIGNATURES = {
     "drag_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "drag_cosine_topk_workspace_bytes": (c_int64, [c_int64, c_int]),
     "drag_cosine_topk_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "drag_cosine_scores_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "drag_l2_normalize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     "drag_patchify_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "drag_resample_u8": (c_int, [ctypes.POINTER(ResampleArgs), c_void_p]),

@@ -415,7 +415,8 @@ extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt,
   DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
   const int groups = (B * H + 7) / 8;
-  const bool w8 = getenv("DRAG_ATTN_W4") == nullptr && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
+  static const bool force_w4 = getenv("DRAG_ATTN_W4") != nullptr;     // A/B switch, read once per process
+  const bool w8 = !force_w4 && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
   const int QB = w8 ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);

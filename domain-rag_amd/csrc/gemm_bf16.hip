@@ -648,8 +648,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
 // faster one per tile, but it needs enough tiles to fill the 256 CUs and loses to the 128x128 kernel when the last round of
 // tiles is mostly empty (measured at M = 1024 / 1536 / 1753, scripts/bench_gemm_small_m.py: 216 tiles 1226 vs 957 TFLOP/s,
 // 504 tiles 1384 vs 1069, but 72 tiles 510 vs 680 and 288 tiles 927 vs 993).
+// A/B switches are read once per process (not per launch)
+static bool env_flag(const char* name) { return getenv(name) != nullptr; }
 static bool use_t256(long long M, int N, int K) {
-  if (getenv("DRAG_GEMM_T128") != nullptr || N < 256 || K < 256) return false;
+  static const bool force_t128 = env_flag("DRAG_GEMM_T128");
+  if (force_t128 || N < 256 || K < 256) return false;
   if (M >= 2048) return true;
   if (M < 1024) return false;
   const long long tiles = ((M + 255) / 256) * ((N + 255) / 256);
@@ -669,7 +672,8 @@ static int t256_grid(int ntiles) {
     ncu = n & ~7;                                  // multiple of the 8 XCDs, so a workgroup's tiles stay on its XCD's L2
     if (ncu == 0) ncu = 8;
   }
-  if (getenv("DRAG_GEMM_NONPERSISTENT") != nullptr) return ntiles;
+  static const bool nonpersistent = env_flag("DRAG_GEMM_NONPERSISTENT");
+  if (nonpersistent) return ntiles;
   return ntiles < ncu ? ntiles : ncu;
 }
 
@@ -682,9 +686,10 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   k.cm.rpb = c_rpb > 0 ? c_rpb : M; k.cm.bs = c_bs; k.cm.ld = ldc;
   k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
   k.a_bytes = 0; k.w_bytes = 0;
+  static const bool narrow = env_flag("DRAG_GEMM_NARROW");
   k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&
            (!resid || ((uintptr_t)resid & 15) == 0) && (!gate || (((uintptr_t)gate & 15) == 0 && ldg % 8 == 0)) &&
-           getenv("DRAG_GEMM_NARROW") == nullptr;
+           !narrow;
   k.tiles_m = (M + BM - 1) / BM; k.tiles_n = (N + BN - 1) / BN;
   return k.tiles_m * k.tiles_n;
 }

@@ -268,6 +268,30 @@ extern "C" int64_t drag_cosine_topk_workspace_bytes(int64_t N, int32_t Q) {
   return 16 * npad * 4 + 2 * 16 * G1 * (long long)KMAX * 8 + 256;
 }
 
+// scan only: scores[q, n] = <corpus[n], queries[q]> for Q <= 16 queries, row stride npad = ceil64(N) floats.
+// The same kernel, launch geometry and summation order as the first stage of drag_cosine_topk_f32 (bench.py times
+// the HBM-bound pass alone through this entry; tests compare it bit for bit with the oracle's score order).
+extern "C" int drag_cosine_scores_f32(const float* corpus, const float* queries, int64_t N, int32_t d, int32_t Q,
+                                      float* scores, void* stream) {
+  DRAG_CHECK(corpus && queries && scores, "drag_cosine_scores_f32: null pointer");
+  DRAG_CHECK(N > 0 && Q > 0 && Q <= 16, "drag_cosine_scores_f32: N > 0 and 1 <= Q <= 16 (one scan pass)");
+  DRAG_CHECK(d > 0 && d % 64 == 0 && d <= 1024, "drag_cosine_scores_f32: d must be a multiple of 64, <= 1024");
+  DRAG_CHECK(N < (1ll << 32) - 1, "drag_cosine_scores_f32: N must fit 32 bits");
+  const int lds = (d / 64) * 4096 + 4 * 8192;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)ip_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DRAG_CHECK(e == hipSuccess, "drag_cosine_scores_f32: cannot raise dynamic LDS limit");
+  }
+  const long long ngroups = (N + 15) / 16;
+  const int grid = (int)min((long long)2048, (ngroups + 3) / 4);
+  ScanArgs sa;
+  sa.corpus = corpus; sa.queries = queries; sa.scores = scores;
+  sa.N = N; sa.npad = (N + 63) / 64 * 64; sa.d = d; sa.Q = Q;
+  hipLaunchKernelGGL(ip_scan_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, sa);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, int32_t d, int32_t Q,
                                     int32_t k, float* out_d, int64_t* out_i, void* workspace, void* stream) {
   DRAG_CHECK(corpus && queries && out_d && out_i && workspace, "drag_cosine_topk_f32: null pointer");

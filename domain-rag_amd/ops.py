@@ -22,8 +22,9 @@ class GemmRecorder:
     other steps run the way the product does (hipGraph replay, no events) so the timed region is not slowed by ~16k
     event records."""
 
-    def __init__(self, every: int = 1):
+    def __init__(self, every: int = 1, f32: bool = False):
         self.every = max(1, int(every))
+        self.f32 = f32              # also bracket the float32 matrix-core launches (conv2d_f32_kernel: the CLIP tower, LaMa)
         self.events = []
         self.shapes = []
         self.is_conv = []
@@ -37,6 +38,8 @@ class GemmRecorder:
     @staticmethod
     def kernel_of(shape, conv=False):
         """the dispatch rule of drag_gemm_bf16 / drag_conv3x3_bf16 (csrc/gemm_bf16.hip: use_t256)"""
+        if conv == "f32":
+            return "conv2d_f32_kernel"
         M, N, K = shape
         big = False
         if N >= 256 and K >= 256:
@@ -217,13 +220,23 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _need_rows(t: torch.Tensor, name: str):
+    """the kernels take a base pointer + (rows, d): a sliced / transposed view would be scanned with the wrong stride"""
+    if t.dim() != 2 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous [rows, d] matrix (got shape {tuple(t.shape)}, strides {t.stride()}); "
+                         "call .contiguous() on views")
+
+
 def cosine_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int):
     """(D, I) = exact inner-product top-k; D f32 [Q, k] descending, I int64 [Q, k]."""
     lib = _lib.load()
     _need(corpus, torch.float32, "corpus")
     _need(queries, torch.float32, "queries")
+    _need_rows(corpus, "corpus"); _need_rows(queries, "queries")
     N, d = corpus.shape
     Q = queries.shape[0]
+    if queries.shape[1] != d:
+        raise ValueError(f"queries have d = {queries.shape[1]}, corpus has d = {d}")
     ws_bytes = lib.drag_cosine_topk_workspace_bytes(N, Q)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=corpus.device)
     D = torch.empty((Q, k), dtype=torch.float32, device=corpus.device)
@@ -233,9 +246,25 @@ def cosine_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int):
     return D, I
 
 
+def cosine_scores(corpus: torch.Tensor, queries: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """scan pass alone: f32 [Q <= 16, ceil64(N)] inner products in the pinned summation order (entries >= N unspecified)"""
+    lib = _lib.load()
+    _need(corpus, torch.float32, "corpus")
+    _need(queries, torch.float32, "queries")
+    _need_rows(corpus, "corpus"); _need_rows(queries, "queries")
+    N, d = corpus.shape
+    Q = queries.shape[0]
+    npad = (N + 63) // 64 * 64
+    if out is None:
+        out = torch.empty((Q, npad), dtype=torch.float32, device=corpus.device)
+    check(lib.drag_cosine_scores_f32(_p(corpus), _p(queries), N, d, Q, _p(out), _stream()), "drag_cosine_scores_f32")
+    return out
+
+
 def l2_normalize_(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _need(x, torch.float32, "x")
+    _need_rows(x, "x")
     check(lib.drag_l2_normalize_f32(_p(x), x.shape[0], x.shape[1], _stream()), "drag_l2_normalize_f32")
     return x
 
@@ -401,6 +430,15 @@ def conv2d_f32(x: torch.Tensor, w: torch.Tensor, y: torch.Tensor, *, B: int, Hi:
     a.resid = resid.data_ptr() if resid is not None else None
     a.B, a.Hi, a.Wi, a.Cin, a.ldx, a.Ho, a.Wo, a.Cout, a.ldy, a.ld_add, a.ld_res = B, Hi, Wi, Cin, ldx, Ho, Wo, Cout, ldy, ld_add, ld_res
     a.KH, a.KW, a.stride, a.pad, a.pad_mode, a.transposed, a.act = KH, KW, stride, pad, pad_mode, int(transposed), act
+    if _recorder is not None and _recorder.f32:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+        check(lib.drag_conv2d_f32(ctypes.byref(a), _stream()), "drag_conv2d_f32")
+        e_ev.record()
+        _recorder.events.append((s_ev, e_ev, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin))
+        _recorder.shapes.append((B * Ho * Wo, Cout, KH * KW * Cin))
+        _recorder.is_conv.append("f32")
+        return y
     check(lib.drag_conv2d_f32(ctypes.byref(a), _stream()), "drag_conv2d_f32")
     return y
 

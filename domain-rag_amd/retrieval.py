@@ -307,24 +307,46 @@ def embed_images(model: ClipImageModel, tensors: torch.Tensor, batch: int = 256)
     return torch.cat(outs, 0) if outs else torch.empty((0, 512), device=model.device)
 
 
-def allgather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """Concatenate per-rank row shards (split by ``shard_bounds``) into the global [n_total, d] matrix on every
-    rank with ONE all_gather of equal-sized (padded) shards.  Works with RCCL ("nccl", GPU tensors) and gloo."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    d = local.shape[1]
+def pack_shard(local: torch.Tensor, n_total: int, world: int, rank: int) -> torch.Tensor:
+    """this rank's rows padded with zero rows to the largest shard's row count (all-gather needs equal sizes)"""
     cap = shard_bounds(n_total, world, 0)[1]                      # largest shard
     s, e = shard_bounds(n_total, world, rank)
-    assert local.shape[0] == e - s, "local shard does not follow shard_bounds()"
-    send = torch.zeros((cap, d), dtype=local.dtype, device=local.device)
+    if local.shape[0] != e - s:
+        raise ValueError(f"rank {rank}: local shard has {local.shape[0]} rows, shard_bounds() says {e - s}")
+    send = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
     send[: e - s] = local
-    recv = torch.empty((world, cap, d), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send, group=group) if hasattr(dist, "all_gather_into_tensor") and local.is_cuda \
-        else dist.all_gather(list(recv.unbind(0)), send, group=group)
-    parts = [recv[r, : shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0]] for r in range(world)]
+    return send
+
+
+def unpack_shards(recv: torch.Tensor, n_total: int) -> torch.Tensor:
+    """[world, cap, d] gathered padded shards -> [n_total, d] in the GLOBAL row order (rank 0's rows first), so an index
+    into the result is the row's position in the sorted corpus path list whatever the world size"""
+    world = recv.shape[0]
+    parts = []
+    for r in range(world):
+        s, e = shard_bounds(n_total, world, r)
+        parts.append(recv[r, : e - s])
     return torch.cat(parts, 0)
+
+
+def allgather_rows(local: torch.Tensor, n_total: int, group=None, force: bool = False) -> torch.Tensor:
+    """Concatenate per-rank row shards (split by ``shard_bounds``) into the global [n_total, d] matrix on every
+    rank with ONE all_gather of equal-sized (padded) shards: ``all_gather_into_tensor`` on RCCL (backend "nccl",
+    GPU tensors), list-form ``all_gather`` on gloo.  A single rank returns ``local`` itself unless ``force`` (which
+    sends the one shard through the collective anyway: the RCCL call path is then exercised on a 1-GPU box)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1 and not force:
+        return local
+    send = pack_shard(local, n_total, world, rank)
+    recv = torch.empty((world,) + tuple(send.shape), dtype=local.dtype, device=local.device)
+    if local.is_cuda and hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        dist.all_gather(list(recv.unbind(0)), send, group=group)
+    return unpack_shards(recv, n_total)
 
 
 def compute_corpus_features(model: ClipImageModel, preprocess, image_paths: list[str], batch: int = 256, decode_workers: int | None = None,

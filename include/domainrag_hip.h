@@ -157,6 +157,11 @@ int64_t drag_cosine_topk_workspace_bytes(int64_t N, int32_t Q);
 int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, int32_t d,
                          int32_t Q, int32_t k, float* out_d, int64_t* out_i, void* workspace,
                          void* stream);
+/* Scan pass of the above alone (one pass, Q <= 16): scores f32 [Q, ceil64(N)] = corpus . queries in the same fixed
+ * summation order (what faiss computes before its heap; retrieval/clip100_resnet_style_all_shots.py:431).  Entries
+ * N..ceil64(N) of a score row are unspecified. */
+int drag_cosine_scores_f32(const float* corpus, const float* queries, int64_t N, int32_t d, int32_t Q,
+                           float* scores, void* stream);
 /* ResNet50 stem style vector: conv1 7x7/2 (no bias) + eval-BatchNorm (folded scale/shift) + ReLU + maxpool 3x3/2,
  * then per-channel mean and sqrt(unbiased var + eps) -> out f32 [B, 128] = [mean(64) | std(64)].
  * Replaces ResNetEncoder.forward + calc_mean_std (retrieval/clip100_resnet_style_all_shots.py:51-74,197-200).

@@ -1,0 +1,50 @@
+"""bench.py's launcher on CPU: `--gpus N` starts N ranks itself (gloo self-test mode: rendezvous, rank count by all-reduce, the
+reference's unit sharding, the one all-gather into the global row order), refuses to run N ranks on fewer GPUs and refuses a
+--gpus / WORLD_SIZE mismatch — it can no longer print n_gpus for ranks that did not run (outpainting_updown_sampling_redux.py
+:157-177,1605-1715 is the fan-out it stands in for)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    for n in (2, 3):
+        r = _run(["--gpus", str(n), "--selftest-launcher"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = _json_line(r.stdout)
+        assert out == {"selftest": "launcher", "n_ranks": n, "joined_ranks": n, "backend": "gloo", "ok": True}
+
+
+def test_single_rank_selftest_needs_no_rendezvous():
+    r = _run(["--gpus", "1", "--selftest-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_line(r.stdout)["n_ranks"] == 1
+
+
+def test_more_ranks_than_gpus_fails_loudly():
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run(["--gpus", str(max(have + 1, 2)), "--no-cpu-baseline"], timeout=120)
+    assert r.returncode != 0
+    assert "GPU(s) are visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_mismatch_fails_loudly():
+    r = _run(["--gpus", "2", "--selftest-launcher"], env_extra={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "n_ranks" not in r.stdout

@@ -1,0 +1,184 @@
+"""Round-2 parity at BASELINE's FULL sizes — the cases round 1 only covered in miniature:
+  * Flux VAE decode + both encodes at latent 128x128 (1024^2 pixels: 8.4 M-row implicit-GEMM convs, two-stage GroupNorm
+    over 128-ch x 1024^2 maps, the 16 384-token mid-block attention) with B = 2, against the float32 CPU oracle
+    (AutoencoderKL.decode / .encode as reached from outpainting_updown_sampling_redux.py:1246-1257);
+  * SigLIP-so400m/14-384 in its full configuration (27 layers x 1152, head_dim 72) against upstream transformers'
+    SiglipVisionModel with shared weights (FluxPriorReduxPipeline.encode_image, outpainting_...:1237-1243);
+  * one full-size double + single DiT block at B = 8: row i of the batch is image i alone (bits), and equals the oracle;
+  * the sharded all-gather order == the single-GPU order at N = 118 287, and the RCCL call path itself on this GPU;
+  * the scan-only entry (drag_cosine_scores_f32) bit for bit against the oracle's pinned summation order.
+These are slow (the oracle runs on the host cores): minutes, not seconds."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _rand(shape, seed, scale=1.0):
+    return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale).bfloat16()
+
+
+VAE_TOL = 1e-2          # max |HIP - fp32 oracle| / max |oracle|, decoded image in [0,1] and packed latents alike
+PIXEL_TOL = 3           # uint8 levels: 1e-2 of full scale = 2.55, rounded up
+
+
+def test_vae_full_size_decode_and_encodes_vs_fp32_oracle(gpu):
+    from domain_rag_amd import vae
+    from oracle import vae as ov
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = vae.VaeConfig()                      # (128, 256, 512, 512), 2 layers per block: the FLUX.1 VAE
+    p = vae.init_params(cfg, seed=3)
+    p32 = {k: v.float() for k, v in p.items()}
+    model = vae.FluxVaeHIP(cfg, p, gpu)
+    B, h, w = 2, 64, 64                        # 64x64 tokens = latent 128x128 = 1024x1024 pixels
+    tok = _rand((B, h * w, 64), 5)
+    img_u8, rows = model.decode_tokens(tok.to(gpu), B, h, w, return_rows=True)
+    H, W = img_u8.shape[1:3]
+    assert (H, W) == (1024, 1024)
+    got = (rows.view(B, H, W, -1)[..., :3].float().cpu() / 2 + 0.5).clamp(0, 1).permute(0, 3, 1, 2)
+    img_u8 = img_u8.cpu()
+    with torch.no_grad():
+        for b in range(B):                     # one image at a time bounds the oracle's memory (the 16 384^2 score matrix)
+            _, ref32 = ov.decode_tokens_to_u8(p32, tok[b:b + 1].float(), h, w)
+            e = _rel(got[b:b + 1], ref32)
+            assert e < VAE_TOL, ("decode", b, e)
+            d = (img_u8[b].int() - (ref32[0].permute(1, 2, 0) * 255).round().int()).abs()
+            assert d.max().item() <= PIXEL_TOL, ("pixels", b, d.max().item(), (d > 1).float().mean().item())
+            del ref32
+    # image 1 of the batch == the same image decoded alone (per-image arithmetic is independent of the batch)
+    alone = model.decode_tokens(tok[1:2].to(gpu), 1, h, w).cpu()
+    assert torch.equal(alone[0], img_u8[1])
+
+    # ---- encodes: posterior mode of the plain image, and a sampled posterior of the masked image (the two Fill encodes)
+    g = torch.Generator().manual_seed(7)
+    img = (torch.rand(B, 1024, 1024, 3, generator=g) * 255).to(torch.uint8)
+    mask = torch.zeros(B, 1024, 1024, dtype=torch.uint8); mask[:, :, 300:900] = 255
+    noise = torch.randn(B, 16, 128, 128, generator=g).bfloat16()
+    for use_mask, nz in [(False, None), (True, noise)]:
+        toks = torch.empty((B, h * w, 64), dtype=torch.bfloat16, device=gpu)
+        model.encode_to_tokens(img.to(gpu), mask.to(gpu) if use_mask else None, None if nz is None else nz.to(gpu), toks, 64)
+        toks = toks.cpu()
+        with torch.no_grad():
+            for b in range(B):
+                x = ov.preprocess_image(img[b:b + 1])
+                if use_mask:
+                    x = x * (1 - ov.preprocess_mask(mask[b:b + 1]))
+                ref = ov.pack_latents(ov.sample_latents(ov.encode_moments(p32, x), None if nz is None else nz[b:b + 1].float()))
+                e = _rel(toks[b:b + 1], ref)
+                assert e < 1.5e-2, ("encode", use_mask, b, e)
+
+
+def test_siglip_so400m_full_config_vs_transformers(gpu):
+    from domain_rag_amd import vit
+    from oracle import vit as ov
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = vit.VitConfig.siglip_so400m()
+    assert (cfg.hidden, cfg.layers, cfg.heads, cfg.intermediate, cfg.image_size, cfg.patch_size) == (1152, 27, 16, 4304, 384, 14)
+    g = vit.init_generic_params(cfg, 11)
+    img = (torch.rand(2, 384, 384, 3, generator=torch.Generator().manual_seed(2)) * 255).to(torch.uint8)
+    px = ov.normalize_u8(img, cfg.mean, cfg.std)
+    ref32 = ov.siglip_last_hidden_state(g, 384, 14, 1152, 16, 27, 4304, px, torch.float32)
+    out = vit.VitHIP(cfg, g, gpu)(img.to(gpu))
+    assert out.shape == (2, 729, 1152)
+    e = _rel(out, ref32)
+    # bf16 tower (the reference runs SigLIP in torch.bfloat16: batch_generate_flux_kshot.py:49,139) vs the float32 model
+    assert e < 2e-2, e
+    # the mean error is what the Redux MLP sees: far below the max
+    assert ((out.float().cpu() - ref32).abs().mean() / ref32.abs().mean()).item() < 1e-2
+
+
+def test_full_size_dit_blocks_batch8_rows_are_images(gpu):
+    """B = 8, S = 1241 + 4096, D = 3072: 1 double + 1 single block of the Fill transformer.  Image i of the batch must carry
+    exactly the bits of image i run alone, and images 0 and 7 must match the bf16 CPU oracle."""
+    from domain_rag_amd.flux import FluxTransformerHIP, latent_image_ids
+    from domain_rag_amd.flux_params import FluxConfig, init_params
+    from oracle import flux as oflux
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = FluxConfig(in_channels=384, num_layers=1, num_single_layers=1)
+    params = init_params(cfg, seed=21)
+    g = torch.Generator().manual_seed(22)
+    B, St, h, w = 8, 512 + 729, 64, 64
+    hidden = torch.randn(B, h * w, 384, generator=g).bfloat16()
+    enc = torch.randn(B, St, 4096, generator=g).bfloat16()
+    pooled = torch.randn(B, 768, generator=g).bfloat16()
+    t, gd = torch.full((B,), 0.6172), torch.full((B,), 30.0)
+    img_ids, txt_ids = latent_image_ids(h, w), torch.zeros(St, 3)
+    model = FluxTransformerHIP(cfg, params, gpu)
+    out8 = model(hidden.to(gpu), enc.to(gpu), pooled.to(gpu), t, img_ids, txt_ids, gd).clone()
+    for i in (0, 3, 7):
+        one = model(hidden[i:i + 1].to(gpu), enc[i:i + 1].to(gpu), pooled[i:i + 1].to(gpu), t[:1], img_ids, txt_ids, gd[:1])
+        assert torch.equal(one[0], out8[i]), f"image {i}: batch row differs from the single-image run"
+    ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    with torch.no_grad():
+        for i in (0, 7):
+            ref = oflux.flux_forward(params, ocfg, hidden[i:i + 1], enc[i:i + 1], pooled[i:i + 1], t[:1], img_ids, txt_ids, gd[:1])
+            assert _rel(out8[i:i + 1], ref) < 2e-2, i
+
+
+def test_sharded_gather_order_equals_single_order(gpu):
+    """N = 118 287 rows cut into 8 (and 3) rank shards by shard_bounds, zero-padded, stacked like all_gather_into_tensor
+    delivers them and unpacked: the very same matrix, hence the very same (D, I) — indices are global rows."""
+    from domain_rag_amd import ops
+    from domain_rag_amd.retrieval import pack_shard, shard_bounds, unpack_shards
+    N = 118287
+    g = torch.Generator(device=gpu).manual_seed(3)
+    corpus = torch.randn(N, 512, generator=g, device=gpu)
+    ops.l2_normalize_(corpus)
+    q = (corpus[[11, 59143, 118286]] + 0.05 * torch.randn(3, 512, generator=g, device=gpu)).contiguous()
+    D0, I0 = ops.cosine_topk(corpus, q, 100)
+    for W in (8, 3):
+        recv = torch.stack([pack_shard(corpus[slice(*shard_bounds(N, W, r))], N, W, r) for r in range(W)])
+        assert recv.shape[1] == shard_bounds(N, W, 0)[1]
+        again = unpack_shards(recv, N)
+        assert torch.equal(again, corpus)
+        D1, I1 = ops.cosine_topk(again.contiguous(), q, 100)
+        assert torch.equal(I1, I0) and torch.equal(D1, D0)
+
+
+def test_rccl_all_gather_call_path_on_this_gpu(gpu):
+    """backend "nccl" IS RCCL on ROCm: a one-rank communicator sends the shard through all_gather_into_tensor (force=True) —
+    the branch the 8-GPU run takes; N > 1 itself is the driver's scaling run and the gloo tests."""
+    import torch.distributed as dist
+    from domain_rag_amd.retrieval import allgather_rows
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    try:
+        x = torch.randn(1000, 512, device=gpu)
+        ones = torch.ones(1, device=gpu)
+        dist.all_reduce(ones)
+        assert ones.item() == 1.0
+        y = allgather_rows(x, 1000, force=True)
+        assert y is not x and torch.equal(y, x)
+        assert allgather_rows(x, 1000) is x
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scan_only_entry_matches_oracle_scores_bitwise(gpu):
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(5)
+    for N, Q in ((1000, 16), (4099, 3), (17, 1)):
+        corpus = rng.standard_normal((N, 512)).astype(np.float32)
+        corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
+        q = rng.standard_normal((Q, 512)).astype(np.float32)
+        sc = ops.cosine_scores(torch.from_numpy(corpus).to(gpu), torch.from_numpy(q).to(gpu))
+        assert sc.shape == (Q, (N + 63) // 64 * 64)
+        assert np.array_equal(sc[:, :N].cpu().numpy(), oret.ip_scores(corpus, q))
+    with pytest.raises(ValueError):
+        ops.cosine_scores(torch.zeros(10, 512, device=gpu)[:, :256], torch.zeros(1, 256, device=gpu))
+    with pytest.raises(RuntimeError):
+        ops.cosine_scores(torch.zeros(10, 512, device=gpu), torch.zeros(17, 512, device=gpu))
