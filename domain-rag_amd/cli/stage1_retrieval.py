@@ -23,6 +23,76 @@ RESULTS_DIR = "./retrieval_results"
 LAMAINPAINT_DIR = "../lamainpaint"
 
 
+CLIP_DEFAULT = os.path.join("~", ".cache", "clip", "ViT-B-32.pt")
+RESNET_DEFAULT = os.path.join("~", ".cache", "torch", "hub", "checkpoints", "resnet50-0676ba61.pth")
+
+
+def resolve_weights(args):
+    """(clip_weights_path | None, resnet_weights_path | None).  The reference loads pretrained CLIP ViT-B/32 and torchvision
+    IMAGENET1K_V1 weights by default (retrieval/clip100_resnet_style_all_shots.py:54,209); so does this CLI: explicit flag, then
+    the environment, then the libraries' own download caches.  Seeded random weights only with --synthetic-weights /
+    DRAG_SYNTHETIC_WEIGHTS=1 — never silently (a drop-in run would otherwise write a meaningless retrieval JSON)."""
+    synthetic = args.synthetic_weights or os.environ.get("DRAG_SYNTHETIC_WEIGHTS", "") not in ("", "0")
+    if synthetic:
+        if args.clip_weights or args.resnet_weights:
+            raise SystemExit("--synthetic-weights excludes --clip-weights / --resnet-weights")
+        return None, None
+    out = []
+    for flag, given, env, default, what in (("--clip-weights", args.clip_weights, "DRAG_CLIP_WEIGHTS", CLIP_DEFAULT, "CLIP ViT-B/32"),
+                                            ("--resnet-weights", args.resnet_weights, "DRAG_RESNET_WEIGHTS", RESNET_DEFAULT,
+                                             "torchvision resnet50 (IMAGENET1K_V1)")):
+        path = given or os.environ.get(env) or os.path.expanduser(default)
+        if not os.path.isfile(path):
+            raise SystemExit(f"stage 1: no {what} weights: {path} does not exist.  Pass {flag} <file> (or ${env}); "
+                             f"--synthetic-weights runs with seeded random weights instead (tests / benchmarks only).")
+        out.append(path)
+    return out[0], out[1]
+
+
+def tensor_fingerprint(tensors) -> str:
+    """short sha256 over the raw bytes of a few tensors (identifies a set of weights without hashing hundreds of MB)"""
+    import hashlib
+    h = hashlib.sha256()
+    for t in tensors:
+        a = t.detach().to("cpu", torch.float32).contiguous().numpy()
+        h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return h.hexdigest()[:16]
+
+
+def feature_cache_meta(model) -> dict:
+    """what a cached embedding matrix depends on besides the image files"""
+    return {"clip": getattr(model, "fingerprint", "unknown"), "precision": getattr(model, "precision", "unknown"),
+            "preprocess": "pil-bicubic-224-centercrop"}
+
+
+def style_cache_meta(stem) -> dict:
+    try:
+        import cv2  # noqa: F401
+        backend = "cv2"
+    except ImportError:
+        backend = "cv2-restated"
+    return {"stem": tensor_fingerprint([stem.state[k] for k in sorted(stem.state)]), "resize": backend}
+
+
+def _meta_path(cache_f: str) -> str:
+    return os.path.splitext(cache_f)[0] + ".meta.json"
+
+
+def local_cache_is_stale(cache_f: str, want: dict) -> bool:
+    """A local cache written by THIS CLI carries a side file with the weights / precision it was computed from; when that
+    differs from the running model the cache is stale.  A cache without a side file (written by the reference script, or copied
+    in) is taken as it is, like the reference takes it."""
+    mp = _meta_path(cache_f)
+    if not os.path.exists(mp):
+        return False
+    try:
+        with open(mp) as f:
+            have = json.load(f)
+    except Exception:
+        return True
+    return any(have.get(k) != v for k, v in want.items())
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="CLIP+ResNet图像检索 - 多shot版本 (MI355X)")
     p.add_argument("--datasets", type=str, nargs="+", default=["ArTaxOr", "DIOR", "FISH", "NEU-DET", "UODD", "clipart1k"])
@@ -44,8 +114,14 @@ def build_parser():
     # additions (not in the reference)
     p.add_argument("--clip-precision", choices=["fp32", "bf16"], default=None,
                    help="arithmetic of the CLIP tower: fp32 (default; what openai-CLIP computes on its CPU path) or the faster bf16 MFMA tower")
-    p.add_argument("--clip-weights", type=str, default=None, help="openai CLIP ViT-B/32 state_dict (.pt); default: synthetic")
-    p.add_argument("--resnet-weights", type=str, default=None, help="torchvision resnet50 state_dict (.pt); default: synthetic")
+    p.add_argument("--clip-weights", type=str, default=None,
+                   help="openai CLIP ViT-B/32 checkpoint (ViT-B-32.pt); default: $DRAG_CLIP_WEIGHTS, else openai-CLIP's own download "
+                        "cache ~/.cache/clip/ViT-B-32.pt (where the reference's clip.load() leaves it)")
+    p.add_argument("--resnet-weights", type=str, default=None,
+                   help="torchvision resnet50 state_dict; default: $DRAG_RESNET_WEIGHTS, else torchvision's hub cache "
+                        "~/.cache/torch/hub/checkpoints/resnet50-0676ba61.pth (IMAGENET1K_V1, what the reference loads)")
+    p.add_argument("--synthetic-weights", action="store_true",
+                   help="run with seeded random weights of the same architectures (tests / benchmarks; results are meaningless for retrieval)")
     p.add_argument("--embed-batch", type=int, default=256)
     p.add_argument("--no-visuals", action="store_true", help="skip the per-query *_visual.jpg contact sheets")
     p.add_argument("--decode-procs", type=int, default=-1,
@@ -145,7 +221,13 @@ def load_or_compute_features(args, tag, root, subdirs, pre_feats, pre_paths, mod
     cache_p = os.path.join(results_dir, f"{tag}_image_paths.json")
     glob_c = (os.path.join("..", f"{tag}_embeddings_global.pt"), os.path.join("..", "result_clip_vision", f"{tag}_embeddings_global.pt")) \
         if getattr(args, "global_features", False) else ()
-    hit = resolve_feature_cache(pre_feats, pre_paths, cache_f, cache_p, args.force_recompute, glob_c)
+    meta = feature_cache_meta(model)
+    if os.path.exists(cache_f) and local_cache_is_stale(cache_f, meta):
+        print(f"本地缓存特征与当前CLIP权重/精度不符，重新计算: {cache_f}")
+        cache_f_use, cache_p_use = cache_f + ".stale", cache_p + ".stale"        # names that do not exist: skips the local step
+    else:
+        cache_f_use, cache_p_use = cache_f, cache_p
+    hit = resolve_feature_cache(pre_feats, pre_paths, cache_f_use, cache_p_use, args.force_recompute, glob_c)
     if hit is not None:
         print(f"成功加载 {len(hit[0])} 个预提取特征")
         return np.asarray(hit[0], dtype=np.float32), hit[1]
@@ -162,6 +244,8 @@ def load_or_compute_features(args, tag, root, subdirs, pre_feats, pre_paths, mod
         np.save(cache_f, feats)
         with open(cache_p, "w") as fh:
             json.dump(valid, fh)
+        with open(_meta_path(cache_f), "w") as fh:
+            json.dump(meta, fh)
     return feats, valid
 
 
@@ -268,10 +352,11 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
     print(f"使用设备: {device}")
-    model, preprocess = R.load_clip("ViT-B/32", device, weights=args.clip_weights, precision=args.clip_precision)
+    clip_w, resnet_w = resolve_weights(args)
+    model, preprocess = R.load_clip("ViT-B/32", device, weights=clip_w, precision=args.clip_precision)
     if not args.host_preprocess:
         preprocess = R.load_clip_device_preprocess(device)
-    stem = R.StemStyle(torch.load(args.resnet_weights, map_location="cpu") if args.resnet_weights else None, device)
+    stem = R.StemStyle(torch.load(resnet_w, map_location="cpu") if resnet_w else None, device)
     feats, paths = {}, {}
     if args.dataset_source in ("coco", "both"):
         f, p = load_or_compute_features(args, "coco", args.coco_dir, None, args.pretrained_coco_features, args.pretrained_coco_paths,
@@ -289,10 +374,14 @@ def main(argv=None):
     all_shots: dict = {}
     style_cache: dict = {}
     sc_path = args.style_cache or os.path.join(results_dir, "style_cache.npz")
+    sc_meta = json.dumps(style_cache_meta(stem), sort_keys=True)
     if os.path.exists(sc_path):   # the reference recomputes all 100 candidates' style vectors for every query (:468-470)
         z = np.load(sc_path, allow_pickle=False)
-        style_cache = {p: f for p, f in zip(z["paths"].tolist(), z["feats"])}
-        print(f"已加载 {len(style_cache)} 个缓存的风格特征: {sc_path}")
+        if "meta" in z.files and str(z["meta"]) == sc_meta:
+            style_cache = {p: f for p, f in zip(z["paths"].tolist(), z["feats"])}
+            print(f"已加载 {len(style_cache)} 个缓存的风格特征: {sc_path}")
+        else:     # other stem weights or another resize backend produced these vectors: mixing them into the L2 re-rank is wrong
+            print(f"风格特征缓存与当前ResNet权重/缩放实现不符，已忽略: {sc_path}")
     if rank == 0:   # queries are few; the corpus embedding above is the sharded part
         for ds in args.datasets:
             all_shots[ds] = {}
@@ -304,7 +393,8 @@ def main(argv=None):
                 else:
                     print(f"跳过数据集 {ds} 的 {shot}_shot")
         if style_cache:
-            np.savez(sc_path, paths=np.array(list(style_cache), dtype=str), feats=np.stack(list(style_cache.values())))
+            np.savez(sc_path, paths=np.array(list(style_cache), dtype=str), feats=np.stack(list(style_cache.values())),
+                     meta=np.array(sc_meta))
         if any(all_shots.values()):
             out = os.path.join(results_dir, "all_shots_retrieval_results.json")
             with open(out, "w", encoding="utf-8") as f:

@@ -137,7 +137,7 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
         print(f"跳过数据集 {dataset} {shot}-shot，因为找不到样本")
         return 0, 0
     result_dir = f"{args.output_dir}/{dataset}_{shot}shot_retrieval"
-    ts = os.environ.get("DRAG_TIMESTAMP") or datetime.now().strftime("%Y%m%d_%H%M%S")
+    ts = run_timestamp(world)
     base = os.path.join(result_dir, f"results_coco_{COCO_IMAGE_SCALE}_target_{TARGET_IMAGE_SCALE}_cocotext_{COCO_TEXT_SCALE}"
                                     f"_targettext_{TARGET_TEXT_SCALE}_{ts}")
     os.makedirs(base, exist_ok=True)
@@ -191,6 +191,26 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
         f.write(f"成功处理样本数: {ok}\n失败处理样本数: {bad}\n总共生成图像数: {images}\n\n生成图像尺寸统计:\n\n完成时间: {stamp()}\n")
     print(f"数据集 {dataset} {shot}-shot处理完成：成功 {ok} 个样本，失败 {bad} 个样本，总共生成 {images} 张图像")
     return ok, bad
+
+
+def run_timestamp(world: int) -> str:
+    """the ``_<timestamp>`` suffix of a results directory (batch_generate_flux_kshot.py:798-802).  One process: now, like the
+    reference.  Several ranks of one launch must agree on ONE directory per dataset (each rank calling now() splits a dataset run
+    over directories whenever the ranks cross a second boundary): $DRAG_TIMESTAMP if the launcher exports one, else the start
+    time of the common parent process (the torch.distributed.run agent), which every rank reads identically from /proc."""
+    env = os.environ.get("DRAG_TIMESTAMP")
+    if env:
+        return env
+    if world > 1:
+        try:
+            with open(f"/proc/{os.getppid()}/stat") as f:
+                ticks = int(f.read().rsplit(")", 1)[1].split()[19])          # field 22: start time in clock ticks since boot
+            with open("/proc/stat") as f:
+                btime = next(int(ln.split()[1]) for ln in f if ln.startswith("btime"))
+            return datetime.fromtimestamp(btime + ticks / os.sysconf("SC_CLK_TCK")).strftime("%Y%m%d_%H%M%S")
+        except Exception as e:
+            print(f"警告：无法确定共享时间戳 ({e})；各进程的结果目录可能不同，请设置 DRAG_TIMESTAMP")
+    return datetime.now().strftime("%Y%m%d_%H%M%S")
 
 
 def main(argv=None):

@@ -129,6 +129,14 @@ def _draws(generator, seed_default, B, H, W, n):
     return [torch.randn((B, 16, H // 8, W // 8), generator=generator, dtype=torch.bfloat16) for _ in range(n)]
 
 
+def _step_hook(pipe, callback):
+    """diffusers' ``callback_on_step_end(pipe, step_index, timestep, {"latents": packed latents}) -> dict``: observers only
+    (the returned dict is ignored; the reference passes no callback)"""
+    if callback is None:
+        return None
+    return lambda i, latents: callback(pipe, i, None, {"latents": latents})
+
+
 class _FluxPipe(_Pipe):
     _kind = "dev"
 
@@ -163,7 +171,7 @@ class FluxPipeline(_FluxPipe):
         self.pipe = E.FluxTxt2ImgHIP(self.tr, self.vae)
 
     def __call__(self, prompt=None, guidance_scale=3.5, num_inference_steps=28, height=1024, width=1024, generator=None,
-                 prompt_embeds=None, pooled_prompt_embeds=None, **_):
+                 prompt_embeds=None, pooled_prompt_embeds=None, callback_on_step_end=None, **_):
         self._require()
         if prompt_embeds is None or pooled_prompt_embeds is None:
             raise ValueError("prompt_embeds and pooled_prompt_embeds are required (the reference always passes the Redux prior's)")
@@ -171,7 +179,7 @@ class FluxPipeline(_FluxPipe):
         height, width = height // 16 * 16, width // 16 * 16
         noise = E.pack_noise(_draws(generator, 0, B, height, width, 1)[0])
         out = self.pipe(prompt_embeds, pooled_prompt_embeds, height=height, width=width, guidance_scale=guidance_scale,
-                        num_inference_steps=num_inference_steps, noise_tokens=noise)
+                        num_inference_steps=num_inference_steps, noise_tokens=noise, on_step=_step_hook(self, callback_on_step_end))
         return PipelineOutput(self._to_pil(out))
 
 
@@ -183,7 +191,8 @@ class FluxFillPipeline(_FluxPipe):
         self.pipe = FluxFillHIP(self.tr, self.vae)
 
     def __call__(self, prompt=None, image=None, mask_image=None, height=1024, width=1024, guidance_scale=30.0,
-                 num_inference_steps=50, prompt_embeds=None, pooled_prompt_embeds=None, generator=None, strength=1.0, **_):
+                 num_inference_steps=50, prompt_embeds=None, pooled_prompt_embeds=None, generator=None, strength=1.0,
+                 callback_on_step_end=None, **_):
         from PIL import Image
         self._require()
         if image is None or mask_image is None:
@@ -208,7 +217,8 @@ class FluxFillPipeline(_FluxPipe):
         enc_n, noise, menc_n = _draws(generator, 0, 1, H16, W16, 3)       # draw order of FluxFillPipeline.__call__
         out = self.pipe(img_u8, msk_u8, prompt_embeds, pooled_prompt_embeds, guidance_scale=guidance_scale,
                         num_inference_steps=num_inference_steps, strength=strength, enc_noise=enc_n.to(self.device),
-                        masked_enc_noise=menc_n.to(self.device), noise_tokens=E.pack_noise(noise).to(self.device))
+                        masked_enc_noise=menc_n.to(self.device), noise_tokens=E.pack_noise(noise).to(self.device),
+                        on_step=_step_hook(self, callback_on_step_end))
         return PipelineOutput(self._to_pil(out))
 
 

@@ -128,7 +128,9 @@ class FluxTxt2ImgHIP:
         self.tr, self.vae, self.dev, self.use_graph = transformer, vae, transformer.device, use_graph
 
     def __call__(self, prompt_embeds, pooled, *, height: int, width: int, guidance_scale: float, num_inference_steps: int,
-                 noise_tokens: torch.Tensor) -> torch.Tensor:
+                 noise_tokens: torch.Tensor, on_step=None) -> torch.Tensor:
+        """``on_step(i, latents)``: called after every Euler update with a bf16 [B, n_tok, 64] COPY of the packed latents
+        (what diffusers hands ``callback_on_step_end`` as ``latents``); used by scripts/accept_real_weights.py"""
         B = prompt_embeds.shape[0]
         h, w = height // 16, width // 16
         key = (B, h, w, prompt_embeds.shape[1])
@@ -146,6 +148,8 @@ class FluxTxt2ImgHIP:
             fwd = self.tr.forward_graphed if self.use_graph else self.tr.forward
             v = fwd(lat, prompt_embeds, pooled, t, img_ids, txt_ids, guidance)
             ops.flow_euler_rows(lat, v, B * h * w, 64, 64, 64, float(sigmas[i + 1] - sigmas[i]))
+            if on_step is not None:
+                on_step(i, lat.clone())
         return self.vae.decode_tokens(lat, B, h, w, ld=64).clone()      # the decoder's buffer is reused by the next call
 
 

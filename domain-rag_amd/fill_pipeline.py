@@ -46,7 +46,7 @@ class FluxFillHIP:
 
     def __call__(self, image_u8: torch.Tensor, mask_u8: torch.Tensor, prompt_embeds: torch.Tensor, pooled: torch.Tensor, *,
                  guidance_scale: float, num_inference_steps: int, strength: float, enc_noise: torch.Tensor | None,
-                 masked_enc_noise: torch.Tensor | None, noise_tokens: torch.Tensor, recorder=None) -> torch.Tensor:
+                 masked_enc_noise: torch.Tensor | None, noise_tokens: torch.Tensor, recorder=None, on_step=None) -> torch.Tensor:
         """image_u8 [B,H,W,3], mask_u8 [B,H,W] (255 = repaint), prompt_embeds bf16 [B,L,4096], pooled bf16 [B,768];
         enc_noise / masked_enc_noise bf16 [B,16,H/8,W/8] (generator draws for the two VAE posterior samples, None =
         mode); noise_tokens bf16 [B, n_tok, 64] (packed generator noise).  Returns uint8 RGB [B,H,W,3] on device."""
@@ -75,6 +75,8 @@ class FluxFillHIP:
                 fwd = self.tr.forward_graphed if (self.use_graph and not timed) else self.tr.forward
                 v = fwd(hidden, prompt_embeds, pooled, t, self._img_ids, self._txt_ids, guidance)
                 ops.flow_euler_rows(hv, v, B * Si, 64, C, 64, float(sigmas[i + 1] - sigmas[i]))
+                if on_step is not None:       # diffusers' callback_on_step_end sees the packed latents after the update
+                    on_step(i, hidden[:, :, :64].clone())
             ops.set_recorder(recorder)
             return self.vae.decode_tokens(hv, B, h, w, ld=C).clone()      # the decoder's buffer is reused by the next call
         finally:

@@ -51,7 +51,11 @@ class ReduxPriorHIP:
         T, Dv = self.vit.cfg.tokens, self.vit.cfg.hidden
         Lt, Dt, P = t5_embeds.shape[0], self.txt_dim, pooled.shape[-1]
         L = Lt + T
-        key = (n, Lt, P, t5_embeds.data_ptr(), pooled.data_ptr())
+        if N < 1 or n % N != 0:
+            raise ValueError(f"{n} images do not split into prior calls of group={N}")
+        if len(embeds_scale) != N or len(pooled_scale) != N:
+            raise ValueError(f"need {N} scales per prior call (got {len(embeds_scale)} / {len(pooled_scale)})")
+        key = (n, N, Lt, P, t5_embeds.data_ptr(), pooled.data_ptr())     # N: the output buffers are sized by G = n / N
         bf = dict(dtype=torch.bfloat16, device=self.dev)
         if self._key != key:
             slab = torch.empty((n, L, Dt), **bf)

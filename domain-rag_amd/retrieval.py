@@ -148,7 +148,16 @@ def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None 
     else:
         g = init_generic_params(cfg, seed, device=device if str(device) != "cpu" else "cpu")
     tower = ClipVitF32HIP(cfg, g, device) if precision == "fp32" else VitHIP(cfg, g, device)
-    return ClipImageModel(tower), clip_preprocess
+    model = ClipImageModel(tower)
+    # identity of what an embedding depends on (stage 1 stores it next to its feature caches)
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("proj", "patch.weight", "ln_post.weight"):
+        a = g[name].detach().to("cpu", torch.float32).contiguous().numpy()
+        h.update(name.encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    model.fingerprint = ("synthetic-seed%d-" % seed if weights is None else "") + h.hexdigest()[:16]
+    model.precision = precision
+    return model, clip_preprocess
 
 
 def load_clip_device_preprocess(device="cuda"):

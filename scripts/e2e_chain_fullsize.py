@@ -54,7 +54,7 @@ def main():
                   open(os.path.join(root, f"datasets/{ds}/annotations/1_shot.json"), "w"))
         t0, _ = run("domain_rag_amd.cli.stage0_lama", ["--datasets", ds, "--shots", "1", "--synthetic-weights"], os.path.join(root, "lama_inpaint"))
         assert Image.open(os.path.join(root, "lamainpaint", ds, "1_shot", "insect_00.jpg")).size == (504, 376)
-        t1, _ = run("domain_rag_amd.cli.stage1_retrieval", ["--datasets", ds, "--shots", "1", "--coco-dir", "./coco", "--pretrained-coco-features", "none.pt"],
+        t1, _ = run("domain_rag_amd.cli.stage1_retrieval", ["--datasets", ds, "--shots", "1", "--coco-dir", "./coco", "--pretrained-coco-features", "none.pt", "--synthetic-weights"],
                     os.path.join(root, "retrieval"))
         rr = os.path.join(root, "retrieval", "retrieval_results")
         top = json.load(open(os.path.join(rr, "all_shots_retrieval_results.json")))[ds]["1_shot"]["insect_00"][0]["similar_images"]

@@ -47,7 +47,7 @@ def test_three_stages_on_mini_dataset(gpu, tmp_path):
 
     # ---- stage 1 (run from ./retrieval like domainrag.sh)
     _run("domain_rag_amd.cli.stage1_retrieval", ["--datasets", ds, "--shots", "1", "--coco-dir", "./coco", "--clip-top-k", "6",
-                                                 "--pretrained-coco-features", "none.pt"], cwd=root / "retrieval")
+                                                 "--pretrained-coco-features", "none.pt", "--synthetic-weights"], cwd=root / "retrieval")
     rr = root / "retrieval" / "retrieval_results"
     allr = json.load(open(rr / "all_shots_retrieval_results.json"))
     entry = allr[ds]["1_shot"]["beetle_01"][0]
