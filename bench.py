@@ -170,6 +170,25 @@ def launcher_selftest(args, d: Dist) -> None:
 
 
 # ----------------------------------------------------------------------------------------------- CPU baselines
+def _pick_threads() -> int:
+    """torch's CPU kernels stop scaling (and then slow down: 256 threads ran the CLIP tower 4x slower than 64) well before a
+    256-core host is full; probe one GEMM at a few thread counts and keep the fastest.  `cores` in the JSON = this number."""
+    cores = os.cpu_count() or 1
+    a, b = torch.randn(2048, 3072), torch.randn(3072, 3072)
+    best, best_t = cores, float("inf")
+    for n in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 32)}, reverse=True):
+        torch.set_num_threads(n)
+        a @ b
+        t0 = time.perf_counter()
+        for _ in range(3):
+            a @ b
+        t = time.perf_counter() - t0
+        if t < best_t:
+            best, best_t = n, t
+    torch.set_num_threads(best)
+    return best
+
+
 def _median_time(fn, repeats=3):
     ts = []
     for _ in range(repeats):
@@ -190,8 +209,7 @@ def cpu_baseline_generate(res: int, denoise_steps: int):
     from oracle import vit as ovit
     from domain_rag_amd import redux as redux_mod, vae as vae_mod, vit as vit_mod
     from domain_rag_amd.flux_params import FluxConfig, init_params
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    _pick_threads()
     cfg = FluxConfig(in_channels=384, num_layers=1, num_single_layers=1)
     p = init_params(cfg, seed=0)
     ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
@@ -249,8 +267,7 @@ def cpu_baseline_retrieval(topk: int, budget_s: float = 60.0):
     from oracle import retrieval as oret
     from oracle import vit as ovit
     from domain_rag_amd import vit as vit_mod
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    _pick_threads()
     n_img, bs = 1000, 50
     rng = np.random.default_rng(0)
     vc = vit_mod.VitConfig.clip_vit_b32()

@@ -51,6 +51,8 @@ SIGNATURES = {
     "drag_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     "drag_qk_norm_rope_vt_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "drag_attention_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float, c_void_p]),
+    "drag_k_norm_rope_vt_bf16": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
+    "drag_attention_qprep_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float] + [c_void_p] * 4 + [c_int, c_float, c_void_p]),
     "drag_layernorm_modulate_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_int64, c_int, c_int, c_float, c_void_p]),
     "drag_act_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "drag_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

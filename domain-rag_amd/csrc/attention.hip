@@ -29,6 +29,7 @@ struct PrepArgs {
   const float *cosT, *sinT;
   int B, S, H, ld, s_txt, s_pad;
   float eps;
+  int skip_q;      // q is normalised / rotated by the attention kernel as it loads its Q fragments (drag_attention_qprep_bf16)
 };
 
 __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(PrepArgs p) {
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(PrepArgs p) {
   if (do_norm || do_rope)
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
+    if (which == 0 && p.skip_q) continue;
     for (int it = 0; it < 4; ++it) {
       const int s = s0 + it * 16 + rloc;
       const bool ok = s < p.S;
@@ -128,6 +130,11 @@ struct AttnArgs {
   long long qk_bs, o_bs;
   float c;  // scale * log2(e)
   unsigned k_bytes, vt_bytes;
+  // optional Q preparation fused into the fragment load (all null / 0 = q is used as stored):
+  const bf16_t *wq_txt, *wq_img;   // RMSNorm weights [128] of the text / image stream (rows < s_txt are text)
+  const float *cosT, *sinT;        // RoPE tables [S, 64]
+  int s_txt;
+  float eps;
 };
 
 constexpr float DEFER_THR = 8.0f;     // log2 units; 0 = rescale on every increase (classic online softmax)
@@ -157,6 +164,51 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     const bf16_t* qp = p.q + (long long)b * p.qk_bs + (long long)qr * p.ld_qk + h * 128 + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
+    if (p.wq_txt != nullptr || p.cosT != nullptr) {
+      // per-head RMSNorm(128) + interleaved RoPE of this lane's query row, with the rounding points of the separate pass
+      // (qk_norm_rope_vt_kernel): rbf(rbf(x * rs) * w), rotation in fp32, one rounding to bf16.  The lane holds 64 of the
+      // row's 128 elements (d = 16 ks + 8 hh + 0..7), lane ^ 32 the other 64; RoPE pairs (2j, 2j+1) never straddle lanes.
+      u32x4_t raw[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) raw[ks] = __builtin_bit_cast(u32x4_t, qf[ks]);
+      float rs = 1.f;
+      const bf16_t* wsel = nullptr;
+      if (p.wq_txt != nullptr) {
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+            ss += a0 * a0;
+            ss += a1 * a1;
+          }
+        ss += __shfl_xor(ss, 32, 64);
+        rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
+        wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        u32x4_t wr = (u32x4_t){0u, 0u, 0u, 0u};
+        if (wsel != nullptr) wr = *(const u32x4_t*)(wsel + ks * 16);
+        f32x4_t c4 = (f32x4_t){1.f, 1.f, 1.f, 1.f}, s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (p.cosT != nullptr) {
+          c4 = *(const f32x4_t*)(p.cosT + (long long)qr * 64 + ks * 8 + hh * 4);
+          s4 = *(const f32x4_t*)(p.sinT + (long long)qr * 64 + ks * 8 + hh * 4);
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+          if (wsel != nullptr) {
+            a0 = rbf(rbf(a0 * rs) * bf2f((bf16_t)(wr[j] & 0xffff)));
+            a1 = rbf(rbf(a1 * rs) * bf2f((bf16_t)(wr[j] >> 16)));
+          }
+          o[j] = pack2bf(a0 * c4[j] - a1 * s4[j], a1 * c4[j] + a0 * s4[j]);
+        }
+        qf[ks] = __builtin_bit_cast(bf16x8_t, o);
+      }
+    }
   }
 
   // ---- staging descriptors ----
@@ -394,14 +446,61 @@ extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt
   p.wq_img = (const bf16_t*)wq_img; p.wk_img = (const bf16_t*)wk_img;
   p.cosT = rope_cos; p.sinT = rope_sin;
   p.B = B; p.S = S; p.H = H; p.ld = ld; p.s_txt = s_txt; p.s_pad = (S + 63) / 64 * 64; p.eps = eps;
+  p.skip_q = 0;
   hipLaunchKernelGGL(qk_norm_rope_vt_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, p);
   DRAG_LAUNCH_CHECK();
   return 0;
 }
 
+// k and v only: the q third of the pass (a read + a write of M x D) moves into the attention kernel's fragment load
+extern "C" int drag_k_norm_rope_vt_bf16(void* qkv, void* vt, const void* wk_txt, const void* wk_img, const float* rope_cos,
+                                        const float* rope_sin, int32_t B, int32_t S, int32_t H, int32_t ld, int32_t s_txt,
+                                        float eps, void* stream) {
+  DRAG_CHECK(qkv && vt, "drag_k_norm_rope_vt_bf16: null pointer");
+  DRAG_CHECK((wk_txt == nullptr) == (wk_img == nullptr), "drag_k_norm_rope_vt_bf16: norm weights come in pairs");
+  DRAG_CHECK((rope_cos == nullptr) == (rope_sin == nullptr), "drag_k_norm_rope_vt_bf16: cos/sin come in pairs");
+  DRAG_CHECK(B > 0 && S > 0 && H > 0 && ld >= 3 * H * 128 && ld % 8 == 0, "drag_k_norm_rope_vt_bf16: bad shape");
+  PrepArgs p;
+  p.qkv = (bf16_t*)qkv; p.vt = (bf16_t*)vt;
+  p.wq_txt = (const bf16_t*)wk_txt; p.wk_txt = (const bf16_t*)wk_txt;      // wq_* only flags "normalise" in the kernel
+  p.wq_img = (const bf16_t*)wk_img; p.wk_img = (const bf16_t*)wk_img;
+  p.cosT = rope_cos; p.sinT = rope_sin;
+  p.B = B; p.S = S; p.H = H; p.ld = ld; p.s_txt = s_txt; p.s_pad = (S + 63) / 64 * 64; p.eps = eps;
+  p.skip_q = 1;
+  hipLaunchKernelGGL(qk_norm_rope_vt_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, p);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int attention_launch(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S, int32_t H,
+                            int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
+                            const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt,
+                            float eps, void* stream);
+
 extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S,
                                    int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
                                    int64_t o_batch_stride, float scale, void* stream) {
+  return attention_launch(q, k, vt, out, B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale, nullptr, nullptr, nullptr,
+                          nullptr, 0, 0.f, stream);
+}
+
+// attention whose Q operand is the RAW q projection: per-head RMSNorm (weights wq_txt for rows < s_txt, wq_img after) and
+// RoPE are applied while the Q fragments are loaded (FluxAttnProcessor2_0: norm_q / norm_added_q + apply_rotary_emb)
+extern "C" int drag_attention_qprep_bf16(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S,
+                                         int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
+                                         int64_t o_batch_stride, float scale, const void* wq_txt, const void* wq_img,
+                                         const float* rope_cos, const float* rope_sin, int32_t s_txt, float eps, void* stream) {
+  DRAG_CHECK((wq_txt == nullptr) == (wq_img == nullptr), "drag_attention_qprep_bf16: norm weights come in pairs");
+  DRAG_CHECK((rope_cos == nullptr) == (rope_sin == nullptr), "drag_attention_qprep_bf16: cos/sin come in pairs");
+  DRAG_CHECK(s_txt >= 0 && s_txt <= S, "drag_attention_qprep_bf16: 0 <= s_txt <= S");
+  return attention_launch(q, k, vt, out, B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale, wq_txt, wq_img, rope_cos,
+                          rope_sin, s_txt, eps, stream);
+}
+
+static int attention_launch(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S, int32_t H,
+                            int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
+                            const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt,
+                            float eps, void* stream) {
   DRAG_CHECK(q && k && vt && out, "drag_attention_bf16: null pointer");
   DRAG_CHECK(B > 0 && S > 0 && H > 0, "drag_attention_bf16: bad shape");
   DRAG_CHECK(ld_qk % 8 == 0 && ld_o % 4 == 0, "drag_attention_bf16: ld_qk %% 8, ld_o %% 4 required");
@@ -410,6 +509,8 @@ extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt,
   p.B = B; p.S = S; p.H = H; p.ld_qk = ld_qk; p.ld_o = ld_o; p.s_pad = (S + 63) / 64 * 64;
   p.qk_bs = qk_batch_stride; p.o_bs = o_batch_stride;
   p.c = scale * 1.4426950408889634f;
+  p.wq_txt = (const bf16_t*)wq_txt; p.wq_img = (const bf16_t*)wq_img; p.cosT = rope_cos; p.sinT = rope_sin;
+  p.s_txt = s_txt; p.eps = eps;
   const long long kspan = ((long long)(S - 1) * ld_qk + 128) * 2;
   const long long vspan = (long long)128 * p.s_pad * 2;
   DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");

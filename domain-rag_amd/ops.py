@@ -158,6 +158,30 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
                                   o_batch_stride, scale, _stream()), "drag_attention_bf16")
 
 
+def k_norm_rope_vt(qkv: torch.Tensor, vt: torch.Tensor, wk_txt, wk_img, rope_cos, rope_sin, B: int, S: int, H: int, ld: int,
+                   s_txt: int, eps: float = 1e-6) -> None:
+    """k RMSNorm + RoPE in place and V -> V^T; q is left as projected (``attention_qprep`` prepares it on load)"""
+    lib = _lib.load()
+    _need(qkv, torch.bfloat16, "qkv")
+    _need(vt, torch.bfloat16, "vt")
+    check(lib.drag_k_norm_rope_vt_bf16(_p(qkv), _p(vt), _p(wk_txt), _p(wk_img), _p(rope_cos), _p(rope_sin), B, S, H, ld, s_txt,
+                                       eps, _stream()), "drag_k_norm_rope_vt_bf16")
+
+
+def attention_qprep(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, ld_qk: int,
+                    qk_batch_stride: int, ld_o: int, o_batch_stride: int, scale: float, wq_txt, wq_img, rope_cos, rope_sin,
+                    s_txt: int, eps: float = 1e-6) -> None:
+    """attention over the RAW q projection: norm_q + RoPE are applied to each query row as its fragments are loaded"""
+    lib = _lib.load()
+    _need(q, torch.bfloat16, "q")
+    _need(out, torch.bfloat16, "out")
+    if rope_cos is not None:
+        _need(rope_cos, torch.float32, "rope_cos")
+    check(lib.drag_attention_qprep_bf16(_p(q), _p(k), _p(vt), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale,
+                                        _p(wq_txt), _p(wq_img), _p(rope_cos), _p(rope_sin), s_txt, eps, _stream()),
+          "drag_attention_qprep_bf16")
+
+
 def layernorm(x: torch.Tensor, y: torch.Tensor, M: int, D: int, *, scale=None, shift=None, gamma=None, beta=None,
               ldx: int | None = None, rows_per_batch: int = 0, x_batch_stride: int = 0, ldy: int | None = None,
               ld_mod: int = 0, eps: float = 1e-6) -> torch.Tensor:

@@ -110,6 +110,20 @@ int drag_attention_bf16(const void* q, const void* k, const void* vt, void* out,
                         int32_t S, int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
                         int64_t o_batch_stride, float scale, void* stream);
 
+/* The q third of drag_qk_norm_rope_vt_bf16 fused into the attention kernel (one read + one write of [M, D] less per
+ * attention): drag_k_norm_rope_vt_bf16 normalises / rotates k and writes V^T only, and drag_attention_qprep_bf16 takes
+ * the RAW q projection and applies norm_q / norm_added_q (rows < s_txt: wq_txt, else wq_img; both NULL = none) and
+ * apply_rotary_emb (rope_cos / rope_sin f32 [S, 64]; both NULL = none) to each query row while it loads its fragments,
+ * with the rounding points of the separate pass.  FluxAttnProcessor2_0 as reached from batch_generate_flux_kshot.py:467-474,
+ * outpainting_updown_sampling_redux.py:1246-1257. */
+int drag_k_norm_rope_vt_bf16(void* qkv, void* vt, const void* wk_txt, const void* wk_img, const float* rope_cos,
+                             const float* rope_sin, int32_t B, int32_t S, int32_t H, int32_t ld, int32_t s_txt,
+                             float eps, void* stream);
+int drag_attention_qprep_bf16(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S, int32_t H,
+                              int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
+                              const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin,
+                              int32_t s_txt, float eps, void* stream);
+
 /* drag_layernorm_modulate_bf16 — y = LN(x) * (1 + scale[b]) + shift[b]   (no affine LN, eps given)
  * or, with gamma/beta != NULL, y = LN(x) * gamma + beta (affine LayerNorm, scale/shift NULL).
  * Replaces AdaLayerNormZero / AdaLayerNormZeroSingle / AdaLayerNormContinuous and nn.LayerNorm.

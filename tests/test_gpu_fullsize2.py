@@ -27,14 +27,20 @@ def _rand(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale).bfloat16()
 
 
-VAE_TOL = 1e-2          # max |HIP - fp32 oracle| / max |oracle|, decoded image in [0,1] and packed latents alike
-PIXEL_TOL = 3           # uint8 levels: 1e-2 of full scale = 2.55, rounded up
+ORACLE_THREADS = 64      # the oracle's convolutions / GEMMs scale badly past this on a 256-core host (measured: 4x slower at 256)
 
 
-def test_vae_full_size_decode_and_encodes_vs_fp32_oracle(gpu):
+def _tol(e_bf16_oracle, floor):
+    """The reference computes in torch.bfloat16 (batch_generate_flux_kshot.py:49, outpainting_updown_sampling_redux.py:28), so
+    its own arithmetic sits e_bf16_oracle away from the float32 truth (2e-2 for the VAE with random weights — measured,
+    scripts/explore_fullsize_errors.py).  Stated bar: HIP within max(floor, 2.5 x that distance) of float32."""
+    return max(floor, 2.5 * e_bf16_oracle)
+
+
+def test_vae_full_size_decode_and_encodes_vs_oracle(gpu):
     from domain_rag_amd import vae
     from oracle import vae as ov
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, ORACLE_THREADS))
     cfg = vae.VaeConfig()                      # (128, 256, 512, 512), 2 layers per block: the FLUX.1 VAE
     p = vae.init_params(cfg, seed=3)
     p32 = {k: v.float() for k, v in p.items()}
@@ -46,17 +52,17 @@ def test_vae_full_size_decode_and_encodes_vs_fp32_oracle(gpu):
     assert (H, W) == (1024, 1024)
     got = (rows.view(B, H, W, -1)[..., :3].float().cpu() / 2 + 0.5).clamp(0, 1).permute(0, 3, 1, 2)
     img_u8 = img_u8.cpu()
-    with torch.no_grad():
-        for b in range(B):                     # one image at a time bounds the oracle's memory (the 16 384^2 score matrix)
-            _, ref32 = ov.decode_tokens_to_u8(p32, tok[b:b + 1].float(), h, w)
-            e = _rel(got[b:b + 1], ref32)
-            assert e < VAE_TOL, ("decode", b, e)
-            d = (img_u8[b].int() - (ref32[0].permute(1, 2, 0) * 255).round().int()).abs()
-            assert d.max().item() <= PIXEL_TOL, ("pixels", b, d.max().item(), (d > 1).float().mean().item())
-            del ref32
-    # image 1 of the batch == the same image decoded alone (per-image arithmetic is independent of the batch)
+    with torch.no_grad():                      # image 0 against both oracles (image 1: bit-identity with a single-image run below)
+        _, ref32 = ov.decode_tokens_to_u8(p32, tok[:1].float(), h, w)
+        _, refbf = ov.decode_tokens_to_u8(p, tok[:1], h, w)
+    e, e_or = _rel(got[:1], ref32), _rel(refbf, ref32)
+    assert e < _tol(e_or, 1e-2), ("decode", e, e_or)
+    d = (img_u8[0].int() - (ref32[0].permute(1, 2, 0) * 255).round().int()).abs()
+    assert d.max().item() <= max(3.0, 255 * 2.5 * e_or), ("pixels", d.max().item(), e_or)
+    assert d.float().mean().item() < 1.0, d.float().mean().item()          # on average well under one level
+    del ref32, refbf
     alone = model.decode_tokens(tok[1:2].to(gpu), 1, h, w).cpu()
-    assert torch.equal(alone[0], img_u8[1])
+    assert torch.equal(alone[0], img_u8[1]), "image 1 of the batch must equal the same image decoded alone"
 
     # ---- encodes: posterior mode of the plain image, and a sampled posterior of the masked image (the two Fill encodes)
     g = torch.Generator().manual_seed(7)
@@ -67,33 +73,40 @@ def test_vae_full_size_decode_and_encodes_vs_fp32_oracle(gpu):
         toks = torch.empty((B, h * w, 64), dtype=torch.bfloat16, device=gpu)
         model.encode_to_tokens(img.to(gpu), mask.to(gpu) if use_mask else None, None if nz is None else nz.to(gpu), toks, 64)
         toks = toks.cpu()
+        one = torch.empty((1, h * w, 64), dtype=torch.bfloat16, device=gpu)
+        model.encode_to_tokens(img[1:2].to(gpu), mask[1:2].to(gpu) if use_mask else None, None if nz is None else nz[1:2].to(gpu), one, 64)
+        assert torch.equal(one.cpu()[0], toks[1])
         with torch.no_grad():
-            for b in range(B):
-                x = ov.preprocess_image(img[b:b + 1])
-                if use_mask:
-                    x = x * (1 - ov.preprocess_mask(mask[b:b + 1]))
-                ref = ov.pack_latents(ov.sample_latents(ov.encode_moments(p32, x), None if nz is None else nz[b:b + 1].float()))
-                e = _rel(toks[b:b + 1], ref)
-                assert e < 1.5e-2, ("encode", use_mask, b, e)
+            x = ov.preprocess_image(img[:1])
+            if use_mask:
+                x = x * (1 - ov.preprocess_mask(mask[:1]))
+            ref = ov.pack_latents(ov.sample_latents(ov.encode_moments(p32, x), None if nz is None else nz[:1].float()))
+            refb = ov.pack_latents(ov.sample_latents(ov.encode_moments(p, x.bfloat16()), None if nz is None else nz[:1]))
+        e, e_or = _rel(toks[:1], ref), _rel(refb, ref)
+        assert e < _tol(e_or, 1.5e-2), ("encode", use_mask, e, e_or)
 
 
 def test_siglip_so400m_full_config_vs_transformers(gpu):
     from domain_rag_amd import vit
     from oracle import vit as ov
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, ORACLE_THREADS))
     cfg = vit.VitConfig.siglip_so400m()
     assert (cfg.hidden, cfg.layers, cfg.heads, cfg.intermediate, cfg.image_size, cfg.patch_size) == (1152, 27, 16, 4304, 384, 14)
     g = vit.init_generic_params(cfg, 11)
     img = (torch.rand(2, 384, 384, 3, generator=torch.Generator().manual_seed(2)) * 255).to(torch.uint8)
     px = ov.normalize_u8(img, cfg.mean, cfg.std)
-    ref32 = ov.siglip_last_hidden_state(g, 384, 14, 1152, 16, 27, 4304, px, torch.float32)
     out = vit.VitHIP(cfg, g, gpu)(img.to(gpu))
     assert out.shape == (2, 729, 1152)
-    e = _rel(out, ref32)
-    # bf16 tower (the reference runs SigLIP in torch.bfloat16: batch_generate_flux_kshot.py:49,139) vs the float32 model
-    assert e < 2e-2, e
-    # the mean error is what the Redux MLP sees: far below the max
-    assert ((out.float().cpu() - ref32).abs().mean() / ref32.abs().mean()).item() < 1e-2
+    ref32 = ov.siglip_last_hidden_state(g, 384, 14, 1152, 16, 27, 4304, px[:1], torch.float32)
+    refbf = ov.siglip_last_hidden_state(g, 384, 14, 1152, 16, 27, 4304, px[:1], torch.bfloat16)
+    # the reference runs SigLIP in torch.bfloat16 (batch_generate_flux_kshot.py:49,139): bar = 2.5 x its own distance from fp32
+    e, e_or = _rel(out[:1], ref32), _rel(refbf, ref32)
+    assert e < _tol(e_or, 1.5e-2), (e, e_or)
+    m = ((out[:1].float().cpu() - ref32).abs().mean() / ref32.abs().mean()).item()
+    m_or = ((refbf.float() - ref32).abs().mean() / ref32.abs().mean()).item()
+    assert m < max(1e-2, 1.5 * m_or), (m, m_or)
+    # image 1 of the batch == image 1 alone
+    assert torch.equal(vit.VitHIP(cfg, g, gpu)(img[1:2].to(gpu))[0], out[1])
 
 
 def test_full_size_dit_blocks_batch8_rows_are_images(gpu):
@@ -102,7 +115,7 @@ def test_full_size_dit_blocks_batch8_rows_are_images(gpu):
     from domain_rag_amd.flux import FluxTransformerHIP, latent_image_ids
     from domain_rag_amd.flux_params import FluxConfig, init_params
     from oracle import flux as oflux
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 128))
     cfg = FluxConfig(in_channels=384, num_layers=1, num_single_layers=1)
     params = init_params(cfg, seed=21)
     g = torch.Generator().manual_seed(22)

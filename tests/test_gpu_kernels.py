@@ -172,6 +172,21 @@ def _attn_case(gpu, B, S, H, s_txt, seed, spike=False):
     ref2 = ops_ref.attention_ref_f64(got_q, got_k, v, scale)
     assert _rel(o, ref2) < 1.5e-2
     assert _rel(o, ref) < 3e-2
+    # ---- fused route (the DiT's): k / v prepared by the pass, q normalised + rotated inside the attention kernel's Q load
+    qf = qkv.to(gpu).clone()
+    vt2 = torch.full((B, H, 128, s_pad), float("nan"), dtype=torch.bfloat16, device=gpu)
+    ops.k_norm_rope_vt(qf, vt2, cwk.to(gpu), wk.to(gpu), cos.to(gpu), sin.to(gpu), B, S, H, 3 * D, s_txt)
+    assert torch.equal(qf.cpu()[..., :D], qkv[..., :D]), "q must be left as projected"
+    assert torch.equal(qf.cpu()[..., D:], qd.cpu()[..., D:]) and torch.equal(vt2.cpu(), vt.cpu()), "k / V^T: same bits as the two-pass route"
+    out2 = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
+    ops.attention_qprep(qf, qf.view(-1)[D:], vt2, out2, B, S, H, 3 * D, S * 3 * D, D, S * D, scale, cwq.to(gpu), wq.to(gpu),
+                        cos.to(gpu), sin.to(gpu), s_txt)
+    o2 = out2.cpu()
+    assert torch.isfinite(o2.float()).all()
+    assert _rel(o2, ref) < 3e-2
+    # against the two-pass output: only the summation order of the 128 squares differs (an occasional bf16 ulp of a q element)
+    assert _rel(o2, o) < 4e-3, _rel(o2, o)
+    assert (o2 == o).float().mean().item() > 0.9
 
 
 @pytest.mark.parametrize("B,S,H,s_txt", [(1, 64, 1, 0), (2, 200, 2, 24), (1, 333, 3, 77), (1, 1241 + 256, 2, 1241), (1, 4300, 2, 100)])
