@@ -1,0 +1,197 @@
+// jpeg.hip — baseline JPEG files -> RGB pixels on gfx950, byte-identical to PIL / libjpeg-turbo (arithmetic: jpeg_core.h).
+//
+// Replaces the `Image.open(path).convert("RGB")` the reference pays per corpus image before CLIP's preprocess
+// (retrieval/clip100_resnet_style_all_shots.py:270-281) — SURVEY §8(f)-2: once the tower embeds 11 k images/s, libjpeg on the
+// host cores (3.8 k images/s with 32 worker processes) is what bounds stage 1.
+//
+// The host only reads the files: a batch is one byte blob + offsets.  Four launches per batch:
+//   jpeg_parse_kernel      one image per LANE: walks the marker segments, writes a 48-word descriptor (size, sampling, table
+//                          offsets, scan offset, status).  The host reads the descriptors back once to size the outputs.
+//   jpeg_huffman_kernel    one image per LANE, one wave per workgroup.  Entropy decoding is inherently serial per image (COCO
+//                          files carry no restart markers), so the parallelism is ACROSS images: 64 bit-streams per wave, every
+//                          lane with its own four 8-bit-lookahead code tables in LDS (128 KiB per wave, lane-interleaved so a
+//                          lookup is bank-conflict free whatever the codes are), coefficients scattered into a zeroed int16
+//                          buffer in natural order.  A 4096-image batch is 64 waves on 64 CUs; the other CUs keep running the
+//                          embedding tower of the previous batch on another stream.
+//   jpeg_idct_kernel       one thread per 8x8 block: dequantise + ISLOW IDCT in registers, 8 x 8-byte row stores into the
+//                          component plane.
+//   jpeg_color_kernel      one thread per output pixel: fancy chroma upsampling + YCbCr -> RGB, 3-byte store.
+// The last two are plain data-parallel integer kernels bound by the load/store units (no reuse to stage in LDS).
+#include "drag_common.h"
+#include "jpeg_core.h"
+
+namespace {
+
+struct LdsLut {                      // table entry e of this lane: base[e * 64 + lane]
+  DRAG_LDS uint16_t* base;
+  __device__ __forceinline__ DRAG_LDS uint16_t& operator[](int e) const { return base[e * 64]; }
+};
+
+struct JpegArgs {
+  const uint8_t* data;
+  const int64_t* off;       // [n + 1] byte offsets of the files inside `data`
+  const JpegInfo* info;     // [n]
+  const int64_t* plan;      // [n, 3]: coefficient offset (int16 elements), plane offset (bytes), output offset (bytes)
+  int16_t* coef;
+  uint8_t* planes;
+  uint16_t* qtab;           // [n, 3, 64] quantisation tables in natural order
+  uint8_t* out;
+  int n;
+};
+
+__global__ __launch_bounds__(64) void jpeg_parse_kernel(const uint8_t* data, const int64_t* off, int n, JpegInfo* info) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  JpegInfo o;
+  jpeg_parse(data + off[i], off[i + 1] - off[i], &o);
+  if (o.status == 0) {                               // the Huffman kernel keeps four code tables per lane: DC 0/1, AC 0/1
+    for (int c = 0; c < o.ncomp; ++c)
+      if (o.td[c] > 1 || o.ta[c] > 1) o.status = JPEG_ERR_TABLES;
+  }
+  info[i] = o;
+}
+
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];     // [4 tables][256 entries][64 lanes]
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * 64 + lane;
+  if (i >= a.n) return;
+  const JpegInfo o = a.info[i];
+  if (o.status != 0) return;
+  const uint8_t* d = a.data + a.off[i];
+  const int64_t len = a.off[i + 1] - a.off[i];
+  JpegHuffSlow slow[4];
+  const uint8_t* vals[4];
+  LdsLut lut[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {                      // t = class * 2 + id
+    lut[t].base = (DRAG_LDS uint16_t*)lds + t * 256 * 64 + lane;
+    const int ofs = o.dht_off[(t >> 1) * 4 + (t & 1)];
+    vals[t] = nullptr;
+    if (ofs >= 0) {
+      jpeg_build_huff(d + ofs, lut[t], &slow[t]);
+      vals[t] = d + ofs + 16;
+    }
+  }
+  // quantisation tables of the components, natural order, for the IDCT kernel
+  for (int c = 0; c < o.ncomp; ++c) {
+    const uint8_t* qt = d + o.dqt_off[o.tq[c]];
+    uint16_t* q = a.qtab + ((long long)i * 3 + c) * 64;
+    for (int k = 0; k < 64; ++k) q[jpeg_natural_order(k)] = o.dqt_16[o.tq[c]] ? (uint16_t)jpeg_u16(qt + 2 * k) : (uint16_t)qt[k];
+  }
+  int16_t* cbase[3];
+  int bw[3];
+  {
+    long long p = a.plan[(long long)i * 3];
+    for (int c = 0; c < o.ncomp; ++c) {
+      cbase[c] = a.coef + p;
+      bw[c] = o.mcus_x * o.hs[c];
+      p += (long long)bw[c] * (o.mcus_y * o.vs[c]) * 64;
+    }
+  }
+  JpegBits b;
+  jpeg_bits_init(&b, d, o.scan_off, len);
+  int pred[3] = {0, 0, 0};
+  int togo = o.restart_interval;
+  for (int my = 0; my < o.mcus_y; ++my)
+    for (int mx = 0; mx < o.mcus_x; ++mx) {
+      if (o.restart_interval && togo == 0) {
+        jpeg_bits_restart(&b);
+        pred[0] = pred[1] = pred[2] = 0;
+        togo = o.restart_interval;
+      }
+      for (int c = 0; c < o.ncomp; ++c) {
+        const int td = o.td[c], ta = 2 + o.ta[c];
+        for (int v = 0; v < o.vs[c]; ++v)
+          for (int h = 0; h < o.hs[c]; ++h) {
+            int16_t* blk = cbase[c] + ((long long)(my * o.vs[c] + v) * bw[c] + mx * o.hs[c] + h) * 64;
+            jpeg_decode_block(&b, lut[td], &slow[td], vals[td], lut[ta], &slow[ta], vals[ta], &pred[c], blk);
+          }
+      }
+      if (o.restart_interval) --togo;
+    }
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegArgs a) {
+  const int i = blockIdx.y;
+  const JpegInfo& o = a.info[i];
+  if (o.status != 0) return;
+  long long blk = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long cofs = a.plan[(long long)i * 3], pofs = a.plan[(long long)i * 3 + 1];
+  int c = 0;
+  for (; c < o.ncomp; ++c) {
+    const long long nb = (long long)(o.mcus_x * o.hs[c]) * (o.mcus_y * o.vs[c]);
+    if (blk < nb) break;
+    blk -= nb; cofs += nb * 64; pofs += nb * 64;
+  }
+  if (c == o.ncomp) return;
+  const int bwc = o.mcus_x * o.hs[c];
+  const int by = (int)(blk / bwc), bx = (int)(blk - (long long)by * bwc);
+  const int ld = bwc * 8;
+  jpeg_idct_block(a.coef + cofs + blk * 64, a.qtab + ((long long)i * 3 + c) * 64, a.planes + pofs + (long long)by * 8 * ld + bx * 8, ld);
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(JpegArgs a) {
+  const int i = blockIdx.y;
+  const JpegInfo& o = a.info[i];
+  if (o.status != 0) return;
+  const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int W = o.width, H = o.height;
+  if (px >= (long long)W * H) return;
+  const int y = (int)(px / W), x = (int)(px - (long long)y * W);
+  const uint8_t* p0 = a.planes + a.plan[(long long)i * 3 + 1];
+  uint8_t* dst = a.out + a.plan[(long long)i * 3 + 2] + px * 3;
+  const int ld0 = o.mcus_x * o.hs[0] * 8;
+  const int Y = p0[(long long)y * ld0 + x];
+  if (o.ncomp == 1) { dst[0] = dst[1] = dst[2] = (uint8_t)Y; return; }
+  const long long n0 = (long long)ld0 * (o.mcus_y * o.vs[0] * 8);
+  const int ld1 = o.mcus_x * 8;
+  const long long n1 = (long long)ld1 * (o.mcus_y * 8);
+  const int dw = (W + o.hmax - 1) / o.hmax, dh = (H + o.vmax - 1) / o.vmax;
+  const int cb = jpeg_upsampled(p0 + n0, ld1, dw, dh, o.hmax, o.vmax, x, y);
+  const int cr = jpeg_upsampled(p0 + n0 + n1, ld1, dw, dh, o.hmax, o.vmax, x, y);
+  uint8_t rgb[3];
+  jpeg_ycc_to_rgb(Y, cb, cr, rgb);
+  dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2];
+}
+
+}  // namespace
+
+static_assert(sizeof(JpegInfo) == sizeof(drag_jpeg_info), "drag_jpeg_info must mirror JpegInfo");
+
+extern "C" int drag_jpeg_parse(const void* data, const int64_t* offsets, int32_t n, drag_jpeg_info* info, void* stream) {
+  DRAG_CHECK(data && offsets && info, "drag_jpeg_parse: null pointer");
+  DRAG_CHECK(n > 0, "drag_jpeg_parse: n must be positive");
+  hipLaunchKernelGGL(jpeg_parse_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)data, offsets, n,
+                     (JpegInfo*)info);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jpeg_info* info, const int64_t* plan,
+                                    int32_t n, int64_t max_blocks, int64_t max_pixels, void* coef_ws, int64_t coef_bytes,
+                                    void* plane_ws, void* qtab_ws, void* out_rgb, void* stream) {
+  DRAG_CHECK(data && offsets && info && plan && coef_ws && plane_ws && qtab_ws && out_rgb, "drag_jpeg_decode_rgb: null pointer");
+  DRAG_CHECK(n > 0 && max_blocks > 0 && max_pixels > 0 && coef_bytes > 0, "drag_jpeg_decode_rgb: bad sizes");
+  DRAG_CHECK(max_blocks < (1ll << 31) * 256 && max_pixels < (1ll << 31) * 256 && n <= 65535, "drag_jpeg_decode_rgb: batch too large");
+  hipStream_t st = (hipStream_t)stream;
+  JpegArgs a;
+  a.data = (const uint8_t*)data; a.off = offsets; a.info = (const JpegInfo*)info; a.plan = plan;
+  a.coef = (int16_t*)coef_ws; a.planes = (uint8_t*)plane_ws; a.qtab = (uint16_t*)qtab_ws; a.out = (uint8_t*)out_rgb; a.n = n;
+  hipError_t e = hipMemsetAsync(coef_ws, 0, (size_t)coef_bytes, st);     // blocks are sparse: only non-zero coefficients are stored
+  DRAG_CHECK(e == hipSuccess, "drag_jpeg_decode_rgb: memset failed");
+  const int lds = 4 * 256 * 64 * 2;                                       // 128 KiB: one wave per CU
+  static bool lds_ok = false;
+  if (!lds_ok) {
+    e = hipFuncSetAttribute((const void*)jpeg_huffman_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DRAG_CHECK(e == hipSuccess, "drag_jpeg_decode_rgb: cannot raise the dynamic LDS limit to 128 KiB");
+    lds_ok = true;
+  }
+  hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((n + 63) / 64), dim3(64), lds, st, a);
+  DRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 255) / 256), n), dim3(256), 0, st, a);
+  DRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((max_pixels + 255) / 256), n), dim3(256), 0, st, a);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,386 @@
+// jpeg_core.h — baseline JPEG decoding arithmetic, byte-identical to libjpeg-turbo's default decompression (what
+// PIL's Image.open(path).convert("RGB") returns for the corpus images the reference embeds one by one,
+// retrieval/clip100_resnet_style_all_shots.py:270-281): Huffman entropy decoding, dequantisation + the "ISLOW" integer
+// IDCT (jidctint.c), "fancy" (triangle) chroma upsampling (jdsample.c) and the fixed-point YCbCr -> RGB tables (jdcolor.c).
+// The reference reaches libjpeg only through Pillow; the algorithms restated here are libjpeg's published ones.
+//
+// Host/device neutral on purpose: csrc/jpeg.hip wraps these functions in gfx950 kernels (one image per LANE for the
+// sequential parts, one thread per 8x8 block / per pixel for the parallel ones), and tests/helpers/jpeg_host.cpp compiles the
+// very same functions with g++ so that the arithmetic is checked against PIL on the build host, where there is no GPU.
+// Nothing on the product path uses the host build.
+//
+// Supported: SOF0 / SOF1 (sequential Huffman, 8-bit), one interleaved scan, 1 component (-> grey replicated to RGB) or 3
+// components YCbCr with the luma at full resolution and the chroma at 1x1, 2x1 or 2x2 subsampling, restart intervals.
+// Everything else (progressive, arithmetic, 12-bit, CMYK / RGB-coded, multi-scan, other sampling ratios) is reported in
+// JpegInfo::status and left to the caller.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define JHD __host__ __device__ __forceinline__
+#else
+#define JHD inline
+#endif
+
+enum {
+  JPEG_OK = 0,
+  JPEG_ERR_NOT_JPEG = 1,
+  JPEG_ERR_TRUNCATED = 2,
+  JPEG_ERR_PROGRESSIVE = 3,      // SOF2 and the other non-sequential / arithmetic / lossless frame types
+  JPEG_ERR_PRECISION = 4,        // not 8 bits per sample
+  JPEG_ERR_COMPONENTS = 5,       // not 1 or 3 components, or a colour space other than grey / YCbCr
+  JPEG_ERR_SAMPLING = 6,         // not 4:4:4 / 4:2:2 / 4:2:0 (full-resolution luma, chroma 1x1 / 2x1 / 2x2 subsampled)
+  JPEG_ERR_MULTISCAN = 7,        // a scan that does not carry all components, or spectral selection / successive approximation
+  JPEG_ERR_TABLES = 8,           // a referenced Huffman / quantisation table was never defined
+  JPEG_ERR_TOO_SMALL = 9,        // subsampled chroma at most 2 samples wide (libjpeg switches to box replication there)
+};
+
+struct JpegInfo {               // == drag_jpeg_info (include/domainrag_hip.h): 48 x int32
+  int32_t status;
+  int32_t width, height, ncomp;
+  int32_t hs[3], vs[3];         // sampling factors
+  int32_t tq[3], td[3], ta[3];  // quantisation / DC / AC table ids per component
+  int32_t hmax, vmax;
+  int32_t mcus_x, mcus_y;
+  int32_t restart_interval;
+  int32_t scan_off;             // offset of the first entropy-coded byte
+  int32_t dqt_off[4];           // offset of a table's first element (zigzag order), -1 = absent
+  int32_t dqt_16[4];            // 1 = 16-bit elements
+  int32_t dht_off[8];           // [class * 4 + id]: offset of the 16 code-length counts, -1 = absent
+  int32_t reserved[7];
+};
+
+JHD int jpeg_natural_order(int k) {   // zigzag position -> natural (row-major) position; positions past 63 alias 63 like libjpeg
+  const uint8_t t[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  return k < 64 ? t[k] : 63;
+}
+
+JHD int jpeg_u16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+// ---------------------------------------------------------------------------------------------- header
+// Walks the marker segments of one file.  Later DQT / DHT definitions override earlier ones (single scan: all of them
+// precede SOS).  Never reads past `len`.
+JHD void jpeg_parse(const uint8_t* d, int64_t len, JpegInfo* o) {
+  for (int i = 0; i < (int)(sizeof(JpegInfo) / 4); ++i) ((int32_t*)o)[i] = 0;
+  for (int i = 0; i < 4; ++i) o->dqt_off[i] = -1;
+  for (int i = 0; i < 8; ++i) o->dht_off[i] = -1;
+  if (len < 4 || d[0] != 0xFF || d[1] != 0xD8) { o->status = JPEG_ERR_NOT_JPEG; return; }
+  int64_t p = 2;
+  bool have_sof = false, jfif = false, adobe = false;
+  int adobe_transform = 0;
+  int cid[3] = {0, 0, 0};
+  for (;;) {
+    if (p + 4 > len) { o->status = JPEG_ERR_TRUNCATED; return; }
+    if (d[p] != 0xFF) { o->status = JPEG_ERR_NOT_JPEG; return; }
+    while (p < len && d[p] == 0xFF) ++p;                 // fill bytes
+    if (p >= len) { o->status = JPEG_ERR_TRUNCATED; return; }
+    const int m = d[p++];
+    if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;    // parameterless
+    if (m == 0xD9) { o->status = JPEG_ERR_TRUNCATED; return; }             // EOI before any scan
+    if (p + 2 > len) { o->status = JPEG_ERR_TRUNCATED; return; }
+    const int L = jpeg_u16(d + p);
+    if (L < 2 || p + L > len) { o->status = JPEG_ERR_TRUNCATED; return; }
+    const uint8_t* s = d + p + 2;
+    const int n = L - 2;
+    if (m == 0xE0) {
+      if (n >= 5 && s[0] == 'J' && s[1] == 'F' && s[2] == 'I' && s[3] == 'F' && s[4] == 0) jfif = true;
+    } else if (m == 0xEE) {
+      if (n >= 12 && s[0] == 'A' && s[1] == 'd' && s[2] == 'o' && s[3] == 'b' && s[4] == 'e') { adobe = true; adobe_transform = s[11]; }
+    } else if (m == 0xDB) {
+      int q = 0;
+      while (q < n) {
+        const int pq = s[q] >> 4, id = s[q] & 15;
+        const int sz = pq ? 128 : 64;
+        if (id > 3 || q + 1 + sz > n) { o->status = JPEG_ERR_TABLES; return; }
+        o->dqt_off[id] = (int32_t)(p + 2 + q + 1);
+        o->dqt_16[id] = pq ? 1 : 0;
+        q += 1 + sz;
+      }
+    } else if (m == 0xC4) {
+      int q = 0;
+      while (q < n) {
+        if (q + 17 > n) { o->status = JPEG_ERR_TABLES; return; }
+        const int tc = s[q] >> 4, id = s[q] & 15;
+        int cnt = 0;
+        for (int i = 0; i < 16; ++i) cnt += s[q + 1 + i];
+        if (tc > 1 || id > 3 || cnt > 256 || q + 17 + cnt > n) { o->status = JPEG_ERR_TABLES; return; }
+        o->dht_off[tc * 4 + id] = (int32_t)(p + 2 + q + 1);
+        q += 17 + cnt;
+      }
+    } else if (m == 0xDD) {
+      if (n >= 2) o->restart_interval = jpeg_u16(s);
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (n < 6) { o->status = JPEG_ERR_TRUNCATED; return; }
+      if (s[0] != 8) { o->status = JPEG_ERR_PRECISION; return; }
+      o->height = jpeg_u16(s + 1); o->width = jpeg_u16(s + 3); o->ncomp = s[5];
+      if (o->ncomp != 1 && o->ncomp != 3) { o->status = JPEG_ERR_COMPONENTS; return; }
+      if (n < 6 + 3 * o->ncomp || o->width <= 0 || o->height <= 0) { o->status = JPEG_ERR_TRUNCATED; return; }
+      for (int c = 0; c < o->ncomp; ++c) {
+        cid[c] = s[6 + 3 * c];
+        o->hs[c] = s[7 + 3 * c] >> 4; o->vs[c] = s[7 + 3 * c] & 15; o->tq[c] = s[8 + 3 * c];
+        if (o->tq[c] > 3) { o->status = JPEG_ERR_TABLES; return; }
+      }
+      have_sof = true;
+    } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      o->status = JPEG_ERR_PROGRESSIVE; return;
+    } else if (m == 0xDA) {
+      if (!have_sof) { o->status = JPEG_ERR_NOT_JPEG; return; }
+      if (n < 1 || s[0] != o->ncomp || n < 1 + 2 * o->ncomp + 3) { o->status = JPEG_ERR_MULTISCAN; return; }
+      for (int c = 0; c < o->ncomp; ++c) {
+        if (s[1 + 2 * c] != cid[c]) { o->status = JPEG_ERR_MULTISCAN; return; }
+        o->td[c] = s[2 + 2 * c] >> 4; o->ta[c] = s[2 + 2 * c] & 15;
+        if (o->td[c] > 3 || o->ta[c] > 3) { o->status = JPEG_ERR_TABLES; return; }
+      }
+      const uint8_t* t = s + 1 + 2 * o->ncomp;
+      if (t[0] != 0 || t[1] != 63 || t[2] != 0) { o->status = JPEG_ERR_MULTISCAN; return; }
+      o->scan_off = (int32_t)(p + L);
+      break;
+    }
+    p += L;
+  }
+  // ---- what the pixel pipeline below can do
+  if (o->ncomp == 1) {
+    o->hs[0] = o->vs[0] = 1;                      // a single-component scan is never interleaved: 1x1 MCUs whatever SOF says
+  } else {
+    // libjpeg's colour-space guess (jdapimin.c default_decompress_parms): JFIF -> YCbCr; Adobe transform 1 -> YCbCr, 0 -> RGB;
+    // neither: component ids 'R','G','B' -> RGB, anything else -> YCbCr
+    bool ycc = true;
+    if (jfif) ycc = true;
+    else if (adobe) ycc = adobe_transform == 1;
+    else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') ycc = false;
+    if (!ycc) { o->status = JPEG_ERR_COMPONENTS; return; }
+    // 4:4:4, 4:2:2 (h2v1), 4:2:0 (h2v2).  4:4:0 (h1v2) has a fancy upsampler in libjpeg-turbo too, but no encoder at hand
+    // writes it, so its arithmetic could not be checked against the library: left to the caller rather than guessed.
+    const int h0 = o->hs[0], v0 = o->vs[0];
+    if (!((h0 == 1 && v0 == 1) || (h0 == 2 && v0 == 1) || (h0 == 2 && v0 == 2)) || o->hs[1] != 1 || o->vs[1] != 1 || o->hs[2] != 1 ||
+        o->vs[2] != 1) {
+      o->status = JPEG_ERR_SAMPLING; return;
+    }
+  }
+  o->hmax = o->hs[0]; o->vmax = o->vs[0];
+  o->mcus_x = (o->width + 8 * o->hmax - 1) / (8 * o->hmax);
+  o->mcus_y = (o->height + 8 * o->vmax - 1) / (8 * o->vmax);
+  for (int c = 0; c < o->ncomp; ++c) {
+    if (o->dqt_off[o->tq[c]] < 0 || o->dht_off[o->td[c]] < 0 || o->dht_off[4 + o->ta[c]] < 0) { o->status = JPEG_ERR_TABLES; return; }
+  }
+  // jdsample.c picks the triangle filters only when downsampled_width > 2 (box replication otherwise): images under 5 pixels wide
+  if (o->ncomp == 3 && o->hmax == 2 && (o->width + 1) / 2 <= 2) { o->status = JPEG_ERR_TOO_SMALL; return; }
+}
+
+// geometry of component c's sample plane as the IDCT writes it (whole blocks)
+JHD int jpeg_blocks_w(const JpegInfo* o, int c) { return o->mcus_x * o->hs[c]; }
+JHD int jpeg_blocks_h(const JpegInfo* o, int c) { return o->mcus_y * o->vs[c]; }
+JHD int64_t jpeg_total_blocks(const JpegInfo* o) {
+  int64_t t = 0;
+  for (int c = 0; c < o->ncomp; ++c) t += (int64_t)jpeg_blocks_w(o, c) * jpeg_blocks_h(o, c);
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------- Huffman tables
+// 8-bit lookahead table: entry = (code length << 8) | symbol for codes of <= 8 bits, 0 otherwise; plus libjpeg's
+// maxcode / valoffset arrays for the bit-by-bit path of longer codes.
+struct JpegHuffSlow {
+  int32_t maxcode[18];     // maxcode[l] = largest code of length l (-1 if none); maxcode[17] = sentinel
+  int32_t valoff[17];      // huffval index = code + valoff[l]
+};
+
+template <typename LUT>     // LUT: anything indexable as lut[i] = uint16_t (an LDS pointer on the GPU)
+JHD void jpeg_build_huff(const uint8_t* counts /* 16 counts, then the symbols */, LUT lut, JpegHuffSlow* slow) {
+  for (int i = 0; i < 256; ++i) lut[i] = 0;
+  const uint8_t* vals = counts + 16;
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    const int n = counts[l - 1];
+    slow->valoff[l] = k - code;
+    if (n) {
+      for (int i = 0; i < n; ++i, ++k, ++code) {
+        if (l <= 8) {
+          const int base = code << (8 - l);
+          for (int f = 0; f < (1 << (8 - l)); ++f) lut[(base + f) & 255] = (uint16_t)((l << 8) | vals[k]);
+        }
+      }
+      slow->maxcode[l] = code - 1;
+    } else {
+      slow->maxcode[l] = -1;
+    }
+    code <<= 1;
+  }
+  slow->maxcode[17] = 0xFFFFF;
+}
+
+// ---------------------------------------------------------------------------------------------- bit reader
+struct JpegBits {
+  const uint8_t* d;
+  int64_t pos, end;
+  uint64_t buf;       // MSB-aligned
+  int cnt;
+  int marker;         // a marker was met: the reader feeds zero bits from there on (libjpeg's behaviour at end of data)
+};
+
+JHD void jpeg_bits_init(JpegBits* b, const uint8_t* d, int64_t pos, int64_t end) {
+  b->d = d; b->pos = pos; b->end = end; b->buf = 0; b->cnt = 0; b->marker = 0;
+}
+JHD void jpeg_bits_fill(JpegBits* b) {
+  while (b->cnt <= 56) {
+    unsigned byte = 0;
+    if (!b->marker && b->pos < b->end) {
+      byte = b->d[b->pos];
+      if (byte == 0xFF) {
+        const unsigned nx = b->pos + 1 < b->end ? b->d[b->pos + 1] : 0xD9;
+        if (nx == 0) b->pos += 2;                      // stuffed zero
+        else { b->marker = (int)nx; byte = 0; }        // leave pos at the 0xFF
+      } else {
+        b->pos += 1;
+      }
+    } else if (!b->marker) {
+      b->marker = 0xD9;
+    }
+    b->buf |= (uint64_t)byte << (56 - b->cnt);
+    b->cnt += 8;
+  }
+}
+JHD int jpeg_bits_peek(const JpegBits* b, int n) { return (int)(b->buf >> (64 - n)); }
+JHD void jpeg_bits_skip(JpegBits* b, int n) { b->buf <<= n; b->cnt -= n; }
+JHD int jpeg_receive_extend(JpegBits* b, int s) {       // s in 1..16
+  const int r = jpeg_bits_peek(b, s);
+  jpeg_bits_skip(b, s);
+  return r < (1 << (s - 1)) ? r - (1 << s) + 1 : r;
+}
+template <typename LUT>
+JHD int jpeg_decode_symbol(JpegBits* b, LUT lut, const JpegHuffSlow* slow, const uint8_t* vals) {
+  const unsigned e = lut[jpeg_bits_peek(b, 8)];
+  if (e) { jpeg_bits_skip(b, (int)(e >> 8)); return (int)(e & 255); }
+  int l = 9;
+  int code = jpeg_bits_peek(b, 9);
+  while (l <= 16 && code > slow->maxcode[l]) { ++l; code = jpeg_bits_peek(b, l > 16 ? 16 : l); }
+  if (l > 16) { jpeg_bits_skip(b, 16); return 0; }     // corrupt data: libjpeg warns and returns 0
+  jpeg_bits_skip(b, l);
+  return vals[(code + slow->valoff[l]) & 255];
+}
+// after an MCU count hits the restart interval (jdhuff.c process_restart): the bits left in the current byte are padding;
+// the reader has necessarily run into the RSTn marker while filling (at most 7 data bits precede it), so step over it.  A
+// stream that has something else there is corrupt: resynchronise on the next RSTn like libjpeg's default resync does.
+JHD void jpeg_bits_restart(JpegBits* b) {
+  jpeg_bits_fill(b);
+  int64_t p = b->pos;
+  if (b->marker >= 0xD0 && b->marker <= 0xD7) {
+    p += 2;
+  } else {
+    while (p + 1 < b->end && !(b->d[p] == 0xFF && b->d[p + 1] >= 0xD0 && b->d[p + 1] <= 0xD7)) ++p;
+    p = p + 1 < b->end ? p + 2 : b->end;
+  }
+  b->pos = p; b->buf = 0; b->cnt = 0; b->marker = 0;
+}
+
+// one 8x8 block: DC difference + AC run/size pairs -> coefficients in NATURAL order (the block must be zero on entry)
+template <typename LUT>
+JHD void jpeg_decode_block(JpegBits* b, LUT dc_lut, const JpegHuffSlow* dc_slow, const uint8_t* dc_vals, LUT ac_lut,
+                           const JpegHuffSlow* ac_slow, const uint8_t* ac_vals, int* dc_pred, int16_t* coef) {
+  jpeg_bits_fill(b);
+  int s = jpeg_decode_symbol(b, dc_lut, dc_slow, dc_vals) & 15;
+  if (s) *dc_pred += jpeg_receive_extend(b, s);     // a fill leaves >= 57 bits: enough for a 16-bit code + 16 extra bits
+  coef[0] = (int16_t)*dc_pred;
+  for (int k = 1; k < 64; ++k) {
+    jpeg_bits_fill(b);
+    const int rs = jpeg_decode_symbol(b, ac_lut, ac_slow, ac_vals);
+    const int r = rs >> 4;
+    s = rs & 15;
+    if (s) {
+      k += r;
+      const int v = jpeg_receive_extend(b, s);
+      coef[jpeg_natural_order(k)] = (int16_t)v;
+    } else {
+      if (r != 15) break;
+      k += 15;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- IDCT (jidctint.c, ISLOW)
+// in: 64 coefficients (natural order), q: 64 quantisation values (natural order); out: 8 rows of 8 samples, row stride `ld`.
+// Final clamp = saturation to [0, 255] after the +128 level shift: what libjpeg-turbo's SIMD kernels compute (the C code's
+// masked table lookup differs only for |value| > 511, which no encoder produces).
+JHD int jpeg_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+JHD uint8_t jpeg_clamp255(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+JHD void jpeg_idct_1d(const int in[8], int out[8], int shift, bool first) {
+  const int C0298 = 2446, C0390 = 3196, C0541 = 4433, C0765 = 6270, C0899 = 7373, C1175 = 9633, C1501 = 12299, C1847 = 15137,
+            C1961 = 16069, C2053 = 16819, C2562 = 20995, C3072 = 25172;
+  (void)first;
+  int z2 = in[2], z3 = in[6];
+  int z1 = (z2 + z3) * C0541;
+  int tmp2 = z1 + z3 * (-C1847);
+  int tmp3 = z1 + z2 * C0765;
+  int tmp0 = (in[0] + in[4]) * 8192;          // << CONST_BITS (13), written as a multiply: defined for negative values
+  int tmp1 = (in[0] - in[4]) * 8192;
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int z4 = tmp1 + tmp3;
+  const int z5 = (z3 + z4) * C1175;
+  tmp0 *= C0298; tmp1 *= C2053; tmp2 *= C3072; tmp3 *= C1501;
+  z1 *= -C0899; z2 *= -C2562; z3 *= -C1961; z4 *= -C0390;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  out[0] = jpeg_descale(tmp10 + tmp3, shift); out[7] = jpeg_descale(tmp10 - tmp3, shift);
+  out[1] = jpeg_descale(tmp11 + tmp2, shift); out[6] = jpeg_descale(tmp11 - tmp2, shift);
+  out[2] = jpeg_descale(tmp12 + tmp1, shift); out[5] = jpeg_descale(tmp12 - tmp1, shift);
+  out[3] = jpeg_descale(tmp13 + tmp0, shift); out[4] = jpeg_descale(tmp13 - tmp0, shift);
+}
+
+JHD void jpeg_idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, int ld) {
+  int ws[64];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {               // pass 1: columns, scaled up by 2^PASS1_BITS (2)
+    int in[8], o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) in[r] = (int)coef[r * 8 + c] * (int)q[r * 8 + c];
+    jpeg_idct_1d(in, o, 13 - 2, true);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ws[r * 8 + c] = o[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {               // pass 2: rows, descale by 2^(13 + 2 + 3), level shift, clamp
+    int in[8], o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) in[c] = ws[r * 8 + c];
+    jpeg_idct_1d(in, o, 13 + 2 + 3, false);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[r * ld + c] = jpeg_clamp255(o[c] + 128);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- upsample + colour
+// chroma sample for output pixel (x, y) of a plane `pl` (row stride ld) holding dw x dh REAL samples, subsampled by
+// (hsub, vsub) in {(1,1), (2,1), (2,2)}: jdsample.c fullsize / h2v1_fancy / h2v2_fancy, with libjpeg's edge rules (the row
+// above the first = the first, below the last real row = the last; first / last column special cases).
+JHD int jpeg_upsampled(const uint8_t* pl, int ld, int dw, int dh, int hsub, int vsub, int x, int y) {
+  if (hsub == 1 && vsub == 1) return pl[y * ld + x];
+  if (vsub == 1) {                                     // h2v1
+    const int i = x >> 1;
+    const uint8_t* r = pl + y * ld;
+    if ((x & 1) == 0) return i == 0 ? r[0] : (3 * r[i] + r[i - 1] + 1) >> 2;
+    return i == dw - 1 ? r[i] : (3 * r[i] + r[i + 1] + 2) >> 2;
+  }
+  const int j = y >> 1;
+  const int jn = (y & 1) == 0 ? (j > 0 ? j - 1 : 0) : (j + 1 < dh ? j + 1 : dh - 1);      // the further row
+  const uint8_t* r0 = pl + j * ld;
+  const uint8_t* r1 = pl + jn * ld;
+  const int i = x >> 1;                                // h2v2
+  const int t = 3 * r0[i] + r1[i];
+  if ((x & 1) == 0) {
+    if (i == 0) return (t * 4 + 8) >> 4;
+    return (t * 3 + (3 * r0[i - 1] + r1[i - 1]) + 8) >> 4;
+  }
+  if (i == dw - 1) return (t * 4 + 7) >> 4;
+  return (t * 3 + (3 * r0[i + 1] + r1[i + 1]) + 7) >> 4;
+}
+
+JHD void jpeg_ycc_to_rgb(int y, int cb, int cr, uint8_t* rgb) {
+  cb -= 128; cr -= 128;
+  rgb[0] = jpeg_clamp255(y + ((91881 * cr + 32768) >> 16));
+  rgb[1] = jpeg_clamp255(y + (((-22554) * cb + 32768 + (-46802) * cr) >> 16));
+  rgb[2] = jpeg_clamp255(y + ((116130 * cb + 32768) >> 16));
+}

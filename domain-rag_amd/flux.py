@@ -21,8 +21,12 @@ import math
 
 import torch
 
+import os
+
 from . import ops
 from .flux_params import FluxConfig
+
+_SEPARATE_QPREP = os.environ.get("DRAG_QPREP_SEPARATE", "") not in ("", "0")     # measurement switch, read once
 
 
 def rope_tables(ids: torch.Tensor, axes_dims=(16, 56, 56), theta: float = 10000.0):
@@ -233,10 +237,14 @@ class FluxTransformerHIP:
                      c_batch_stride=S * 3 * D, ldc=3 * D)
             ops.gemm(nrm_txt, blk["cwqkv"], out=qkv, bias=blk["cbqkv"], M=Mt, lda=D, c_rows_per_batch=St,
                      c_batch_stride=S * 3 * D, ldc=3 * D)
-            # k: RMSNorm + RoPE in place, V -> V^T; q: norm_q / norm_added_q + RoPE inside the attention kernel's Q load
-            ops.k_norm_rope_vt(qkv, vt, blk["cnk"], blk["nk"], cos, sin, B, S, H, 3 * D, St)
-            ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, attn, B, S, H, 3 * D, S * 3 * D, D, S * D, scale,
-                                blk["cnq"], blk["nq"], cos, sin, St)
+            if _SEPARATE_QPREP:     # A/B switch: the round-1 route (q prepared by the pass, plain attention)
+                ops.qk_norm_rope_vt(qkv, vt, blk["cnq"], blk["cnk"], blk["nq"], blk["nk"], cos, sin, B, S, H, 3 * D, St)
+                ops.attention(qkv, qkv.view(-1)[D:], vt, attn, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
+            else:
+                # k: RMSNorm + RoPE in place, V -> V^T; q: norm_q / norm_added_q + RoPE inside the attention kernel's Q load
+                ops.k_norm_rope_vt(qkv, vt, blk["cnk"], blk["nk"], cos, sin, B, S, H, 3 * D, St)
+                ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, attn, B, S, H, 3 * D, S * 3 * D, D, S * D, scale,
+                                    blk["cnq"], blk["nq"], cos, sin, St)
             ops.gemm(attn_img, blk["wo"], out=x_img, bias=blk["bo"], M=Mi, a_rows_per_batch=Si, a_batch_stride=S * D,
                      lda=D, c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D, gate=modv[mo + 2 * D:], resid=x_img, ldg=LM)
             ops.gemm(attn, blk["cwo"], out=x, bias=blk["cbo"], M=Mt, a_rows_per_batch=St, a_batch_stride=S * D,
@@ -262,9 +270,13 @@ class FluxTransformerHIP:
                           x_batch_stride=S * D)
             ops.gemm(nrm, blk["wqkv"], out=qkv, bias=blk["bqkv"], M=M, lda=D, ldc=3 * D)
             ops.gemm(nrm, blk["wm"], out=cat_mlp, bias=blk["bm"], act=ops.ACT_GELU_TANH, M=M, lda=D, ldc=D + F)
-            ops.k_norm_rope_vt(qkv, vt, blk["nk"], blk["nk"], cos, sin, B, S, H, 3 * D, 0)
-            ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, catb, B, S, H, 3 * D, S * 3 * D, D + F, S * (D + F), scale,
-                                blk["nq"], blk["nq"], cos, sin, 0)
+            if _SEPARATE_QPREP:
+                ops.qk_norm_rope_vt(qkv, vt, blk["nq"], blk["nk"], blk["nq"], blk["nk"], cos, sin, B, S, H, 3 * D, 0)
+                ops.attention(qkv, qkv.view(-1)[D:], vt, catb, B, S, H, 3 * D, S * 3 * D, D + F, S * (D + F), scale)
+            else:
+                ops.k_norm_rope_vt(qkv, vt, blk["nk"], blk["nk"], cos, sin, B, S, H, 3 * D, 0)
+                ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, catb, B, S, H, 3 * D, S * 3 * D, D + F, S * (D + F), scale,
+                                    blk["nq"], blk["nq"], cos, sin, 0)
             ops.gemm(catb, blk["wo"], out=x, bias=blk["bo"], M=M, lda=D + F, c_rows_per_batch=S, c_batch_stride=S * D,
                      ldc=D, gate=modv[mo + 2 * D:], resid=x, ldg=LM)
             if taps is not None:

@@ -1,0 +1,135 @@
+"""JPEG files -> RGB pixels on the GPU (``drag_jpeg_parse`` / ``drag_jpeg_decode_rgb``), byte-identical to
+``PIL.Image.open(f).convert("RGB")`` — the decode the reference pays per corpus image before CLIP's preprocess
+(retrieval/clip100_resnet_style_all_shots.py:270-281).  SURVEY §8(f)-2.
+
+The host's part is reading files: a batch travels as ONE byte blob + offsets; markers are parsed on the device, the only
+read-back is the per-file descriptor (size, sampling, status) needed to size the outputs.  Files the device path does not
+cover (progressive, CMYK, unusual sampling — ``status != 0``) are reported, not guessed: the caller decodes those few with
+PIL (same bytes by definition).
+
+    batch = decode_files([bytes, ...], device)      # -> DecodedBatch
+    batch.image(i)                                   # uint8 [H, W, 3] view on the device, or None if status[i] != 0
+    for (h, w), idx, imgs in batch.groups():         # same-size images as one dense [m, h, w, 3] tensor (for the resample kernel)
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _p, _stream, check
+
+INFO_WORDS = 48
+STATUS_TEXT = {0: "ok", 1: "not a JPEG", 2: "truncated header", 3: "progressive / arithmetic / lossless", 4: "not 8-bit",
+               5: "not grey or YCbCr", 6: "sampling other than 4:4:4 / 4:2:2 / 4:2:0", 7: "multi-scan", 8: "table problem",
+               9: "chroma at most 2 samples wide"}
+
+
+class DecodedBatch:
+    def __init__(self, info: np.ndarray, out: torch.Tensor, out_off: np.ndarray, order: np.ndarray):
+        self.info = info                    # int32 [n, 48] (drag_jpeg_info words)
+        self.status = info[:, 0].copy()
+        self.width, self.height = info[:, 1].copy(), info[:, 2].copy()
+        self._out, self._off, self._order = out, out_off, order
+
+    def __len__(self) -> int:
+        return len(self.status)
+
+    def image(self, i: int):
+        if self.status[i] != 0:
+            return None
+        h, w = int(self.height[i]), int(self.width[i])
+        o = int(self._off[i])
+        return self._out[o: o + h * w * 3].view(h, w, 3)
+
+    def groups(self):
+        """((h, w), indices int64 array, uint8 [m, h, w, 3] dense device tensor) per distinct size: the output buffer is laid
+        out size class by size class, so a group is one contiguous slab"""
+        ok = self._order[self.status[self._order] == 0]
+        i = 0
+        while i < len(ok):
+            h, w = int(self.height[ok[i]]), int(self.width[ok[i]])
+            j = i
+            while j < len(ok) and int(self.height[ok[j]]) == h and int(self.width[ok[j]]) == w:
+                j += 1
+            idx = ok[i:j]
+            o = int(self._off[idx[0]])
+            yield (h, w), idx, self._out[o: o + (j - i) * h * w * 3].view(j - i, h, w, 3)
+            i = j
+
+
+_staging: dict = {}
+
+
+def _upload(blobs, device):
+    """concatenate into a pinned staging buffer (reused, grown geometrically) and upload once"""
+    sizes = np.fromiter((len(b) for b in blobs), dtype=np.int64, count=len(blobs))
+    offsets = np.zeros(len(blobs) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offsets[1:])
+    total = int(offsets[-1])
+    key = str(device)
+    buf = _staging.get(key)
+    if buf is None or buf.numel() < total + 16:
+        buf = torch.empty(max(total + 16, 2 * (buf.numel() if buf is not None else 0)), dtype=torch.uint8).pin_memory()
+        _staging[key] = buf
+    host = buf.numpy()
+    for b, o in zip(blobs, offsets[:-1]):
+        host[o: o + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    host[total: total + 16] = 0                       # the bit reader may look one byte past a truncated file
+    data = buf[: total + 16].to(device, non_blocking=True)
+    return data, offsets
+
+
+def decode_files(blobs, device="cuda") -> DecodedBatch:
+    """``blobs``: list of bytes objects (whole files).  All arithmetic runs in libdomainrag_hip.so."""
+    lib = _lib.load()
+    n = len(blobs)
+    if n == 0:
+        raise ValueError("decode_files: empty batch")
+    if n > 65535:
+        raise ValueError("decode_files: at most 65535 files per batch")
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("decode_files: the JPEG decoder is a GPU path (domain-rag_amd has no CPU fallback)")
+    data, offsets = _upload(blobs, device)
+    d_off = torch.from_numpy(offsets).to(device)
+    d_info = torch.empty((n, INFO_WORDS), dtype=torch.int32, device=device)
+    check(lib.drag_jpeg_parse(_p(data), _p(d_off), n, _p(d_info), _stream()), "drag_jpeg_parse")
+    info = d_info.cpu().numpy()                       # the one synchronisation: sizes are needed to plan the outputs
+    ok = info[:, 0] == 0
+    w, h, ncomp = info[:, 1].astype(np.int64), info[:, 2].astype(np.int64), info[:, 3]
+    hs, vs = info[:, 4:7].astype(np.int64), info[:, 7:10].astype(np.int64)
+    mx, my = info[:, 21].astype(np.int64), info[:, 22].astype(np.int64)
+    blocks = np.zeros(n, dtype=np.int64)
+    for c in range(3):
+        blocks += np.where(ok & (ncomp > c), mx * hs[:, c] * my * vs[:, c], 0)
+    pixels = np.where(ok, w * h, 0)
+    # outputs grouped by size class (stable within a class), so same-size images form one dense slab
+    order = np.lexsort((np.arange(n), w, h)).astype(np.int64)
+    plan = np.zeros((n, 3), dtype=np.int64)
+    co = po = oo = 0
+    for i in order:
+        plan[i] = (co, po, oo)
+        co += blocks[i] * 64
+        po += blocks[i] * 64
+        oo += pixels[i] * 3
+    out = torch.empty(max(oo, 1), dtype=torch.uint8, device=device)
+    if not ok.any():
+        return DecodedBatch(info, out, plan[:, 2], order)
+    coef = torch.empty(max(co, 1), dtype=torch.int16, device=device)
+    planes = torch.empty(max(po, 1), dtype=torch.uint8, device=device)
+    qtab = torch.empty((n, 3, 64), dtype=torch.int16, device=device)
+    d_plan = torch.from_numpy(plan).to(device)
+    check(lib.drag_jpeg_decode_rgb(_p(data), _p(d_off), _p(d_info), _p(d_plan), n, int(blocks.max()), int(pixels.max()),
+                                   _p(coef), coef.numel() * 2, _p(planes), _p(qtab), _p(out), _stream()), "drag_jpeg_decode_rgb")
+    return DecodedBatch(info, out, plan[:, 2], order)
+
+
+def info_dict(row: np.ndarray) -> dict:
+    """one descriptor row as a dict (field order of ``drag_jpeg_info``)"""
+    r = [int(v) for v in row]
+    return dict(status=r[0], width=r[1], height=r[2], ncomp=r[3], hs=r[4:7], vs=r[7:10], tq=r[10:13], td=r[13:16], ta=r[16:19],
+                hmax=r[19], vmax=r[20], mcus_x=r[21], mcus_y=r[22], restart_interval=r[23], scan_off=r[24], dqt_off=r[25:29],
+                dqt_16=r[29:33], dht_off=r[33:41])

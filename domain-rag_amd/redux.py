@@ -53,8 +53,14 @@ class ReduxPriorHIP:
         L = Lt + T
         if N < 1 or n % N != 0:
             raise ValueError(f"{n} images do not split into prior calls of group={N}")
-        if len(embeds_scale) != N or len(pooled_scale) != N:
-            raise ValueError(f"need {N} scales per prior call (got {len(embeds_scale)} / {len(pooled_scale)})")
+        def per_image(v, what):       # N scales (one prior call's, repeated for every group) or n (one per image)
+            v = [float(x) for x in v]
+            if len(v) == n:
+                return v
+            if len(v) == N:
+                return v * G
+            raise ValueError(f"{what}: need {N} scales (per prior call) or {n} (per image), got {len(v)}")
+        embeds_scale, pooled_scale = per_image(embeds_scale, "embeds_scale"), per_image(pooled_scale, "pooled_scale")
         key = (n, N, Lt, P, t5_embeds.data_ptr(), pooled.data_ptr())     # N: the output buffers are sized by G = n / N
         bf = dict(dtype=torch.bfloat16, device=self.dev)
         if self._key != key:
@@ -68,8 +74,8 @@ class ReduxPriorHIP:
         ops.gemm(lat.view(-1, Dv), self.w["redux_up.weight"], out=self._mid, bias=self.w["redux_up.bias"], act=ops.ACT_SILU)
         ops.gemm(self._mid, self.w["redux_down.weight"], out=self._slab.view(-1)[Lt * Dt:], bias=self.w["redux_down.bias"],
                  M=n * T, lda=self._mid.shape[1], c_rows_per_batch=T, c_batch_stride=L * Dt, ldc=Dt)
-        es = torch.tensor(list(embeds_scale) * G, dtype=torch.float32).to(self.dev)
-        ps = torch.tensor(list(pooled_scale) * G, dtype=torch.float32).to(self.dev)
+        es = torch.tensor(embeds_scale, dtype=torch.float32).to(self.dev)
+        ps = torch.tensor(pooled_scale, dtype=torch.float32).to(self.dev)
         ops.scale_sum(self._slab, es, self._out, G, N, L * Dt)
         ops.scale_sum(self._pooled_in, ps, self._pout, G, N, P)
         # fresh tensors: the work buffers are reused by the next call, and callers may keep several priors alive

@@ -320,6 +320,37 @@ int drag_clip_embed_ln_f32(const float* emb, const float* cls, const float* pos,
 int drag_attention_small_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t H, int32_t head_dim, int32_t ld,
                              int32_t ldo, float scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Baseline JPEG decode on the GPU: a batch of FILES as one byte blob -> RGB pixels, byte-identical to
+ * PIL.Image.open(f).convert("RGB") (libjpeg-turbo defaults: ISLOW IDCT, fancy upsampling, YCbCr -> RGB tables) — the decode
+ * the reference pays per corpus image at retrieval/clip100_resnet_style_all_shots.py:270-281.
+ *   drag_jpeg_parse: data = concatenated files, offsets int64 [n+1] (device); writes one descriptor per file (device).
+ *     status 0 = decodable here; 1 not a JPEG, 2 truncated header, 3 progressive / arithmetic / lossless, 4 not 8-bit,
+ *     5 not grey / YCbCr, 6 sampling other than 4:4:4 / 4:2:2 / 4:2:0, 7 multi-scan, 8 table problem, 9 chroma <= 2 samples
+ *     wide.  Files with a non-zero status are skipped by drag_jpeg_decode_rgb (the caller decodes those few elsewhere).
+ *   drag_jpeg_decode_rgb: plan int64 [n, 3] (device) = per file: offset into coef_ws (int16 elements), into plane_ws
+ *     (bytes), into out_rgb (bytes); a file needs 64 * blocks int16 of coefficients and 64 * blocks bytes of planes where
+ *     blocks = sum over components of (mcus_x * hs) * (mcus_y * vs), and width * height * 3 output bytes ([H, W, 3]).
+ *     max_blocks / max_pixels: the largest per-file block / pixel count of the batch (launch geometry); coef_bytes: size of
+ *     coef_ws (zeroed by the call); qtab_ws: n * 3 * 64 uint16.  n <= 65535.
+ */
+typedef struct drag_jpeg_info {
+  int32_t status;
+  int32_t width, height, ncomp;
+  int32_t hs[3], vs[3];          /* sampling factors per component */
+  int32_t tq[3], td[3], ta[3];   /* quantisation / DC / AC table ids */
+  int32_t hmax, vmax, mcus_x, mcus_y;
+  int32_t restart_interval;
+  int32_t scan_off;              /* first entropy-coded byte */
+  int32_t dqt_off[4], dqt_16[4]; /* table offsets inside the file (-1 = absent), 16-bit flag */
+  int32_t dht_off[8];            /* [class * 4 + id] */
+  int32_t reserved[7];
+} drag_jpeg_info;
+int drag_jpeg_parse(const void* data, const int64_t* offsets, int32_t n, drag_jpeg_info* info, void* stream);
+int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jpeg_info* info, const int64_t* plan, int32_t n,
+                         int64_t max_blocks, int64_t max_pixels, void* coef_ws, int64_t coef_bytes, void* plane_ws,
+                         void* qtab_ws, void* out_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+// Host build of csrc/jpeg_core.h for tests/test_jpeg_core_host.py: the SAME functions the gfx950 kernels call, compiled with
+// g++ so their arithmetic can be compared with PIL's decode where there is no GPU.  Test infrastructure only.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../domain-rag_amd/csrc/jpeg_core.h"
+
+extern "C" int jpeg_host_info(const uint8_t* d, int64_t len, int32_t* out48) {
+  JpegInfo o;
+  jpeg_parse(d, len, &o);
+  memcpy(out48, &o, sizeof(o));
+  return o.status;
+}
+
+// decode to RGB [H, W, 3]; returns the parse status (nothing is written unless it is 0)
+extern "C" int jpeg_host_decode_rgb(const uint8_t* d, int64_t len, uint8_t* rgb) {
+  JpegInfo o;
+  jpeg_parse(d, len, &o);
+  if (o.status) return o.status;
+  std::vector<uint16_t> lut(4 * 256);
+  JpegHuffSlow slow[4];
+  const uint8_t* vals[4] = {nullptr, nullptr, nullptr, nullptr};
+  // table slots: 0 DC of luma, 1 AC of luma, 2 DC of chroma, 3 AC of chroma (component 1 and 2 may differ: build per component)
+  std::vector<std::vector<uint16_t>> luts(6, std::vector<uint16_t>(256));
+  JpegHuffSlow sl[6];
+  const uint8_t* vv[6];
+  for (int c = 0; c < o.ncomp; ++c) {
+    const uint8_t* dc = d + o.dht_off[o.td[c]];
+    const uint8_t* ac = d + o.dht_off[4 + o.ta[c]];
+    jpeg_build_huff(dc, luts[2 * c].data(), &sl[2 * c]); vv[2 * c] = dc + 16;
+    jpeg_build_huff(ac, luts[2 * c + 1].data(), &sl[2 * c + 1]); vv[2 * c + 1] = ac + 16;
+  }
+  (void)lut; (void)slow; (void)vals;
+  // coefficient storage
+  std::vector<std::vector<int16_t>> coef(o.ncomp);
+  for (int c = 0; c < o.ncomp; ++c) coef[c].assign((size_t)jpeg_blocks_w(&o, c) * jpeg_blocks_h(&o, c) * 64, 0);
+  JpegBits b;
+  jpeg_bits_init(&b, d, o.scan_off, len);
+  int pred[3] = {0, 0, 0};
+  int togo = o.restart_interval;
+  for (int my = 0; my < o.mcus_y; ++my)
+    for (int mx = 0; mx < o.mcus_x; ++mx) {
+      if (o.restart_interval && togo == 0) { jpeg_bits_restart(&b); pred[0] = pred[1] = pred[2] = 0; togo = o.restart_interval; }
+      for (int c = 0; c < o.ncomp; ++c)
+        for (int v = 0; v < o.vs[c]; ++v)
+          for (int h = 0; h < o.hs[c]; ++h) {
+            const int bx = mx * o.hs[c] + h, by = my * o.vs[c] + v;
+            int16_t* blk = coef[c].data() + ((size_t)by * jpeg_blocks_w(&o, c) + bx) * 64;
+            jpeg_decode_block(&b, luts[2 * c].data(), &sl[2 * c], vv[2 * c], luts[2 * c + 1].data(), &sl[2 * c + 1], vv[2 * c + 1],
+                              &pred[c], blk);
+          }
+      if (o.restart_interval) --togo;
+    }
+  // planes
+  std::vector<std::vector<uint8_t>> plane(o.ncomp);
+  for (int c = 0; c < o.ncomp; ++c) {
+    const int bw = jpeg_blocks_w(&o, c), bh = jpeg_blocks_h(&o, c), ld = bw * 8;
+    plane[c].assign((size_t)ld * bh * 8, 0);
+    uint16_t q[64];
+    const uint8_t* qt = d + o.dqt_off[o.tq[c]];
+    for (int k = 0; k < 64; ++k) q[jpeg_natural_order(k)] = o.dqt_16[o.tq[c]] ? (uint16_t)jpeg_u16(qt + 2 * k) : qt[k];
+    for (int by = 0; by < bh; ++by)
+      for (int bx = 0; bx < bw; ++bx)
+        jpeg_idct_block(coef[c].data() + ((size_t)by * bw + bx) * 64, q, plane[c].data() + (size_t)by * 8 * ld + bx * 8, ld);
+  }
+  const int W = o.width, H = o.height;
+  if (o.ncomp == 1) {
+    const int ld = jpeg_blocks_w(&o, 0) * 8;
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) { const uint8_t g = plane[0][(size_t)y * ld + x]; uint8_t* p = rgb + ((size_t)y * W + x) * 3; p[0] = p[1] = p[2] = g; }
+    return 0;
+  }
+  const int ld0 = jpeg_blocks_w(&o, 0) * 8, ld1 = jpeg_blocks_w(&o, 1) * 8;
+  const int dw = (W + o.hmax - 1) / o.hmax, dh = (H + o.vmax - 1) / o.vmax;
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int Y = plane[0][(size_t)y * ld0 + x];
+      const int cb = jpeg_upsampled(plane[1].data(), ld1, dw, dh, o.hmax, o.vmax, x, y);
+      const int cr = jpeg_upsampled(plane[2].data(), ld1, dw, dh, o.hmax, o.vmax, x, y);
+      jpeg_ycc_to_rgb(Y, cb, cr, rgb + ((size_t)y * W + x) * 3);
+    }
+  return 0;
+}

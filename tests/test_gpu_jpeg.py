@@ -1,0 +1,107 @@
+"""GPU JPEG decode (csrc/jpeg.hip) against PIL itself: Image.open(f).convert("RGB") byte for byte — the oracle here is the real
+dependency the reference decodes with (retrieval/clip100_resnet_style_all_shots.py:270-281), not a restatement."""
+import io
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageFile
+
+pytestmark = pytest.mark.gpu
+
+
+def natural_image(rng, h, w):
+    base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+    a = np.asarray(Image.fromarray(base).resize((w, h), Image.BICUBIC)).astype(np.int16) + rng.integers(-20, 20, (h, w, 3))
+    return Image.fromarray(np.clip(a, 0, 255).astype(np.uint8))
+
+
+def encode(im, **kw):
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, im.size[0] * im.size[1] * 4)
+    bio = io.BytesIO()
+    im.save(bio, "JPEG", **kw)
+    return bio.getvalue()
+
+
+def pil_rgb(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def test_mixed_batch_is_byte_identical_to_pil(gpu):
+    """one batch mixing sizes, subsamplings, qualities, optimised tables, grey images, restart markers and files the device
+    path must hand back (progressive, CMYK, a PNG, a truncated header)"""
+    from domain_rag_amd import jpeg
+    rng = np.random.default_rng(0)
+    blobs, want = [], []
+    for (w, h) in [(640, 480), (480, 640), (33, 17), (101, 77), (8, 8), (17, 40), (500, 375), (5, 3), (16, 1), (640, 480)]:
+        for sub in (0, 1, 2):
+            for q, kw in ((30, {}), (75, {"optimize": True}), (95, {}), (100, {"optimize": True})):
+                blobs.append(encode(natural_image(rng, h, w), quality=q, subsampling=sub, **kw))
+        blobs.append(encode(natural_image(rng, h, w).convert("L"), quality=80))
+    for kw in ({"restart_marker_blocks": 3}, {"restart_marker_rows": 1}):
+        blobs.append(encode(natural_image(rng, 90, 130), quality=80, subsampling=2, **kw))
+    blobs.append(encode(Image.fromarray(rng.integers(0, 256, (96, 120, 3), dtype=np.uint8)), quality=5))        # noise: saturation
+    n_ok = len(blobs)
+    rejected = [(encode(natural_image(rng, 40, 56), quality=80, progressive=True), 3),
+                (encode(natural_image(rng, 40, 56).convert("CMYK"), quality=80), 5),
+                (b"\x89PNG\r\n\x1a\n" + bytes(40), 1), (blobs[0][:40], 2)]
+    blobs += [b for b, _ in rejected]
+    batch = jpeg.decode_files(blobs, gpu)
+    assert len(batch) == len(blobs)
+    assert (batch.status[:n_ok] == 0).all(), [(i, int(s)) for i, s in enumerate(batch.status[:n_ok]) if s]
+    assert batch.status[n_ok:].tolist() == [s for _, s in rejected]
+    for i in range(n_ok):
+        ref = pil_rgb(blobs[i])
+        got = batch.image(i).cpu().numpy()
+        assert got.shape == ref.shape and np.array_equal(got, ref), (i, ref.shape, int(np.abs(got.astype(int) - ref).max()))
+    assert all(batch.image(i) is None for i in range(n_ok, len(blobs)))
+    # groups(): every decodable image exactly once, same-size images as one dense slab with the same bytes
+    seen = []
+    for (h, w), idx, imgs in batch.groups():
+        assert imgs.shape == (len(idx), h, w, 3) and imgs.is_contiguous()
+        for k, i in enumerate(idx.tolist()):
+            assert torch.equal(imgs[k], batch.image(i))
+        seen += idx.tolist()
+    assert sorted(seen) == list(range(n_ok))
+
+
+def test_decode_is_independent_of_the_batch(gpu):
+    """an image decodes to the same bytes alone, first, last or in the middle of a batch (per-lane state only)"""
+    from domain_rag_amd import jpeg
+    rng = np.random.default_rng(1)
+    files = [encode(natural_image(rng, 120, 160), quality=int(rng.integers(20, 98)), subsampling=int(rng.integers(0, 3))) for _ in range(70)]
+    full = jpeg.decode_files(files, gpu)
+    alone = jpeg.decode_files([files[37]], gpu)
+    assert torch.equal(alone.image(0), full.image(37))
+    rev = jpeg.decode_files(files[::-1], gpu)
+    for i in (0, 1, 63, 64, 69):                      # lanes of both waves, both ends
+        assert torch.equal(rev.image(len(files) - 1 - i), full.image(i))
+
+
+def test_decoded_pixels_feed_the_clip_preprocess_unchanged(gpu):
+    """decode -> PIL-exact resize + centre crop on the device == PIL decode -> PIL resize -> crop, byte for byte: the
+    embedding (and the top-k) cannot tell which route produced the crop"""
+    from domain_rag_amd import jpeg, resample
+    rng = np.random.default_rng(2)
+    files = [encode(natural_image(rng, 480, 640), quality=90, subsampling=2) for _ in range(3)] + \
+            [encode(natural_image(rng, 333, 500), quality=85, subsampling=1)]
+    batch = jpeg.decode_files(files, gpu)
+    crops = torch.empty((len(files), 224, 224, 3), dtype=torch.uint8, device=gpu)
+    for (h, w), idx, imgs in batch.groups():
+        out = resample.clip_preprocess_u8(imgs)
+        crops[torch.from_numpy(idx).to(gpu)] = out
+    for i, f in enumerate(files):
+        im = Image.open(io.BytesIO(f)).convert("RGB")
+        nw, nh, box = resample.clip_resize_plan(*im.size)
+        ref = np.asarray(im.resize((nw, nh), Image.BICUBIC).crop(box))
+        assert np.array_equal(crops[i].cpu().numpy(), ref), i
+
+
+def test_argument_errors(gpu):
+    from domain_rag_amd import jpeg
+    with pytest.raises(ValueError):
+        jpeg.decode_files([], gpu)
+    with pytest.raises(RuntimeError):
+        jpeg.decode_files([b"x"], "cpu")
+    b = jpeg.decode_files([b"not a jpeg at all"], gpu)
+    assert b.status.tolist() == [1] and b.image(0) is None and list(b.groups()) == []
