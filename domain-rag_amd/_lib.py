@@ -93,7 +93,7 @@ SIGNATURES = {
     "drag_attention_small_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     "drag_lama_blend_u8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "drag_jpeg_parse": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "drag_jpeg_decode_rgb": (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int64, c_void_p, c_int64] + [c_void_p] * 4),
+    "drag_jpeg_decode_rgb": (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int64, c_void_p, c_int64] + [c_void_p] * 5),
 }
 
 _lib = None

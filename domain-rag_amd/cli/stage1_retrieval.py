@@ -126,6 +126,9 @@ def build_parser():
     p.add_argument("--no-visuals", action="store_true", help="skip the per-query *_visual.jpg contact sheets")
     p.add_argument("--decode-procs", type=int, default=-1,
                    help="worker processes for JPEG decode + CLIP resize/crop of the corpus (-1: auto, 0: thread pool + GPU resize)")
+    p.add_argument("--decode", choices=["gpu", "host"], default="gpu",
+                   help="corpus JPEG decode: on the GPU (default; byte-identical to PIL, the host only reads the files) or on the "
+                        "host (PIL in --decode-procs worker processes / threads)")
     p.add_argument("--host-preprocess", action="store_true",
                    help="resize on the host with PIL like the reference (default: PIL-exact resize on the GPU; same bits)")
     p.add_argument("--style-cache", type=str, default=None,
@@ -239,7 +242,8 @@ def load_or_compute_features(args, tag, root, subdirs, pre_feats, pre_paths, mod
     if procs < 0:                                   # auto: worker processes when the host has cores to spare
         ncpu = os.cpu_count() or 1
         procs = min(32, ncpu // 2) if ncpu >= 8 else 0
-    feats, valid = R.compute_corpus_features(model, preprocess, paths, batch=args.embed_batch, decode_procs=procs)
+    feats, valid = R.compute_corpus_features(model, preprocess, paths, batch=args.embed_batch, decode_procs=procs,
+                                             gpu_decode=(args.decode == "gpu" and not args.host_preprocess))
     if rank0 and len(feats):
         np.save(cache_f, feats)
         with open(cache_p, "w") as fh:

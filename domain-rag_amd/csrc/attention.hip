@@ -157,60 +157,9 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   const int b = bh / p.H, h = bh - b * p.H;
   const int q0 = (loc - (loc / nqb) * nqb) * QB + w * 32;
 
-  // ---- Q fragments stay in registers: B operand, lane -> query (l&31), k = 16ks + 8hh .. +8 ----
+  // ---- Q fragments stay in registers: B operand, lane -> query (l&31), k = 16ks + 8hh .. +8 (loaded below, after the
+  // first K / V^T tiles have been requested: one workgroup per CU, so nothing else hides this prologue's latency) ----
   bf16x8_t qf[8];
-  {
-    const int qr = min(q0 + (l & 31), p.S - 1);
-    const bf16_t* qp = p.q + (long long)b * p.qk_bs + (long long)qr * p.ld_qk + h * 128 + hh * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
-    if (p.wq_txt != nullptr || p.cosT != nullptr) {
-      // per-head RMSNorm(128) + interleaved RoPE of this lane's query row, with the rounding points of the separate pass
-      // (qk_norm_rope_vt_kernel): rbf(rbf(x * rs) * w), rotation in fp32, one rounding to bf16.  The lane holds 64 of the
-      // row's 128 elements (d = 16 ks + 8 hh + 0..7), lane ^ 32 the other 64; RoPE pairs (2j, 2j+1) never straddle lanes.
-      u32x4_t raw[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) raw[ks] = __builtin_bit_cast(u32x4_t, qf[ks]);
-      float rs = 1.f;
-      const bf16_t* wsel = nullptr;
-      if (p.wq_txt != nullptr) {
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
-            ss += a0 * a0;
-            ss += a1 * a1;
-          }
-        ss += __shfl_xor(ss, 32, 64);
-        rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
-        wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        u32x4_t wr = (u32x4_t){0u, 0u, 0u, 0u};
-        if (wsel != nullptr) wr = *(const u32x4_t*)(wsel + ks * 16);
-        f32x4_t c4 = (f32x4_t){1.f, 1.f, 1.f, 1.f}, s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (p.cosT != nullptr) {
-          c4 = *(const f32x4_t*)(p.cosT + (long long)qr * 64 + ks * 8 + hh * 4);
-          s4 = *(const f32x4_t*)(p.sinT + (long long)qr * 64 + ks * 8 + hh * 4);
-        }
-        u32x4_t o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
-          if (wsel != nullptr) {
-            a0 = rbf(rbf(a0 * rs) * bf2f((bf16_t)(wr[j] & 0xffff)));
-            a1 = rbf(rbf(a1 * rs) * bf2f((bf16_t)(wr[j] >> 16)));
-          }
-          o[j] = pack2bf(a0 * c4[j] - a1 * s4[j], a1 * c4[j] + a0 * s4[j]);
-        }
-        qf[ks] = __builtin_bit_cast(bf16x8_t, o);
-      }
-    }
-  }
-
   // ---- staging descriptors ----
   const bf16_t* kbase = p.k + (long long)b * p.qk_bs + h * 128;
   const bf16_t* vbase = p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
@@ -304,6 +253,59 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   stage_k(0, 0);
   stage_v(0, 0);
   if (nkv > 1) stage_k(1, 64);
+  // Q load (+ optional RMSNorm / RoPE) while those tiles are in flight
+  {
+    const int qr = min(q0 + (l & 31), p.S - 1);
+    const bf16_t* qp = p.q + (long long)b * p.qk_bs + (long long)qr * p.ld_qk + h * 128 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
+    if (p.wq_txt != nullptr || p.cosT != nullptr) {
+      // per-head RMSNorm(128) + interleaved RoPE of this lane's query row, with the rounding points of the separate pass
+      // (qk_norm_rope_vt_kernel): rbf(rbf(x * rs) * w), rotation in fp32, one rounding to bf16.  The lane holds 64 of the
+      // row's 128 elements (d = 16 ks + 8 hh + 0..7), lane ^ 32 the other 64; RoPE pairs (2j, 2j+1) never straddle lanes.
+      u32x4_t raw[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) raw[ks] = __builtin_bit_cast(u32x4_t, qf[ks]);
+      float rs = 1.f;
+      const bf16_t* wsel = nullptr;
+      if (p.wq_txt != nullptr) {
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+            ss += a0 * a0;
+            ss += a1 * a1;
+          }
+        ss += __shfl_xor(ss, 32, 64);
+        rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
+        wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        u32x4_t wr = (u32x4_t){0u, 0u, 0u, 0u};
+        if (wsel != nullptr) wr = *(const u32x4_t*)(wsel + ks * 16);
+        f32x4_t c4 = (f32x4_t){1.f, 1.f, 1.f, 1.f}, s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (p.cosT != nullptr) {
+          c4 = *(const f32x4_t*)(p.cosT + (long long)qr * 64 + ks * 8 + hh * 4);
+          s4 = *(const f32x4_t*)(p.sinT + (long long)qr * 64 + ks * 8 + hh * 4);
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+          if (wsel != nullptr) {
+            a0 = rbf(rbf(a0 * rs) * bf2f((bf16_t)(wr[j] & 0xffff)));
+            a1 = rbf(rbf(a1 * rs) * bf2f((bf16_t)(wr[j] >> 16)));
+          }
+          o[j] = pack2bf(a0 * c4[j] - a1 * s4[j], a1 * c4[j] + a0 * s4[j]);
+        }
+        qf[ks] = __builtin_bit_cast(bf16x8_t, o);
+      }
+    }
+  }
+
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll

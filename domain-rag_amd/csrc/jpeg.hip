@@ -36,6 +36,7 @@ struct JpegArgs {
   uint8_t* planes;
   uint16_t* qtab;           // [n, 3, 64] quantisation tables in natural order
   uint8_t* out;
+  int32_t* scan_status;     // [n]: 0 = the entropy-coded data ended at the EOI marker, as a clean file's does
   int n;
 };
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
   const int i = blockIdx.x * 64 + lane;
   if (i >= a.n) return;
   const JpegInfo o = a.info[i];
-  if (o.status != 0) return;
+  if (o.status != 0) { a.scan_status[i] = 0; return; }
   const uint8_t* d = a.data + a.off[i];
   const int64_t len = a.off[i + 1] - a.off[i];
   JpegHuffSlow slow[4];
@@ -110,6 +111,10 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
       }
       if (o.restart_interval) --togo;
     }
+  // A clean scan ends with < 8 padding bits followed by EOI.  Anything else (data cut short, trailing segments, a decoder
+  // that lost sync on damaged data) is reported: libjpeg / PIL decide what such a file means (warning, OSError), not this kernel.
+  jpeg_bits_fill(&b);
+  a.scan_status[i] = (b.marker == 0xD9 && b.pos + 2 <= len) ? 0 : 1;
 }
 
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegArgs a) {
@@ -170,14 +175,15 @@ extern "C" int drag_jpeg_parse(const void* data, const int64_t* offsets, int32_t
 
 extern "C" int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jpeg_info* info, const int64_t* plan,
                                     int32_t n, int64_t max_blocks, int64_t max_pixels, void* coef_ws, int64_t coef_bytes,
-                                    void* plane_ws, void* qtab_ws, void* out_rgb, void* stream) {
-  DRAG_CHECK(data && offsets && info && plan && coef_ws && plane_ws && qtab_ws && out_rgb, "drag_jpeg_decode_rgb: null pointer");
+                                    void* plane_ws, void* qtab_ws, void* out_rgb, int32_t* scan_status, void* stream) {
+  DRAG_CHECK(data && offsets && info && plan && coef_ws && plane_ws && qtab_ws && out_rgb && scan_status,
+             "drag_jpeg_decode_rgb: null pointer");
   DRAG_CHECK(n > 0 && max_blocks > 0 && max_pixels > 0 && coef_bytes > 0, "drag_jpeg_decode_rgb: bad sizes");
   DRAG_CHECK(max_blocks < (1ll << 31) * 256 && max_pixels < (1ll << 31) * 256 && n <= 65535, "drag_jpeg_decode_rgb: batch too large");
   hipStream_t st = (hipStream_t)stream;
   JpegArgs a;
   a.data = (const uint8_t*)data; a.off = offsets; a.info = (const JpegInfo*)info; a.plan = plan;
-  a.coef = (int16_t*)coef_ws; a.planes = (uint8_t*)plane_ws; a.qtab = (uint16_t*)qtab_ws; a.out = (uint8_t*)out_rgb; a.n = n;
+  a.coef = (int16_t*)coef_ws; a.planes = (uint8_t*)plane_ws; a.qtab = (uint16_t*)qtab_ws; a.out = (uint8_t*)out_rgb; a.scan_status = scan_status; a.n = n;
   hipError_t e = hipMemsetAsync(coef_ws, 0, (size_t)coef_bytes, st);     // blocks are sparse: only non-zero coefficients are stored
   DRAG_CHECK(e == hipSuccess, "drag_jpeg_decode_rgb: memset failed");
   const int lds = 4 * 256 * 64 * 2;                                       // 128 KiB: one wave per CU

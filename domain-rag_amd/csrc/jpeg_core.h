@@ -222,7 +222,30 @@ struct JpegBits {
 JHD void jpeg_bits_init(JpegBits* b, const uint8_t* d, int64_t pos, int64_t end) {
   b->d = d; b->pos = pos; b->end = end; b->buf = 0; b->cnt = 0; b->marker = 0;
 }
+// Guarantees > 32 valid bits (one code of <= 16 bits plus <= 16 extra bits) whenever the stream has them.  Fast path: four
+// bytes at once when none of them is 0xFF (no stuffing, no marker) — entropy-coded data is 0xFF-free almost everywhere, so
+// the byte-wise loop below (stuffed zeros, markers, the last bytes of the file) runs rarely.
 JHD void jpeg_bits_fill(JpegBits* b) {
+  if (b->cnt > 32) return;
+  if (!b->marker && b->pos + 4 <= b->end) {
+    uint32_t le;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // hipcc splits an align-1 load into four byte loads: fetch the two aligned dwords around the position (one 8-byte
+    // request; the blob is padded, so the second dword always exists) and funnel-shift them (v_alignbyte_b32)
+    const uintptr_t a = (uintptr_t)(b->d + b->pos);
+    const uint32_t* p4 = (const uint32_t*)(a & ~(uintptr_t)3);
+    le = __builtin_amdgcn_alignbyte(p4[1], p4[0], (unsigned)(a & 3));
+#else
+    __builtin_memcpy(&le, b->d + b->pos, 4);
+#endif
+    const uint32_t w = __builtin_bswap32(le);          // the stream is big-endian
+    if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) {          // no byte of w is 0xFF
+      b->buf |= (uint64_t)w << (32 - b->cnt);
+      b->cnt += 32;
+      b->pos += 4;
+      return;
+    }
+  }
   while (b->cnt <= 56) {
     unsigned byte = 0;
     if (!b->marker && b->pos < b->end) {

@@ -24,7 +24,7 @@ from .ops import _p, _stream, check
 INFO_WORDS = 48
 STATUS_TEXT = {0: "ok", 1: "not a JPEG", 2: "truncated header", 3: "progressive / arithmetic / lossless", 4: "not 8-bit",
                5: "not grey or YCbCr", 6: "sampling other than 4:4:4 / 4:2:2 / 4:2:0", 7: "multi-scan", 8: "table problem",
-               9: "chroma at most 2 samples wide"}
+               9: "chroma at most 2 samples wide", 10: "entropy-coded data does not end at EOI (cut short / trailing data / damaged)"}
 
 
 class DecodedBatch:
@@ -82,8 +82,9 @@ def _upload(blobs, device):
     return data, offsets
 
 
-def decode_files(blobs, device="cuda") -> DecodedBatch:
-    """``blobs``: list of bytes objects (whole files).  All arithmetic runs in libdomainrag_hip.so."""
+def decode_files(blobs, device="cuda", check_scan: bool = True) -> DecodedBatch:
+    """``blobs``: list of bytes objects (whole files).  All arithmetic runs in libdomainrag_hip.so.  ``check_scan``: read the
+    per-file end-of-scan flags back (one more synchronisation) and mark files whose entropy data does not end at EOI."""
     lib = _lib.load()
     n = len(blobs)
     if n == 0:
@@ -122,8 +123,11 @@ def decode_files(blobs, device="cuda") -> DecodedBatch:
     planes = torch.empty(max(po, 1), dtype=torch.uint8, device=device)
     qtab = torch.empty((n, 3, 64), dtype=torch.int16, device=device)
     d_plan = torch.from_numpy(plan).to(device)
+    scan = torch.empty(n, dtype=torch.int32, device=device)
     check(lib.drag_jpeg_decode_rgb(_p(data), _p(d_off), _p(d_info), _p(d_plan), n, int(blocks.max()), int(pixels.max()),
-                                   _p(coef), coef.numel() * 2, _p(planes), _p(qtab), _p(out), _stream()), "drag_jpeg_decode_rgb")
+                                   _p(coef), coef.numel() * 2, _p(planes), _p(qtab), _p(out), _p(scan), _stream()), "drag_jpeg_decode_rgb")
+    if check_scan:      # a scan that does not end at EOI: let libjpeg / PIL decide what the file means (status 10)
+        info[:, 0] = np.where((info[:, 0] == 0) & (scan.cpu().numpy() != 0), 10, info[:, 0])
     return DecodedBatch(info, out, plan[:, 2], order)
 
 

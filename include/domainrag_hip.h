@@ -333,6 +333,9 @@ int drag_attention_small_f32(const float* qkv, float* out, int32_t B, int32_t T,
  *     blocks = sum over components of (mcus_x * hs) * (mcus_y * vs), and width * height * 3 output bytes ([H, W, 3]).
  *     max_blocks / max_pixels: the largest per-file block / pixel count of the batch (launch geometry); coef_bytes: size of
  *     coef_ws (zeroed by the call); qtab_ws: n * 3 * 64 uint16.  n <= 65535.
+ *     scan_status int32 [n] (device): 0 when the entropy-coded data ended at the EOI marker as a clean file's does, 1 otherwise
+ *     (cut short, trailing data, damaged): such a file's pixels are what this decoder made of it, and the caller should let
+ *     libjpeg / PIL decide instead (they warn or raise).
  */
 typedef struct drag_jpeg_info {
   int32_t status;
@@ -349,7 +352,7 @@ typedef struct drag_jpeg_info {
 int drag_jpeg_parse(const void* data, const int64_t* offsets, int32_t n, drag_jpeg_info* info, void* stream);
 int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jpeg_info* info, const int64_t* plan, int32_t n,
                          int64_t max_blocks, int64_t max_pixels, void* coef_ws, int64_t coef_bytes, void* plane_ws,
-                         void* qtab_ws, void* out_rgb, void* stream);
+                         void* qtab_ws, void* out_rgb, int32_t* scan_status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,3 +37,7 @@ for workers in (1, 16):
     t0 = time.perf_counter(); b, valid = R.compute_corpus_features(model, R.load_clip_device_preprocess(dev), paths, 256, decode_workers=workers); t_new = (time.perf_counter() - t0) / N
     print(f"decode_workers={workers}: {1/t_new:.0f} img/s ({t_new*1e3:.2f} ms/img) vs reference-shaped loop {1/t_ref:.0f} img/s ({t_ref*1e3:.2f} ms/img): {t_ref/t_new:.1f}x; "
           f"embeddings bit-identical: {np.array_equal(a, b[:500])}", flush=True)
+R.compute_corpus_features(model, None, paths[:256], 256, gpu_decode=True)
+t0 = time.perf_counter(); b, valid = R.compute_corpus_features(model, None, paths, 1024, gpu_decode=True); t_new = (time.perf_counter() - t0) / N
+print(f"gpu_decode: {1/t_new:.0f} img/s ({t_new*1e3:.3f} ms/img) vs reference-shaped loop {1/t_ref:.0f} img/s: {t_ref/t_new:.1f}x; "
+      f"embeddings bit-identical: {np.array_equal(a, b[:500])}", flush=True)
