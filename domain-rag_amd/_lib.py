@@ -48,6 +48,7 @@ class Conv2dF32Args(ctypes.Structure):
 SIGNATURES = {
     "drag_version": (c_int, []),
     "drag_last_error": (ctypes.c_char_p, []),
+    "drag_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "drag_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     "drag_qk_norm_rope_vt_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "drag_attention_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float, c_void_p]),

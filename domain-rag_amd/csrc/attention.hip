@@ -141,7 +141,11 @@ constexpr float DEFER_THR = 8.0f;     // log2 units; 0 = rescale on every increa
 constexpr int KT_BYTES = 64 * 256;   // K tile   [64 keys][128 d] bf16
 constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 
-template <int NW>   // NW: waves per block (4 or 8), 32 queries each
+// SCHED 0: per KV tile, 16 {S(j+1) MFMA | exp of S(j)} steps, then the 16 P V MFMAs.
+// SCHED 1: the P V MFMAs of key group s2 are issued as soon as that group's 16 probabilities are packed (from step 4 on, one
+//          per step next to the S MFMA), so the exp stream is spread over 28 MFMAs instead of 16 and only 4 P V MFMAs trail
+//          the loop.  Same arithmetic, same order per accumulator: bit-identical outputs.
+template <int NW, int SCHED>   // NW: waves per block (4 or 8), 32 queries each
 __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
   const int w = wave_id(), l = lane_id();
@@ -373,6 +377,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
           const int t1 = (g + 1) >> 3, ks1 = (g + 1) & 7;
           kf = *(const bf16x8_t*)(smem + (ak[ks1] + (KN + t1 * (32 * 256))));
         }
+        bf16x8_t vfg;
+        if (SCHED == 1 && g >= 4) vfg = *(const bf16x8_t*)(smem + (av[(g >> 2) - 1] + (VB + (g & 3) * (32 * 128))));
         sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], (g & 7) == 0 ? zero16 : sn[g >> 3], 0, 0, 0);
         // unconditional (no branches: a branch here splits the block and hipcc then hoists the whole softmax out of the
         // interleave): past the last tile the K rows clamp to S-1 and the V^T offsets fall outside the descriptor's range
@@ -391,6 +397,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
         uint32_t wd = pack2bf(e0, e1);
         asm volatile("" : "+v"(wd), "+v"(ps));
         pk[g >> 2][g & 3] = wd;
+        if (SCHED == 1 && g >= 4)       // O^T[dt = g & 3] += V^T[.., keys of group (g >> 2) - 1] P^T: that group was packed >= 1 step ago
+          oacc[g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfg, __builtin_bit_cast(bf16x8_t, pk[(g >> 2) - 1]), oacc[g & 3], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     for (int s2 = 0; s2 < 4; ++s2) pf[s2] = __builtin_bit_cast(bf16x8_t, pk[s2]);
     // ---- O^T += V^T P^T ----
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
+    for (int s2 = (SCHED == 1 ? 3 : 0); s2 < 4; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8_t vf = *(const bf16x8_t*)(smem + (av[s2] + (VB + dt * (32 * 128))));
@@ -518,13 +526,15 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
   const int groups = (B * H + 7) / 8;
-  static const bool force_w4 = getenv("DRAG_ATTN_W4") != nullptr;     // A/B switch, read once per process
-  const bool w8 = !force_w4 && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
+  const bool w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
   const int QB = w8 ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
-  if (w8) hipLaunchKernelGGL((attention_d128_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attention_d128_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  const bool s1 = drag_opt(DRAG_OPT_ATTN_SCHED) == 1;
+  if (w8 && s1) hipLaunchKernelGGL((attention_d128_kernel<8, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else if (w8) hipLaunchKernelGGL((attention_d128_kernel<8, 0>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else if (s1) hipLaunchKernelGGL((attention_d128_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attention_d128_kernel<4, 0>), grid, dim3(256), 0, (hipStream_t)stream, p);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

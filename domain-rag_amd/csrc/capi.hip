@@ -1,5 +1,6 @@
 // capi.hip — version / error plumbing of the C ABI (include/domainrag_hip.h).
 #include "drag_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -11,3 +12,37 @@ void drag_set_error(const char* msg) {
 
 extern "C" const char* drag_last_error(void) { return g_err; }
 extern "C" int drag_version(void) { return 100; }  // 0.1.0
+
+// ---- tuning switches (measurement only: every setting computes the same values unless its comment says otherwise).  Initial
+// values come from the environment ONCE; drag_set_option changes them at run time so one process can A/B kernels.
+static int g_opt[DRAG_OPT_COUNT];
+static bool g_opt_init = false;
+static const char* const g_opt_names[DRAG_OPT_COUNT] = {"attn_sched", "attn_w4"};
+static const char* const g_opt_env[DRAG_OPT_COUNT] = {"DRAG_ATTN_SCHED", "DRAG_ATTN_W4"};
+
+static void opt_init() {
+  if (g_opt_init) return;
+  for (int i = 0; i < DRAG_OPT_COUNT; ++i) {
+    const char* e = getenv(g_opt_env[i]);
+    g_opt[i] = e ? (*e ? atoi(e) : 1) : 0;
+  }
+  g_opt[DRAG_OPT_ATTN_SCHED] = getenv(g_opt_env[DRAG_OPT_ATTN_SCHED]) ? g_opt[DRAG_OPT_ATTN_SCHED] : DRAG_ATTN_SCHED_DEFAULT;
+  g_opt_init = true;
+}
+
+int drag_opt(int idx) {
+  opt_init();
+  return g_opt[idx];
+}
+
+extern "C" int drag_set_option(const char* name, int32_t value) {
+  DRAG_CHECK(name != nullptr, "drag_set_option: null name");
+  opt_init();
+  for (int i = 0; i < DRAG_OPT_COUNT; ++i)
+    if (strcmp(name, g_opt_names[i]) == 0) {
+      g_opt[i] = value;
+      return 0;
+    }
+  drag_set_error("drag_set_option: unknown option (attn_sched, attn_w4)");
+  return -1;
+}

@@ -86,6 +86,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// tuning switches (capi.hip): read once from the environment, changeable through drag_set_option
+enum { DRAG_OPT_ATTN_SCHED = 0, DRAG_OPT_ATTN_W4 = 1, DRAG_OPT_COUNT = 2 };
+#define DRAG_ATTN_SCHED_DEFAULT 0
+int drag_opt(int idx);
+
 // error plumbing shared by the C ABI
 void drag_set_error(const char* msg);
 #define DRAG_CHECK(cond, msg)          \

@@ -52,64 +52,80 @@ __global__ __launch_bounds__(64) void jpeg_parse_kernel(const uint8_t* data, con
   info[i] = o;
 }
 
+struct LdsNat {                      // zigzag -> natural order, one copy per wave
+  DRAG_LDS uint8_t* t;
+  __device__ __forceinline__ DRAG_LDS uint8_t& operator[](int k) const { return t[k]; }
+};
+
+constexpr int JPEG_LUT_LDS = 4 * 256 * 64 * 2;      // 128 KiB of code tables per wave
+constexpr int JPEG_HUFF_LDS = JPEG_LUT_LDS + 128;   // + the natural-order table
+
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];     // [4 tables][256 entries][64 lanes]
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];     // [4 tables][256 entries][64 lanes] | natural order [80]
   const int lane = threadIdx.x;
   const int i = blockIdx.x * 64 + lane;
+  const LdsNat nat{(DRAG_LDS uint8_t*)lds + JPEG_LUT_LDS};
+  for (int k = lane; k < 80; k += 64) nat[k] = (uint8_t)jpeg_natural_order(k);
+  __syncthreads();
   if (i >= a.n) return;
-  const JpegInfo o = a.info[i];
+  const JpegInfo& o = a.info[i];
   if (o.status != 0) { a.scan_status[i] = 0; return; }
   const uint8_t* d = a.data + a.off[i];
   const int64_t len = a.off[i + 1] - a.off[i];
   JpegHuffSlow slow[4];
-  const uint8_t* vals[4];
-  LdsLut lut[4];
+  DRAG_LDS uint16_t* const lut0 = (DRAG_LDS uint16_t*)lds + lane;     // table t of this lane: lut0 + t * 256 * 64
 #pragma unroll
   for (int t = 0; t < 4; ++t) {                      // t = class * 2 + id
-    lut[t].base = (DRAG_LDS uint16_t*)lds + t * 256 * 64 + lane;
     const int ofs = o.dht_off[(t >> 1) * 4 + (t & 1)];
-    vals[t] = nullptr;
-    if (ofs >= 0) {
-      jpeg_build_huff(d + ofs, lut[t], &slow[t]);
-      vals[t] = d + ofs + 16;
-    }
+    if (ofs >= 0) jpeg_build_huff(d + ofs, LdsLut{lut0 + t * 256 * 64}, &slow[t]);
   }
-  // quantisation tables of the components, natural order, for the IDCT kernel
-  for (int c = 0; c < o.ncomp; ++c) {
-    const uint8_t* qt = d + o.dqt_off[o.tq[c]];
-    uint16_t* q = a.qtab + ((long long)i * 3 + c) * 64;
-    for (int k = 0; k < 64; ++k) q[jpeg_natural_order(k)] = o.dqt_16[o.tq[c]] ? (uint16_t)jpeg_u16(qt + 2 * k) : (uint16_t)qt[k];
-  }
+  // per-component constants with STATIC indices (a dynamically indexed local array lives in scratch = global memory, and a
+  // scratch access per block costs this one-wave-per-CU kernel a full memory round trip)
+  const int ncomp = o.ncomp, mcus_x = o.mcus_x, mcus_y = o.mcus_y, rst = o.restart_interval;
+  int hs[3], vs[3], bw[3], td[3], ta[3];
   int16_t* cbase[3];
-  int bw[3];
+  const uint8_t *dcv[3], *acv[3];
   {
     long long p = a.plan[(long long)i * 3];
-    for (int c = 0; c < o.ncomp; ++c) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const bool on = c < ncomp;
+      hs[c] = on ? o.hs[c] : 0; vs[c] = on ? o.vs[c] : 0;
+      td[c] = on ? o.td[c] : 0; ta[c] = on ? 2 + o.ta[c] : 2;
+      bw[c] = mcus_x * hs[c];
       cbase[c] = a.coef + p;
-      bw[c] = o.mcus_x * o.hs[c];
-      p += (long long)bw[c] * (o.mcus_y * o.vs[c]) * 64;
+      p += (long long)bw[c] * (mcus_y * vs[c]) * 64;
+      dcv[c] = d + o.dht_off[td[c] & 1] + 16;
+      acv[c] = d + o.dht_off[4 + (ta[c] & 1)] + 16;
+      if (on) {                                      // quantisation table, natural order, for the IDCT kernel
+        const uint8_t* qt = d + o.dqt_off[o.tq[c]];
+        const bool q16 = o.dqt_16[o.tq[c]] != 0;
+        uint16_t* q = a.qtab + ((long long)i * 3 + c) * 64;
+        for (int k = 0; k < 64; ++k) q[nat[k]] = q16 ? (uint16_t)jpeg_u16(qt + 2 * k) : (uint16_t)qt[k];
+      }
     }
   }
   JpegBits b;
   jpeg_bits_init(&b, d, o.scan_off, len);
   int pred[3] = {0, 0, 0};
-  int togo = o.restart_interval;
-  for (int my = 0; my < o.mcus_y; ++my)
-    for (int mx = 0; mx < o.mcus_x; ++mx) {
-      if (o.restart_interval && togo == 0) {
+  int togo = rst;
+  for (int my = 0; my < mcus_y; ++my)
+    for (int mx = 0; mx < mcus_x; ++mx) {
+      if (rst && togo == 0) {
         jpeg_bits_restart(&b);
         pred[0] = pred[1] = pred[2] = 0;
-        togo = o.restart_interval;
+        togo = rst;
       }
-      for (int c = 0; c < o.ncomp; ++c) {
-        const int td = o.td[c], ta = 2 + o.ta[c];
-        for (int v = 0; v < o.vs[c]; ++v)
-          for (int h = 0; h < o.hs[c]; ++h) {
-            int16_t* blk = cbase[c] + ((long long)(my * o.vs[c] + v) * bw[c] + mx * o.hs[c] + h) * 64;
-            jpeg_decode_block(&b, lut[td], &slow[td], vals[td], lut[ta], &slow[ta], vals[ta], &pred[c], blk);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const LdsLut dcl{lut0 + td[c] * 256 * 64}, acl{lut0 + ta[c] * 256 * 64};
+        for (int v = 0; v < vs[c]; ++v)
+          for (int h = 0; h < hs[c]; ++h) {
+            int16_t* blk = cbase[c] + ((long long)(my * vs[c] + v) * bw[c] + mx * hs[c] + h) * 64;
+            jpeg_decode_block(&b, dcl, &slow[td[c]], dcv[c], acl, &slow[ta[c]], acv[c], nat, &pred[c], blk);
           }
       }
-      if (o.restart_interval) --togo;
+      if (rst) --togo;
     }
   // A clean scan ends with < 8 padding bits followed by EOI.  Anything else (data cut short, trailing segments, a decoder
   // that lost sync on damaged data) is reported: libjpeg / PIL decide what such a file means (warning, OSError), not this kernel.
@@ -186,7 +202,7 @@ extern "C" int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, co
   a.coef = (int16_t*)coef_ws; a.planes = (uint8_t*)plane_ws; a.qtab = (uint16_t*)qtab_ws; a.out = (uint8_t*)out_rgb; a.scan_status = scan_status; a.n = n;
   hipError_t e = hipMemsetAsync(coef_ws, 0, (size_t)coef_bytes, st);     // blocks are sparse: only non-zero coefficients are stored
   DRAG_CHECK(e == hipSuccess, "drag_jpeg_decode_rgb: memset failed");
-  const int lds = 4 * 256 * 64 * 2;                                       // 128 KiB: one wave per CU
+  const int lds = JPEG_HUFF_LDS;                                          // 128 KiB + 128 B: one wave per CU
   static bool lds_ok = false;
   if (!lds_ok) {
     e = hipFuncSetAttribute((const void*)jpeg_huffman_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -298,9 +298,16 @@ JHD void jpeg_bits_restart(JpegBits* b) {
 }
 
 // one 8x8 block: DC difference + AC run/size pairs -> coefficients in NATURAL order (the block must be zero on entry)
-template <typename LUT>
+// `nat`: the zigzag -> natural-order table (64 + 16 entries, jpeg_fill_natural_order) in whatever memory is cheap to index
+// per lane — LDS on the GPU (a per-symbol lookup in global memory stalls the in-order wave for a full memory round trip).
+template <typename NAT>
+JHD void jpeg_fill_natural_order(NAT nat) {
+  for (int k = 0; k < 80; ++k) nat[k] = (uint8_t)jpeg_natural_order(k);
+}
+
+template <typename LUT, typename NAT>
 JHD void jpeg_decode_block(JpegBits* b, LUT dc_lut, const JpegHuffSlow* dc_slow, const uint8_t* dc_vals, LUT ac_lut,
-                           const JpegHuffSlow* ac_slow, const uint8_t* ac_vals, int* dc_pred, int16_t* coef) {
+                           const JpegHuffSlow* ac_slow, const uint8_t* ac_vals, NAT nat, int* dc_pred, int16_t* coef) {
   jpeg_bits_fill(b);
   int s = jpeg_decode_symbol(b, dc_lut, dc_slow, dc_vals) & 15;
   if (s) *dc_pred += jpeg_receive_extend(b, s);     // a fill leaves >= 57 bits: enough for a 16-bit code + 16 extra bits
@@ -313,7 +320,7 @@ JHD void jpeg_decode_block(JpegBits* b, LUT dc_lut, const JpegHuffSlow* dc_slow,
     if (s) {
       k += r;
       const int v = jpeg_receive_extend(b, s);
-      coef[jpeg_natural_order(k)] = (int16_t)v;
+      coef[nat[k]] = (int16_t)v;                      // k <= 63 + 15: entries past 63 alias 63 like libjpeg's table
     } else {
       if (r != 15) break;
       k += 15;

@@ -75,6 +75,11 @@ def set_recorder(rec: GemmRecorder | None) -> None:
     _recorder = rec
 
 
+def set_option(name: str, value: int) -> None:
+    """measurement switch of the library (``drag_set_option``): "attn_sched", "attn_w4" """
+    check(_lib.load().drag_set_option(name.encode(), int(value)), "drag_set_option")
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -1,4 +1,4 @@
-"""attention kernel variants, interleaved (DVFS drift cancels): 8-wave vs 4-wave blocks"""
+"""attention kernel variants, interleaved rounds in one process (DVFS drift cancels): KV-loop schedules, 8- vs 4-wave blocks"""
 import math, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ def bench(fn, iters=10):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-VARIANTS = {"8-wave": {}, "4-wave": {"DRAG_ATTN_W4": "1"}}
+VARIANTS = {"sched0": {"attn_sched": 0}, "sched1": {"attn_sched": 1}, "sched0-4wave": {"attn_sched": 0, "attn_w4": 1}}
 for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
     D = H * 128
     qkv = torch.randn(B, S, 3 * D, device=dev).bfloat16()
@@ -25,9 +25,9 @@ for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
     t = {k: [] for k in VARIANTS}
     for rep in range(6):
         for name, env in VARIANTS.items():
-            for k in ("DRAG_ATTN_PIPE1", "DRAG_ATTN_W4", "DRAG_ATTN_NOSYNC"): os.environ.pop(k, None)
-            os.environ.update(env)
+            for k in ("attn_sched", "attn_w4"): ops.set_option(k, 0)
+            for k, v in env.items(): ops.set_option(k, v)
             if rep == 0: bench(run, 3)
             t[name].append(bench(run))
-    for k in ("DRAG_ATTN_PIPE1", "DRAG_ATTN_W4", "DRAG_ATTN_NOSYNC"): os.environ.pop(k, None)
+    for k in ("attn_sched", "attn_w4"): ops.set_option(k, 0)
     print(f"attn B={B} S={S} H={H}: " + " | ".join(f"{k} {fl/statistics.median(v)/1e9:.0f} TF/s" for k, v in t.items()), flush=True)

@@ -34,6 +34,8 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* d, int64_t len, uint8_t* rgb)
   // coefficient storage
   std::vector<std::vector<int16_t>> coef(o.ncomp);
   for (int c = 0; c < o.ncomp; ++c) coef[c].assign((size_t)jpeg_blocks_w(&o, c) * jpeg_blocks_h(&o, c) * 64, 0);
+  uint8_t nat[80];
+  jpeg_fill_natural_order(nat);
   JpegBits b;
   jpeg_bits_init(&b, d, o.scan_off, len);
   int pred[3] = {0, 0, 0};
@@ -47,7 +49,7 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* d, int64_t len, uint8_t* rgb)
             const int bx = mx * o.hs[c] + h, by = my * o.vs[c] + v;
             int16_t* blk = coef[c].data() + ((size_t)by * jpeg_blocks_w(&o, c) + bx) * 64;
             jpeg_decode_block(&b, luts[2 * c].data(), &sl[2 * c], vv[2 * c], luts[2 * c + 1].data(), &sl[2 * c + 1], vv[2 * c + 1],
-                              &pred[c], blk);
+                              (const uint8_t*)nat, &pred[c], blk);
           }
       if (o.restart_interval) --togo;
     }

@@ -194,6 +194,30 @@ def test_attention(gpu, B, S, H, s_txt):
     _attn_case(gpu, B, S, H, s_txt, seed=11)
 
 
+def test_attention_schedules_are_bit_identical(gpu):
+    """the KV-loop schedules (drag_set_option "attn_sched") and block shapes ("attn_w4") reorder instructions, not arithmetic"""
+    from domain_rag_amd import ops
+    B, S, H = 2, 4300, 2
+    D = H * 128
+    qkv = _randn((B, S, 3 * D), 3).to(gpu)
+    s_pad = (S + 63) // 64 * 64
+    vt = torch.empty((B, H, 128, s_pad), dtype=torch.bfloat16, device=gpu)
+    ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
+    outs = []
+    try:
+        for sched, w4 in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4)
+            o = torch.empty((B, S, D), dtype=torch.bfloat16, device=gpu)
+            ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+            outs.append(o.cpu())
+    finally:
+        ops.set_option("attn_sched", 0); ops.set_option("attn_w4", 0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
+    assert _rel(outs[0], outs[2]) < 1e-2
+    with pytest.raises(RuntimeError):
+        ops.set_option("no_such_switch", 1)
+
+
 def test_attention_spike(gpu):
     _attn_case(gpu, 1, 300, 1, 10, seed=5, spike=True)
 
