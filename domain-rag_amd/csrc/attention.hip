@@ -145,7 +145,7 @@ constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 // SCHED 1: the P V MFMAs of key group s2 are issued as soon as that group's 16 probabilities are packed (from step 4 on, one
 //          per step next to the S MFMA), so the exp stream is spread over 28 MFMAs instead of 16 and only 4 P V MFMAs trail
 //          the loop.  Same arithmetic, same order per accumulator: bit-identical outputs.
-template <int NW, int SCHED>   // NW: waves per block (4 or 8), 32 queries each
+template <int NW, int SCHED, bool QPREP>   // NW: waves per block (4 or 8), 32 queries each; QPREP: RMSNorm + RoPE of q on load
 __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
   const int w = wave_id(), l = lane_id();
@@ -257,59 +257,55 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   stage_k(0, 0);
   stage_v(0, 0);
   if (nkv > 1) stage_k(1, 64);
-  // Q load (+ optional RMSNorm / RoPE) while those tiles are in flight
+  // Q load (+ RMSNorm / RoPE when QPREP) while those tiles are in flight
   {
     const int qr = min(q0 + (l & 31), p.S - 1);
     const bf16_t* qp = p.q + (long long)b * p.qk_bs + (long long)qr * p.ld_qk + h * 128 + hh * 8;
+    if constexpr (!QPREP) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
-    if (p.wq_txt != nullptr || p.cosT != nullptr) {
+      for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
+    } else {
       // per-head RMSNorm(128) + interleaved RoPE of this lane's query row, with the rounding points of the separate pass
       // (qk_norm_rope_vt_kernel): rbf(rbf(x * rs) * w), rotation in fp32, one rounding to bf16.  The lane holds 64 of the
       // row's 128 elements (d = 16 ks + 8 hh + 0..7), lane ^ 32 the other 64; RoPE pairs (2j, 2j+1) never straddle lanes.
-      u32x4_t raw[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) raw[ks] = __builtin_bit_cast(u32x4_t, qf[ks]);
-      float rs = 1.f;
-      const bf16_t* wsel = nullptr;
-      if (p.wq_txt != nullptr) {
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
-            ss += a0 * a0;
-            ss += a1 * a1;
-          }
-        ss += __shfl_xor(ss, 32, 64);
-        rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
-        wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
-      }
+      // All 32 loads are issued before anything is consumed: one memory latency, overlapped with the K / V^T prologue DMA
+      // (a per-ks `if (table != null)` form compiled to eight serialised load-wait-branch rounds: +91 us per B=8 launch).
+      const bf16_t* wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
+      const float* cp = p.cosT + (long long)qr * 64 + hh * 4;
+      const float* sp = p.sinT + (long long)qr * 64 + hh * 4;
+      u32x4_t raw[8], wr[8];
+      f32x4_t c4[8], s4[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        u32x4_t wr = (u32x4_t){0u, 0u, 0u, 0u};
-        if (wsel != nullptr) wr = *(const u32x4_t*)(wsel + ks * 16);
-        f32x4_t c4 = (f32x4_t){1.f, 1.f, 1.f, 1.f}, s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (p.cosT != nullptr) {
-          c4 = *(const f32x4_t*)(p.cosT + (long long)qr * 64 + ks * 8 + hh * 4);
-          s4 = *(const f32x4_t*)(p.sinT + (long long)qr * 64 + ks * 8 + hh * 4);
+        raw[ks] = *(const u32x4_t*)(qp + ks * 16);
+        wr[ks] = *(const u32x4_t*)(wsel + ks * 16);
+        c4[ks] = *(const f32x4_t*)(cp + ks * 8);
+        s4[ks] = *(const f32x4_t*)(sp + ks * 8);
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+          ss += a0 * a0;
+          ss += a1 * a1;
         }
+      ss += __shfl_xor(ss, 32, 64);
+      const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
         u32x4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
-          if (wsel != nullptr) {
-            a0 = rbf(rbf(a0 * rs) * bf2f((bf16_t)(wr[j] & 0xffff)));
-            a1 = rbf(rbf(a1 * rs) * bf2f((bf16_t)(wr[j] >> 16)));
-          }
-          o[j] = pack2bf(a0 * c4[j] - a1 * s4[j], a1 * c4[j] + a0 * s4[j]);
+          const float a0 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] & 0xffff)) * rs) * bf2f((bf16_t)(wr[ks][j] & 0xffff)));
+          const float a1 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] >> 16)) * rs) * bf2f((bf16_t)(wr[ks][j] >> 16)));
+          o[j] = pack2bf(a0 * c4[ks][j] - a1 * s4[ks][j], a1 * c4[ks][j] + a0 * s4[ks][j]);
         }
         qf[ks] = __builtin_bit_cast(bf16x8_t, o);
       }
     }
   }
-
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
@@ -500,8 +496,9 @@ extern "C" int drag_attention_qprep_bf16(const void* q, const void* k, const voi
                                          int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
                                          int64_t o_batch_stride, float scale, const void* wq_txt, const void* wq_img,
                                          const float* rope_cos, const float* rope_sin, int32_t s_txt, float eps, void* stream) {
-  DRAG_CHECK((wq_txt == nullptr) == (wq_img == nullptr), "drag_attention_qprep_bf16: norm weights come in pairs");
-  DRAG_CHECK((rope_cos == nullptr) == (rope_sin == nullptr), "drag_attention_qprep_bf16: cos/sin come in pairs");
+  DRAG_CHECK(wq_txt && wq_img && rope_cos && rope_sin,
+             "drag_attention_qprep_bf16: the fused q preparation needs both norm weights and both RoPE tables "
+             "(drag_attention_bf16 takes an already prepared q)");
   DRAG_CHECK(s_txt >= 0 && s_txt <= S, "drag_attention_qprep_bf16: 0 <= s_txt <= S");
   return attention_launch(q, k, vt, out, B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale, wq_txt, wq_img, rope_cos,
                           rope_sin, s_txt, eps, stream);
@@ -531,10 +528,17 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
   const bool s1 = drag_opt(DRAG_OPT_ATTN_SCHED) == 1;
-  if (w8 && s1) hipLaunchKernelGGL((attention_d128_kernel<8, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else if (w8) hipLaunchKernelGGL((attention_d128_kernel<8, 0>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else if (s1) hipLaunchKernelGGL((attention_d128_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attention_d128_kernel<4, 0>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  const bool qprep = wq_txt != nullptr;
+  const hipStream_t st = (hipStream_t)stream;
+#define DRAG_ATTN_LAUNCH(NW, SC, QP) hipLaunchKernelGGL((attention_d128_kernel<NW, SC, QP>), grid, dim3(NW * 64), 0, st, p)
+  if (w8) {
+    if (s1) { if (qprep) DRAG_ATTN_LAUNCH(8, 1, true); else DRAG_ATTN_LAUNCH(8, 1, false); }
+    else { if (qprep) DRAG_ATTN_LAUNCH(8, 0, true); else DRAG_ATTN_LAUNCH(8, 0, false); }
+  } else {
+    if (s1) { if (qprep) DRAG_ATTN_LAUNCH(4, 1, true); else DRAG_ATTN_LAUNCH(4, 1, false); }
+    else { if (qprep) DRAG_ATTN_LAUNCH(4, 0, true); else DRAG_ATTN_LAUNCH(4, 0, false); }
+  }
+#undef DRAG_ATTN_LAUNCH
   DRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -9,8 +9,9 @@
 //                          offsets, scan offset, status).  The host reads the descriptors back once to size the outputs.
 //   jpeg_huffman_kernel    one image per LANE, one wave per workgroup.  Entropy decoding is inherently serial per image (COCO
 //                          files carry no restart markers), so the parallelism is ACROSS images: 64 bit-streams per wave, every
-//                          lane with its own four 8-bit-lookahead code tables in LDS (128 KiB per wave, lane-interleaved so a
-//                          lookup is bank-conflict free whatever the codes are), coefficients scattered into a zeroed int16
+//                          lane with its own four code tables in LDS (direct table + packed length limits + symbols, 131 KiB per
+//                          wave, lane-interleaved so a lookup is bank-conflict free whatever the codes are; no per-symbol access
+//                          leaves LDS / registers), coefficients scattered into a zeroed int16
 //                          buffer in natural order.  A 4096-image batch is 64 waves on 64 CUs; the other CUs keep running the
 //                          embedding tower of the previous batch on another stream.
 //   jpeg_idct_kernel       one thread per 8x8 block: dequantise + ISLOW IDCT in registers, 8 x 8-byte row stores into the
@@ -22,10 +23,20 @@
 
 namespace {
 
-struct LdsLut {                      // table entry e of this lane: base[e * 64 + lane]
-  DRAG_LDS uint16_t* base;
-  __device__ __forceinline__ DRAG_LDS uint16_t& operator[](int e) const { return base[e * 64]; }
+// Per-lane decoding tables in LDS, element e of lane l at base[e * 64 + l] (the 64 lanes of an access hit 64 consecutive
+// elements: no bank conflicts whatever the codes are).  DC tables: 6-bit direct table, 16 symbols; AC: 8-bit, 256 symbols.
+template <int LB_, int NV_>
+struct LdsTable {
+  enum { LB = LB_, NV = NV_ };
+  DRAG_LDS uint16_t* l;
+  DRAG_LDS uint32_t* k;
+  DRAG_LDS uint8_t* v;
+  __device__ __forceinline__ DRAG_LDS uint16_t& lut(int i) const { return l[i * 64]; }
+  __device__ __forceinline__ DRAG_LDS uint32_t& limk(int i) const { return k[i * 64]; }
+  __device__ __forceinline__ DRAG_LDS uint8_t& val(int i) const { return v[i * 64]; }
 };
+typedef LdsTable<6, 16> DcTable;
+typedef LdsTable<8, 256> AcTable;
 
 struct JpegArgs {
   const uint8_t* data;
@@ -45,9 +56,14 @@ __global__ __launch_bounds__(64) void jpeg_parse_kernel(const uint8_t* data, con
   if (i >= n) return;
   JpegInfo o;
   jpeg_parse(data + off[i], off[i + 1] - off[i], &o);
-  if (o.status == 0) {                               // the Huffman kernel keeps four code tables per lane: DC 0/1, AC 0/1
-    for (int c = 0; c < o.ncomp; ++c)
-      if (o.td[c] > 1 || o.ta[c] > 1) o.status = JPEG_ERR_TABLES;
+  if (o.status == 0) {                               // the Huffman kernel keeps four code tables per lane: DC 0/1, AC 0/1,
+    const uint8_t* d = data + off[i];                // and 16 symbol slots per DC table (8-bit JPEG has at most 12 categories)
+    for (int c = 0; c < o.ncomp; ++c) {
+      if (o.td[c] > 1 || o.ta[c] > 1) { o.status = JPEG_ERR_TABLES; break; }
+      int cnt = 0;
+      for (int l = 0; l < 16; ++l) cnt += d[o.dht_off[o.td[c]] + l];
+      if (cnt > 16) { o.status = JPEG_ERR_TABLES; break; }
+    }
   }
   info[i] = o;
 }
@@ -57,14 +73,19 @@ struct LdsNat {                      // zigzag -> natural order, one copy per wa
   __device__ __forceinline__ DRAG_LDS uint8_t& operator[](int k) const { return t[k]; }
 };
 
-constexpr int JPEG_LUT_LDS = 4 * 256 * 64 * 2;      // 128 KiB of code tables per wave
-constexpr int JPEG_HUFF_LDS = JPEG_LUT_LDS + 128;   // + the natural-order table
+// LDS carve (bytes): u16 direct tables [2 x 64 DC + 2 x 256 AC][64 lanes] | u32 limit/first words [4 x 17][64] |
+//                    u8 symbols [2 x 16 DC + 2 x 256 AC][64] | natural order [80]
+constexpr int JPEG_LUT_ELEMS = 2 * 64 + 2 * 256;
+constexpr int JPEG_LUT_BYTES = JPEG_LUT_ELEMS * 64 * 2;        //  81 920
+constexpr int JPEG_LIMK_BYTES = 4 * 17 * 64 * 4;               //  17 408
+constexpr int JPEG_VAL_BYTES = (2 * 16 + 2 * 256) * 64;        //  34 816
+constexpr int JPEG_HUFF_LDS = JPEG_LUT_BYTES + JPEG_LIMK_BYTES + JPEG_VAL_BYTES + 128;   // 134 272: one wave per CU
 
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];     // [4 tables][256 entries][64 lanes] | natural order [80]
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x;
   const int i = blockIdx.x * 64 + lane;
-  const LdsNat nat{(DRAG_LDS uint8_t*)lds + JPEG_LUT_LDS};
+  const LdsNat nat{(DRAG_LDS uint8_t*)lds + JPEG_LUT_BYTES + JPEG_LIMK_BYTES + JPEG_VAL_BYTES};
   for (int k = lane; k < 80; k += 64) nat[k] = (uint8_t)jpeg_natural_order(k);
   __syncthreads();
   if (i >= a.n) return;
@@ -72,31 +93,32 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
   if (o.status != 0) { a.scan_status[i] = 0; return; }
   const uint8_t* d = a.data + a.off[i];
   const int64_t len = a.off[i + 1] - a.off[i];
-  JpegHuffSlow slow[4];
-  DRAG_LDS uint16_t* const lut0 = (DRAG_LDS uint16_t*)lds + lane;     // table t of this lane: lut0 + t * 256 * 64
+  DRAG_LDS uint16_t* const L = (DRAG_LDS uint16_t*)lds + lane;
+  DRAG_LDS uint32_t* const K = (DRAG_LDS uint32_t*)(lds + JPEG_LUT_BYTES) + lane;
+  DRAG_LDS uint8_t* const V = (DRAG_LDS uint8_t*)(lds + JPEG_LUT_BYTES + JPEG_LIMK_BYTES) + lane;
+  // table id 0 / 1 of each class
+  const DcTable dct[2] = {{L, K, V}, {L + 64 * 64, K + 17 * 64, V + 16 * 64}};
+  const AcTable act[2] = {{L + 128 * 64, K + 34 * 64, V + 32 * 64}, {L + (128 + 256) * 64, K + 51 * 64, V + (32 + 256) * 64}};
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {                      // t = class * 2 + id
-    const int ofs = o.dht_off[(t >> 1) * 4 + (t & 1)];
-    if (ofs >= 0) jpeg_build_huff(d + ofs, LdsLut{lut0 + t * 256 * 64}, &slow[t]);
+  for (int id = 0; id < 2; ++id) {
+    if (o.dht_off[id] >= 0) jpeg_build_huff(d + o.dht_off[id], dct[id]);
+    if (o.dht_off[4 + id] >= 0) jpeg_build_huff(d + o.dht_off[4 + id], act[id]);
   }
   // per-component constants with STATIC indices (a dynamically indexed local array lives in scratch = global memory, and a
   // scratch access per block costs this one-wave-per-CU kernel a full memory round trip)
   const int ncomp = o.ncomp, mcus_x = o.mcus_x, mcus_y = o.mcus_y, rst = o.restart_interval;
   int hs[3], vs[3], bw[3], td[3], ta[3];
   int16_t* cbase[3];
-  const uint8_t *dcv[3], *acv[3];
   {
     long long p = a.plan[(long long)i * 3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const bool on = c < ncomp;
       hs[c] = on ? o.hs[c] : 0; vs[c] = on ? o.vs[c] : 0;
-      td[c] = on ? o.td[c] : 0; ta[c] = on ? 2 + o.ta[c] : 2;
+      td[c] = on ? (o.td[c] & 1) : 0; ta[c] = on ? (o.ta[c] & 1) : 0;
       bw[c] = mcus_x * hs[c];
       cbase[c] = a.coef + p;
       p += (long long)bw[c] * (mcus_y * vs[c]) * 64;
-      dcv[c] = d + o.dht_off[td[c] & 1] + 16;
-      acv[c] = d + o.dht_off[4 + (ta[c] & 1)] + 16;
       if (on) {                                      // quantisation table, natural order, for the IDCT kernel
         const uint8_t* qt = d + o.dqt_off[o.tq[c]];
         const bool q16 = o.dqt_16[o.tq[c]] != 0;
@@ -118,11 +140,13 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const LdsLut dcl{lut0 + td[c] * 256 * 64}, acl{lut0 + ta[c] * 256 * 64};
+        // the view of table id 1 is the view of id 0 plus constant offsets: select by arithmetic, not by indexing an array
+        const DcTable dc{L + td[c] * (64 * 64), K + td[c] * (17 * 64), V + td[c] * (16 * 64)};
+        const AcTable ac{L + (128 + ta[c] * 256) * 64, K + (34 + ta[c] * 17) * 64, V + (32 + ta[c] * 256) * 64};
         for (int v = 0; v < vs[c]; ++v)
           for (int h = 0; h < hs[c]; ++h) {
             int16_t* blk = cbase[c] + ((long long)(my * vs[c] + v) * bw[c] + mx * hs[c] + h) * 64;
-            jpeg_decode_block(&b, dcl, &slow[td[c]], dcv[c], acl, &slow[ta[c]], acv[c], nat, &pred[c], blk);
+            jpeg_decode_block(&b, dc, ac, nat, &pred[c], blk);
           }
       }
       if (rst) --togo;

@@ -179,35 +179,38 @@ JHD int64_t jpeg_total_blocks(const JpegInfo* o) {
 }
 
 // ---------------------------------------------------------------------------------------------- Huffman tables
-// 8-bit lookahead table: entry = (code length << 8) | symbol for codes of <= 8 bits, 0 otherwise; plus libjpeg's
-// maxcode / valoffset arrays for the bit-by-bit path of longer codes.
-struct JpegHuffSlow {
-  int32_t maxcode[18];     // maxcode[l] = largest code of length l (-1 if none); maxcode[17] = sentinel
-  int32_t valoff[17];      // huffval index = code + valoff[l]
-};
-
-template <typename LUT>     // LUT: anything indexable as lut[i] = uint16_t (an LDS pointer on the GPU)
-JHD void jpeg_build_huff(const uint8_t* counts /* 16 counts, then the symbols */, LUT lut, JpegHuffSlow* slow) {
-  for (int i = 0; i < 256; ++i) lut[i] = 0;
+// A decoding table is seen through a VIEW type T (plain arrays on the host, lane-interleaved LDS on the GPU):
+//   T::LB          lookahead bits of the direct table
+//   t.lut(i)       uint16 [1 << LB]: (code length << 8) | symbol for codes of <= LB bits, 0 otherwise
+//   t.limk(l)      uint32, l = 1..16: low half = exclusive upper bound, left-aligned to 16 bits, of the codes of length <= l
+//                  (canonical codes grow with their length, so these bounds are monotonic and a 16-bit window w belongs to
+//                  the smallest l with w < bound); high half = index of the first symbol of length l
+//   t.val(i)       uint8 [T::NV]: the symbols in code order (symbols past NV are dropped: the caller rejects such tables)
+// Every per-symbol access therefore stays in fast memory; nothing walks maxcode[] bit by bit (libjpeg's slow path does, from
+// cached memory — on a GPU lane that walk is a chain of dependent memory round trips).
+template <typename T>
+JHD void jpeg_build_huff(const uint8_t* counts /* 16 counts, then the symbols */, T t) {
+  for (int i = 0; i < (1 << T::LB); ++i) t.lut(i) = 0;
   const uint8_t* vals = counts + 16;
   int code = 0, k = 0;
+  unsigned bound = 0;
   for (int l = 1; l <= 16; ++l) {
     const int n = counts[l - 1];
-    slow->valoff[l] = k - code;
-    if (n) {
-      for (int i = 0; i < n; ++i, ++k, ++code) {
-        if (l <= 8) {
-          const int base = code << (8 - l);
-          for (int f = 0; f < (1 << (8 - l)); ++f) lut[(base + f) & 255] = (uint16_t)((l << 8) | vals[k]);
-        }
+    const int kfirst = k;
+    for (int i = 0; i < n; ++i, ++k, ++code) {
+      if (k < T::NV) t.val(k) = vals[k];
+      if (l <= T::LB) {
+        const int base = code << (T::LB - l);
+        for (int f = 0; f < (1 << (T::LB - l)); ++f) t.lut((base + f) & ((1 << T::LB) - 1)) = (uint16_t)((l << 8) | vals[k]);
       }
-      slow->maxcode[l] = code - 1;
-    } else {
-      slow->maxcode[l] = -1;
     }
+    if (n) {
+      const unsigned b = (unsigned)code << (16 - l);        // first window value NOT belonging to a code of length <= l
+      bound = b > 0xFFFFu ? 0xFFFFu : b;
+    }
+    t.limk(l) = (uint32_t)bound | ((uint32_t)(kfirst & 0xFFFF) << 16);
     code <<= 1;
   }
-  slow->maxcode[17] = 0xFFFFF;
 }
 
 // ---------------------------------------------------------------------------------------------- bit reader
@@ -222,29 +225,54 @@ struct JpegBits {
 JHD void jpeg_bits_init(JpegBits* b, const uint8_t* d, int64_t pos, int64_t end) {
   b->d = d; b->pos = pos; b->end = end; b->buf = 0; b->cnt = 0; b->marker = 0;
 }
-// Guarantees > 32 valid bits (one code of <= 16 bits plus <= 16 extra bits) whenever the stream has them.  Fast path: four
-// bytes at once when none of them is 0xFF (no stuffing, no marker) — entropy-coded data is 0xFF-free almost everywhere, so
-// the byte-wise loop below (stuffed zeros, markers, the last bytes of the file) runs rarely.
+
+// the 8 stream bytes at `pos`, first byte in bits 0-7 (the caller guarantees pos + 8 <= end + padding)
+JHD uint64_t jpeg_load8(const uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // hipcc splits an align-1 load into byte loads: fetch the three aligned dwords around the position (one request; the blob is
+  // padded, so they always exist) and funnel-shift them (v_alignbyte_b32)
+  const uintptr_t a = (uintptr_t)p;
+  const uint32_t* p4 = (const uint32_t*)(a & ~(uintptr_t)3);
+  const uint32_t w0 = p4[0], w1 = p4[1], w2 = p4[2];
+  const unsigned sh = (unsigned)(a & 3);
+  return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+#else
+  uint64_t w;
+  __builtin_memcpy(&w, p, 8);
+  return w;
+#endif
+}
+
+// Guarantees > 32 valid bits (one code of <= 16 bits plus <= 16 extra bits) whenever the stream has them.  One 8-byte window
+// is fetched per call and consumed IN REGISTERS: four bytes at once when none of them is 0xFF (entropy-coded data is 0xFF-free
+// almost everywhere), byte by byte otherwise (stuffed zeros, markers).  With 64 streams per wave some lane meets a 0xFF in most
+// rounds, so that path must not touch memory either.  The last 8 bytes of the file take the byte-wise memory path.
 JHD void jpeg_bits_fill(JpegBits* b) {
   if (b->cnt > 32) return;
-  if (!b->marker && b->pos + 4 <= b->end) {
-    uint32_t le;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // hipcc splits an align-1 load into four byte loads: fetch the two aligned dwords around the position (one 8-byte
-    // request; the blob is padded, so the second dword always exists) and funnel-shift them (v_alignbyte_b32)
-    const uintptr_t a = (uintptr_t)(b->d + b->pos);
-    const uint32_t* p4 = (const uint32_t*)(a & ~(uintptr_t)3);
-    le = __builtin_amdgcn_alignbyte(p4[1], p4[0], (unsigned)(a & 3));
-#else
-    __builtin_memcpy(&le, b->d + b->pos, 4);
-#endif
-    const uint32_t w = __builtin_bswap32(le);          // the stream is big-endian
-    if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) {          // no byte of w is 0xFF
-      b->buf |= (uint64_t)w << (32 - b->cnt);
+  if (!b->marker && b->pos + 8 <= b->end) {
+    const uint64_t w = jpeg_load8(b->d + b->pos);
+    const uint32_t lo = (uint32_t)w;
+    if ((((~lo) - 0x01010101u) & lo & 0x80808080u) == 0) {          // none of the first four bytes is 0xFF
+      b->buf |= (uint64_t)__builtin_bswap32(lo) << (32 - b->cnt);  // the stream is big-endian
       b->cnt += 32;
       b->pos += 4;
       return;
     }
+    int used = 0;
+    while (b->cnt <= 56 && used < 7) {            // byte `used + 1` of the window is always available to look at
+      unsigned byte = (unsigned)(w >> (8 * used)) & 0xFF;
+      if (byte == 0xFF) {
+        const unsigned nx = (unsigned)(w >> (8 * used + 8)) & 0xFF;
+        if (nx == 0) used += 2;                   // stuffed zero
+        else { b->marker = (int)nx; break; }      // leave pos at the 0xFF
+      } else {
+        used += 1;
+      }
+      b->buf |= (uint64_t)byte << (56 - b->cnt);
+      b->cnt += 8;
+    }
+    b->pos += used;
+    if (b->cnt > 32 || !b->marker) return;        // (at least 4 bytes were consumed unless a marker stopped the loop)
   }
   while (b->cnt <= 56) {
     unsigned byte = 0;
@@ -271,17 +299,31 @@ JHD int jpeg_receive_extend(JpegBits* b, int s) {       // s in 1..16
   jpeg_bits_skip(b, s);
   return r < (1 << (s - 1)) ? r - (1 << s) + 1 : r;
 }
-template <typename LUT>
-JHD int jpeg_decode_symbol(JpegBits* b, LUT lut, const JpegHuffSlow* slow, const uint8_t* vals) {
-  const unsigned e = lut[jpeg_bits_peek(b, 8)];
+
+// one symbol.  The long-code data (16 packed words) is fetched unconditionally next to the direct-table entry: the loads
+// are independent of each other, so a symbol costs one fast-memory latency (two for a code longer than LB bits).
+template <typename T>
+JHD int jpeg_decode_symbol(JpegBits* b, T t) {
+  const unsigned w16 = (unsigned)jpeg_bits_peek(b, 16);
+  const unsigned e = t.lut((int)(w16 >> (16 - T::LB)));
+  uint32_t lk[17];
+#pragma unroll
+  for (int l = T::LB + 1; l <= 16; ++l) lk[l] = t.limk(l);
+  const uint32_t lk_lb = t.limk(T::LB);
   if (e) { jpeg_bits_skip(b, (int)(e >> 8)); return (int)(e & 255); }
-  int l = 9;
-  int code = jpeg_bits_peek(b, 9);
-  while (l <= 16 && code > slow->maxcode[l]) { ++l; code = jpeg_bits_peek(b, l > 16 ? 16 : l); }
-  if (l > 16) { jpeg_bits_skip(b, 16); return 0; }     // corrupt data: libjpeg warns and returns 0
-  jpeg_bits_skip(b, l);
-  return vals[(code + slow->valoff[l]) & 255];
+  int len = 17;
+  uint32_t prev_bound = lk_lb & 0xFFFFu, kfirst = 0, first = 0;
+#pragma unroll
+  for (int l = 16; l > T::LB; --l) {              // smallest l with w16 < bound(l): scan downwards, keep the last hit
+    const uint32_t bound = lk[l] & 0xFFFFu;
+    const uint32_t below = l - 1 > T::LB ? (lk[l - 1] & 0xFFFFu) : prev_bound;
+    if (w16 < bound) { len = l; kfirst = lk[l] >> 16; first = below; }
+  }
+  if (len > 16) { jpeg_bits_skip(b, 16); return 0; }     // not a code of this table (corrupt data): libjpeg warns and returns 0
+  jpeg_bits_skip(b, len);
+  return t.val((int)((kfirst + ((w16 - first) >> (16 - len))) & (T::NV - 1)));
 }
+
 // after an MCU count hits the restart interval (jdhuff.c process_restart): the bits left in the current byte are padding;
 // the reader has necessarily run into the RSTn marker while filling (at most 7 data bits precede it), so step over it.  A
 // stream that has something else there is corrupt: resynchronise on the next RSTn like libjpeg's default resync does.
@@ -297,7 +339,6 @@ JHD void jpeg_bits_restart(JpegBits* b) {
   b->pos = p; b->buf = 0; b->cnt = 0; b->marker = 0;
 }
 
-// one 8x8 block: DC difference + AC run/size pairs -> coefficients in NATURAL order (the block must be zero on entry)
 // `nat`: the zigzag -> natural-order table (64 + 16 entries, jpeg_fill_natural_order) in whatever memory is cheap to index
 // per lane — LDS on the GPU (a per-symbol lookup in global memory stalls the in-order wave for a full memory round trip).
 template <typename NAT>
@@ -305,16 +346,16 @@ JHD void jpeg_fill_natural_order(NAT nat) {
   for (int k = 0; k < 80; ++k) nat[k] = (uint8_t)jpeg_natural_order(k);
 }
 
-template <typename LUT, typename NAT>
-JHD void jpeg_decode_block(JpegBits* b, LUT dc_lut, const JpegHuffSlow* dc_slow, const uint8_t* dc_vals, LUT ac_lut,
-                           const JpegHuffSlow* ac_slow, const uint8_t* ac_vals, NAT nat, int* dc_pred, int16_t* coef) {
+// one 8x8 block: DC difference + AC run/size pairs -> coefficients in NATURAL order (the block must be zero on entry)
+template <typename TDC, typename TAC, typename NAT>
+JHD void jpeg_decode_block(JpegBits* b, TDC dc, TAC ac, NAT nat, int* dc_pred, int16_t* coef) {
   jpeg_bits_fill(b);
-  int s = jpeg_decode_symbol(b, dc_lut, dc_slow, dc_vals) & 15;
-  if (s) *dc_pred += jpeg_receive_extend(b, s);     // a fill leaves >= 57 bits: enough for a 16-bit code + 16 extra bits
+  int s = jpeg_decode_symbol(b, dc) & 15;
+  if (s) *dc_pred += jpeg_receive_extend(b, s);     // a fill leaves >= 33 bits: enough for a 16-bit code + 16 extra bits
   coef[0] = (int16_t)*dc_pred;
   for (int k = 1; k < 64; ++k) {
     jpeg_bits_fill(b);
-    const int rs = jpeg_decode_symbol(b, ac_lut, ac_slow, ac_vals);
+    const int rs = jpeg_decode_symbol(b, ac);
     const int r = rs >> 4;
     s = rs & 15;
     if (s) {

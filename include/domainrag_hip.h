@@ -116,8 +116,8 @@ int drag_attention_bf16(const void* q, const void* k, const void* vt, void* out,
 
 /* The q third of drag_qk_norm_rope_vt_bf16 fused into the attention kernel (one read + one write of [M, D] less per
  * attention): drag_k_norm_rope_vt_bf16 normalises / rotates k and writes V^T only, and drag_attention_qprep_bf16 takes
- * the RAW q projection and applies norm_q / norm_added_q (rows < s_txt: wq_txt, else wq_img; both NULL = none) and
- * apply_rotary_emb (rope_cos / rope_sin f32 [S, 64]; both NULL = none) to each query row while it loads its fragments,
+ * the RAW q projection and applies norm_q / norm_added_q (rows < s_txt: wq_txt, else wq_img) and apply_rotary_emb
+ * (rope_cos / rope_sin f32 [S, 64]) — all four required — to each query row while it loads its fragments,
  * with the rounding points of the separate pass.  FluxAttnProcessor2_0 as reached from batch_generate_flux_kshot.py:467-474,
  * outpainting_updown_sampling_redux.py:1246-1257. */
 int drag_k_norm_rope_vt_bf16(void* qkv, void* vt, const void* wk_txt, const void* wk_img, const float* rope_cos,

@@ -17,20 +17,26 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* d, int64_t len, uint8_t* rgb)
   JpegInfo o;
   jpeg_parse(d, len, &o);
   if (o.status) return o.status;
-  std::vector<uint16_t> lut(4 * 256);
-  JpegHuffSlow slow[4];
-  const uint8_t* vals[4] = {nullptr, nullptr, nullptr, nullptr};
-  // table slots: 0 DC of luma, 1 AC of luma, 2 DC of chroma, 3 AC of chroma (component 1 and 2 may differ: build per component)
-  std::vector<std::vector<uint16_t>> luts(6, std::vector<uint16_t>(256));
-  JpegHuffSlow sl[6];
-  const uint8_t* vv[6];
+  // one table view per (component, class): plain arrays on the host
+  struct HostTable {
+    enum { LB = 8, NV = 256 };
+    uint16_t* l; uint32_t* k; uint8_t* v;
+    uint16_t& lut(int i) const { return l[i]; }
+    uint32_t& limk(int i) const { return k[i]; }
+    uint8_t& val(int i) const { return v[i]; }
+  };
+  struct HostTableDC : HostTable { enum { LB = 6, NV = 16 }; };      // the GPU kernel uses a 6-bit direct table for DC codes: same here
+  std::vector<uint16_t> luts(6 * 256);
+  std::vector<uint32_t> limk(6 * 17);
+  std::vector<uint8_t> vals(6 * 256);
+  HostTableDC tdc[3];
+  HostTable tac[3];
   for (int c = 0; c < o.ncomp; ++c) {
-    const uint8_t* dc = d + o.dht_off[o.td[c]];
-    const uint8_t* ac = d + o.dht_off[4 + o.ta[c]];
-    jpeg_build_huff(dc, luts[2 * c].data(), &sl[2 * c]); vv[2 * c] = dc + 16;
-    jpeg_build_huff(ac, luts[2 * c + 1].data(), &sl[2 * c + 1]); vv[2 * c + 1] = ac + 16;
+    tdc[c].l = luts.data() + (2 * c) * 256; tdc[c].k = limk.data() + (2 * c) * 17; tdc[c].v = vals.data() + (2 * c) * 256;
+    tac[c].l = luts.data() + (2 * c + 1) * 256; tac[c].k = limk.data() + (2 * c + 1) * 17; tac[c].v = vals.data() + (2 * c + 1) * 256;
+    jpeg_build_huff(d + o.dht_off[o.td[c]], tdc[c]);
+    jpeg_build_huff(d + o.dht_off[4 + o.ta[c]], tac[c]);
   }
-  (void)lut; (void)slow; (void)vals;
   // coefficient storage
   std::vector<std::vector<int16_t>> coef(o.ncomp);
   for (int c = 0; c < o.ncomp; ++c) coef[c].assign((size_t)jpeg_blocks_w(&o, c) * jpeg_blocks_h(&o, c) * 64, 0);
@@ -48,8 +54,7 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* d, int64_t len, uint8_t* rgb)
           for (int h = 0; h < o.hs[c]; ++h) {
             const int bx = mx * o.hs[c] + h, by = my * o.vs[c] + v;
             int16_t* blk = coef[c].data() + ((size_t)by * jpeg_blocks_w(&o, c) + bx) * 64;
-            jpeg_decode_block(&b, luts[2 * c].data(), &sl[2 * c], vv[2 * c], luts[2 * c + 1].data(), &sl[2 * c + 1], vv[2 * c + 1],
-                              (const uint8_t*)nat, &pred[c], blk);
+            jpeg_decode_block(&b, tdc[c], tac[c], (const uint8_t*)nat, &pred[c], blk);
           }
       if (o.restart_interval) --togo;
     }

@@ -211,7 +211,7 @@ def test_attention_schedules_are_bit_identical(gpu):
             ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
             outs.append(o.cpu())
     finally:
-        ops.set_option("attn_sched", 0); ops.set_option("attn_w4", 0)
+        ops.set_option("attn_sched", 1); ops.set_option("attn_w4", 0)          # the library's defaults
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
     assert _rel(outs[0], outs[2]) < 1e-2
     with pytest.raises(RuntimeError):
