@@ -135,6 +135,7 @@ struct AttnArgs {
   const float *cosT, *sinT;        // RoPE tables [S, 64]
   int s_txt;
   float eps;
+  int tune;       // measurement bits: 1 = static priority for the younger wave half, 2 = 16-byte epilogue stores
 };
 
 constexpr float DEFER_THR = 8.0f;     // log2 units; 0 = rescale on every increase (classic online softmax)
@@ -145,7 +146,9 @@ constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 // SCHED 1: the P V MFMAs of key group s2 are issued as soon as that group's 16 probabilities are packed (from step 4 on, one
 //          per step next to the S MFMA), so the exp stream is spread over 28 MFMAs instead of 16 and only 4 P V MFMAs trail
 //          the loop.  Same arithmetic, same order per accumulator: bit-identical outputs.
-template <int NW, int SCHED, bool QPREP>   // NW: waves per block (4 or 8), 32 queries each; QPREP: RMSNorm + RoPE of q on load
+// PMAX: the row maxima of S(j+1) are taken at the END of iteration j (next to the trailing P V MFMAs, which need no VALU)
+//       instead of at the start of iteration j+1, where the matrix pipe has nothing to do.  Same values, same order.
+template <int NW, int SCHED, bool QPREP, bool PMAX>   // NW: waves per block (4 or 8), 32 queries each; QPREP: RMSNorm + RoPE of q on load
 __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
   const int w = wave_id(), l = lane_id();
@@ -316,6 +319,29 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
       scur[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : scur[t], 0, 0, 0);
     }
   // one KV tile; PAR = it & 1 is a compile-time constant; reads S from sc, writes S(it+1) to sn
+  // keys >= S of a ragged last tile do not exist: -inf before the row maximum is taken
+  auto mask_and_max = [&](f32x16_t (&sx)[2], const int kvs) -> float {
+    if (kvs + 64 > p.S) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kvs + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= p.S) sx[t][r] = -INFINITY;
+        }
+    }
+    float m = sx[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sx[t][r]);
+    return fmaxf(m, __shfl_xor(m, 32, 64));
+  };
+  float mt_carry = 0.f;
+  if (PMAX) mt_carry = mask_and_max(scur, 0);
+  if (p.tune & 1) {       // T5 static form: the second-dispatched wave half loses VALU arbitration to the older half on every segment
+    if (w >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  }
   auto body = [&](const int it, auto par, f32x16_t (&sc)[2], f32x16_t (&sn)[2]) {
     constexpr int PAR = decltype(par)::value;
     constexpr int KN = ((PAR + 1) & 1) * KT_BYTES;                 // K(it+1)
@@ -326,22 +352,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     __syncthreads();
     // (the LDS-DMA for K(it+2) / V(it+1) is issued piecewise between the MFMAs of the interleaved loop below:
     //  a burst of 2*CPW buffer_load..lds per wave right after the barrier idles the matrix pipe of every SIMD)
-    if (kv0 + 64 > p.S) {     // ragged last tile: keys >= S do not exist
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= p.S) sc[t][r] = -INFINITY;
-        }
-    }
     // ---- online softmax (exp2 domain), deferred rescale ----
-    float mt = sc[0][0];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[t][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mt = PMAX ? mt_carry : mask_and_max(sc, kv0);
     // Only move the running max (and rescale O, l) when some row's max grew by more than 2^8 in the
     // exp2 domain; otherwise P = exp2(s - m_old) is bounded by 2^8, which fp32 accumulation and the
     // bf16 P operand (relative precision is scale-free) absorb.  The previous tile's P·V is complete
@@ -410,6 +422,8 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
         const bf16x8_t vf = *(const bf16x8_t*)(smem + (av[s2] + (VB + dt * (32 * 128))));
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
       }
+    // S(it+1) is complete: its row maxima now, beside the trailing P V MFMAs (in the last iteration sn is stale and unused)
+    if (PMAX) mt_carry = mask_and_max(sn, kv0 + 64);
   };
   for (int it = 0; it < nkv; it += 2) {
     body(it, std::integral_constant<int, 0>{}, scur, snext);
@@ -421,7 +435,26 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   const float lt = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / lt;
   const int qrow = q0 + (l & 31);
-  if (qrow < p.S) {
+  if (p.tune & 2) {
+    // T21: lanes l and l + 32 hold the two 8-byte halves of each 16-byte output chunk.  One v_permlane32_swap per dword
+    // regroups a pair of chunks (g, g + 1) so that the lower half-wave stores chunk g and the upper one chunk g + 1 as
+    // whole 16-byte pieces: 8 store instructions per lane instead of 16 (the tail is store-ISSUE bound).
+    bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 8 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        uint32_t a0 = pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv);
+        uint32_t a1 = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+        uint32_t b0 = pack2bf(oacc[dt][4 * g + 4] * inv, oacc[dt][4 * g + 5] * inv);
+        uint32_t b1 = pack2bf(oacc[dt][4 * g + 6] * inv, oacc[dt][4 * g + 7] * inv);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        // lower lanes: (r[0], r[1]) = (own chunk-g half, upper lane's chunk-g half); upper lanes: (lower's chunk g+1 half, own)
+        const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
+        if (qrow < p.S) *(u32x4_t*)(op + 32 * dt + 8 * g) = o;
+      }
+  } else if (qrow < p.S) {
     bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 4 * hh;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -527,17 +560,20 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   const int QB = w8 ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
-  const bool s1 = drag_opt(DRAG_OPT_ATTN_SCHED) == 1;
+  const int sched = drag_opt(DRAG_OPT_ATTN_SCHED);          // 0, 1, or 2 = schedule 1 + pipelined row maxima
   const bool qprep = wq_txt != nullptr;
+  p.tune = drag_opt(DRAG_OPT_ATTN_TUNE);
+  DRAG_CHECK(!(p.tune & 2) || ld_o % 8 == 0, "drag_attention_bf16: 16-byte epilogue stores need ld_o % 8 == 0");
   const hipStream_t st = (hipStream_t)stream;
-#define DRAG_ATTN_LAUNCH(NW, SC, QP) hipLaunchKernelGGL((attention_d128_kernel<NW, SC, QP>), grid, dim3(NW * 64), 0, st, p)
-  if (w8) {
-    if (s1) { if (qprep) DRAG_ATTN_LAUNCH(8, 1, true); else DRAG_ATTN_LAUNCH(8, 1, false); }
-    else { if (qprep) DRAG_ATTN_LAUNCH(8, 0, true); else DRAG_ATTN_LAUNCH(8, 0, false); }
-  } else {
-    if (s1) { if (qprep) DRAG_ATTN_LAUNCH(4, 1, true); else DRAG_ATTN_LAUNCH(4, 1, false); }
-    else { if (qprep) DRAG_ATTN_LAUNCH(4, 0, true); else DRAG_ATTN_LAUNCH(4, 0, false); }
-  }
+#define DRAG_ATTN_LAUNCH(NW, SC, QP, PM) hipLaunchKernelGGL((attention_d128_kernel<NW, SC, QP, PM>), grid, dim3(NW * 64), 0, st, p)
+#define DRAG_ATTN_PICK(NW)                                                                           \
+  do {                                                                                               \
+    if (sched == 2) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, true); else DRAG_ATTN_LAUNCH(NW, 1, false, true); }        \
+    else if (sched == 1) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, false); else DRAG_ATTN_LAUNCH(NW, 1, false, false); } \
+    else { if (qprep) DRAG_ATTN_LAUNCH(NW, 0, true, false); else DRAG_ATTN_LAUNCH(NW, 0, false, false); }                 \
+  } while (0)
+  if (w8) DRAG_ATTN_PICK(8); else DRAG_ATTN_PICK(4);
+#undef DRAG_ATTN_PICK
 #undef DRAG_ATTN_LAUNCH
   DRAG_LAUNCH_CHECK();
   return 0;

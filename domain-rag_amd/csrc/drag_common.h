@@ -87,7 +87,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // tuning switches (capi.hip): read once from the environment, changeable through drag_set_option
-enum { DRAG_OPT_ATTN_SCHED = 0, DRAG_OPT_ATTN_W4 = 1, DRAG_OPT_COUNT = 2 };
+enum { DRAG_OPT_ATTN_SCHED = 0, DRAG_OPT_ATTN_W4 = 1, DRAG_OPT_ATTN_TUNE = 2, DRAG_OPT_COUNT = 3 };
 #define DRAG_ATTN_SCHED_DEFAULT 1      // +3 % over schedule 0 at every measured shape (scripts/bench_attn.py), same bits
 int drag_opt(int idx);
 

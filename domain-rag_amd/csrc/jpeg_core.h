@@ -220,37 +220,59 @@ struct JpegBits {
   uint64_t buf;       // MSB-aligned
   int cnt;
   int marker;         // a marker was met: the reader feeds zero bits from there on (libjpeg's behaviour at end of data)
+  // read-ahead window: three aligned 8-byte words of the stream held in registers.  `cur` covers [wpos, wpos + 8), `nxt` the
+  // next 8 bytes, `pre` the 8 after those — `pre` was requested one window shift (>= 8 consumed bytes, i.e. ~10 symbols)
+  // before anything looks at it, so its memory latency is off the per-symbol critical path.  With 64 independent streams per
+  // wave some lane misses the cache on almost every request: a load-then-use reader pays a full miss latency per refill.
+  int64_t wpos;
+  uint64_t cur, nxt, pre;
 };
+
+JHD uint64_t jpeg_load8_aligned(const uint8_t* p) {      // p is 8-byte aligned; first stream byte in bits 0-7
+  uint64_t w;
+  __builtin_memcpy(&w, __builtin_assume_aligned(p, 8), 8);
+  return w;
+}
+
+// Every file of a batch must be followed by >= JPEG_TAIL_PAD readable bytes (the next files, or the blob's padding), and the
+// blob must start on an 8-byte boundary: the window reads aligned words around the position without looking at `end`.
+#define JPEG_TAIL_PAD 32
 
 JHD void jpeg_bits_init(JpegBits* b, const uint8_t* d, int64_t pos, int64_t end) {
   b->d = d; b->pos = pos; b->end = end; b->buf = 0; b->cnt = 0; b->marker = 0;
+  const int64_t a = (int64_t)((uintptr_t)(d + pos) & 7);
+  b->wpos = pos - a;
+  b->cur = jpeg_load8_aligned(d + b->wpos);
+  b->nxt = jpeg_load8_aligned(d + b->wpos + 8);
+  b->pre = jpeg_load8_aligned(d + b->wpos + 16);
 }
 
-// the 8 stream bytes at `pos`, first byte in bits 0-7 (the caller guarantees pos + 8 <= end + padding)
-JHD uint64_t jpeg_load8(const uint8_t* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // hipcc splits an align-1 load into byte loads: fetch the three aligned dwords around the position (one request; the blob is
-  // padded, so they always exist) and funnel-shift them (v_alignbyte_b32)
-  const uintptr_t a = (uintptr_t)p;
-  const uint32_t* p4 = (const uint32_t*)(a & ~(uintptr_t)3);
-  const uint32_t w0 = p4[0], w1 = p4[1], w2 = p4[2];
-  const unsigned sh = (unsigned)(a & 3);
-  return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
-#else
-  uint64_t w;
-  __builtin_memcpy(&w, p, 8);
-  return w;
-#endif
+// the 8 stream bytes at `pos` out of the register window, first byte in bits 0-7; shifts the window when pos has left `cur`
+JHD uint64_t jpeg_window8(JpegBits* b) {
+  while (b->pos - b->wpos >= 8) {                 // at most twice (a restart may jump further: re-seed instead)
+    if (b->pos - b->wpos >= 24) {
+      const int64_t a = (int64_t)((uintptr_t)(b->d + b->pos) & 7);
+      b->wpos = b->pos - a;
+      b->cur = jpeg_load8_aligned(b->d + b->wpos);
+      b->nxt = jpeg_load8_aligned(b->d + b->wpos + 8);
+      b->pre = jpeg_load8_aligned(b->d + b->wpos + 16);
+      break;
+    }
+    b->cur = b->nxt; b->nxt = b->pre; b->wpos += 8;
+    b->pre = jpeg_load8_aligned(b->d + b->wpos + 16);
+  }
+  const unsigned o = (unsigned)(b->pos - b->wpos) * 8;
+  return o ? (b->cur >> o) | (b->nxt << (64 - o)) : b->cur;
 }
 
-// Guarantees > 32 valid bits (one code of <= 16 bits plus <= 16 extra bits) whenever the stream has them.  One 8-byte window
-// is fetched per call and consumed IN REGISTERS: four bytes at once when none of them is 0xFF (entropy-coded data is 0xFF-free
-// almost everywhere), byte by byte otherwise (stuffed zeros, markers).  With 64 streams per wave some lane meets a 0xFF in most
-// rounds, so that path must not touch memory either.  The last 8 bytes of the file take the byte-wise memory path.
+// Guarantees > 32 valid bits (one code of <= 16 bits plus <= 16 extra bits) whenever the stream has them.  The bytes come out
+// of the register window: four at once when none of them is 0xFF (entropy-coded data is 0xFF-free almost everywhere), byte by
+// byte otherwise (stuffed zeros, markers) — no memory access on either path.  The last 8 bytes of the file go through the
+// byte-wise memory loop below.
 JHD void jpeg_bits_fill(JpegBits* b) {
   if (b->cnt > 32) return;
   if (!b->marker && b->pos + 8 <= b->end) {
-    const uint64_t w = jpeg_load8(b->d + b->pos);
+    const uint64_t w = jpeg_window8(b);
     const uint32_t lo = (uint32_t)w;
     if ((((~lo) - 0x01010101u) & lo & 0x80808080u) == 0) {          // none of the first four bytes is 0xFF
       b->buf |= (uint64_t)__builtin_bswap32(lo) << (32 - b->cnt);  // the stream is big-endian

@@ -71,14 +71,14 @@ def _upload(blobs, device):
     total = int(offsets[-1])
     key = str(device)
     buf = _staging.get(key)
-    if buf is None or buf.numel() < total + 16:
-        buf = torch.empty(max(total + 16, 2 * (buf.numel() if buf is not None else 0)), dtype=torch.uint8).pin_memory()
+    if buf is None or buf.numel() < total + 64:
+        buf = torch.empty(max(total + 64, 2 * (buf.numel() if buf is not None else 0)), dtype=torch.uint8).pin_memory()
         _staging[key] = buf
     host = buf.numpy()
     for b, o in zip(blobs, offsets[:-1]):
         host[o: o + len(b)] = np.frombuffer(b, dtype=np.uint8)
-    host[total: total + 16] = 0                       # the bit reader may look one byte past a truncated file
-    data = buf[: total + 16].to(device, non_blocking=True)
+    host[total: total + 64] = 0                       # the bit reader's read-ahead window looks up to 32 bytes past a file
+    data = buf[: total + 64].to(device, non_blocking=True)
     return data, offsets
 
 

@@ -25,8 +25,9 @@ extern "C" {
 int drag_version(void);
 const char* drag_last_error(void);
 /* Measurement switches (A/B of kernel variants inside one process; every setting computes the same function):
- *   "attn_sched" 0 | 1 (schedule of the attention kernel's KV-tile loop), "attn_w4" 0 | 1 (128-query blocks at any length).
- * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4.  Returns 0, or -1 for an unknown name. */
+ *   "attn_sched" 0 | 1 | 2 (schedule of the attention kernel's KV-tile loop), "attn_w4" 0 | 1 (128-query blocks at any
+ *   length), "attn_tune" bit 0: static wave priority, bit 1: 16-byte epilogue stores.
+ * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 
 /* activation codes used by epilogues */

@@ -13,7 +13,11 @@ extern "C" int jpeg_host_info(const uint8_t* d, int64_t len, int32_t* out48) {
 }
 
 // decode to RGB [H, W, 3]; returns the parse status (nothing is written unless it is 0)
-extern "C" int jpeg_host_decode_rgb(const uint8_t* d, int64_t len, uint8_t* rgb) {
+extern "C" int jpeg_host_decode_rgb(const uint8_t* file, int64_t len, uint8_t* rgb) {
+  // the reader's contract (jpeg_core.h): the blob starts on an 8-byte boundary and JPEG_TAIL_PAD readable bytes follow the file
+  std::vector<uint64_t> blob((len + JPEG_TAIL_PAD + 7) / 8 + 1, 0);
+  memcpy(blob.data(), file, (size_t)len);
+  const uint8_t* d = (const uint8_t*)blob.data();
   JpegInfo o;
   jpeg_parse(d, len, &o);
   if (o.status) return o.status;

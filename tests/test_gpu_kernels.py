@@ -203,17 +203,19 @@ def test_attention_schedules_are_bit_identical(gpu):
     s_pad = (S + 63) // 64 * 64
     vt = torch.empty((B, H, 128, s_pad), dtype=torch.bfloat16, device=gpu)
     ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
-    outs = []
+    outs = {}
     try:
-        for sched, w4 in ((0, 0), (1, 0), (0, 1), (1, 1)):
-            ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4)
-            o = torch.empty((B, S, D), dtype=torch.bfloat16, device=gpu)
+        for sched, w4, tune in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 3), (1, 0, 2), (0, 1, 0), (1, 1, 0), (2, 1, 3)):
+            ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4); ops.set_option("attn_tune", tune)
+            o = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
             ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
-            outs.append(o.cpu())
+            outs[(sched, w4, tune)] = o.cpu()
     finally:
-        ops.set_option("attn_sched", 1); ops.set_option("attn_w4", 0)          # the library's defaults
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
-    assert _rel(outs[0], outs[2]) < 1e-2
+        ops.set_option("attn_sched", 1); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 0)   # the library's defaults
+    ref = outs[(0, 0, 0)]
+    assert torch.isfinite(ref.float()).all()
+    for key, o in outs.items():
+        assert torch.equal(o, ref), key
     with pytest.raises(RuntimeError):
         ops.set_option("no_such_switch", 1)
 
