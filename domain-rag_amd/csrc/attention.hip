@@ -563,7 +563,7 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   const int sched = drag_opt(DRAG_OPT_ATTN_SCHED);          // 0, 1, or 2 = schedule 1 + pipelined row maxima
   const bool qprep = wq_txt != nullptr;
   p.tune = drag_opt(DRAG_OPT_ATTN_TUNE);
-  DRAG_CHECK(!(p.tune & 2) || ld_o % 8 == 0, "drag_attention_bf16: 16-byte epilogue stores need ld_o % 8 == 0");
+  if (ld_o % 8 != 0 || ((uintptr_t)out & 15) != 0 || o_batch_stride % 8 != 0) p.tune &= ~2;     // 16-byte stores need 16-byte aligned rows
   const hipStream_t st = (hipStream_t)stream;
 #define DRAG_ATTN_LAUNCH(NW, SC, QP, PM) hipLaunchKernelGGL((attention_d128_kernel<NW, SC, QP, PM>), grid, dim3(NW * 64), 0, st, p)
 #define DRAG_ATTN_PICK(NW)                                                                           \

@@ -27,6 +27,7 @@ static void opt_init() {
     g_opt[i] = e ? (*e ? atoi(e) : 1) : 0;
   }
   g_opt[DRAG_OPT_ATTN_SCHED] = getenv(g_opt_env[DRAG_OPT_ATTN_SCHED]) ? g_opt[DRAG_OPT_ATTN_SCHED] : DRAG_ATTN_SCHED_DEFAULT;
+  g_opt[DRAG_OPT_ATTN_TUNE] = getenv(g_opt_env[DRAG_OPT_ATTN_TUNE]) ? g_opt[DRAG_OPT_ATTN_TUNE] : DRAG_ATTN_TUNE_DEFAULT;
   g_opt_init = true;
 }
 

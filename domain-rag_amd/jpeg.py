@@ -61,30 +61,95 @@ class DecodedBatch:
 
 
 _staging: dict = {}
+PAD = 64            # readable bytes after the last file (the bit reader's read-ahead window looks up to 32 bytes past a file)
+
+
+def _staging_buffer(device, nbytes: int, slot: int = 0) -> torch.Tensor:
+    """pinned host buffer of at least nbytes (reused per (device, slot), grown geometrically)"""
+    key = (str(device), slot)
+    buf = _staging.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 2 * (buf.numel() if buf is not None else 0)), dtype=torch.uint8).pin_memory()
+        _staging[key] = buf
+    return buf
+
+
+class StagedFiles:
+    """a batch of files sitting in a pinned host buffer, ready for ONE upload: ``buf[:offsets[-1] + PAD]``; ``errors`` maps the
+    index of a file that could not be read to the exception (its slot is empty: offsets[i] == offsets[i + 1])"""
+
+    def __init__(self, buf: torch.Tensor, offsets: np.ndarray, errors: dict):
+        self.buf, self.offsets, self.errors = buf, offsets, errors
+
+    def __len__(self) -> int:
+        return len(self.offsets) - 1
+
+    def file_bytes(self, i: int) -> bytes:
+        return self.buf.numpy()[self.offsets[i]: self.offsets[i + 1]].tobytes()
+
+
+def stage_paths(paths, device="cuda", slot: int = 0, pool=None) -> StagedFiles:
+    """read files straight into the pinned staging buffer (no intermediate bytes objects, no concatenation pass): sizes first,
+    then ``readinto`` at each file's offset — both on ``pool`` (a ThreadPoolExecutor; file I/O releases the GIL)"""
+    import os
+    n = len(paths)
+
+    def size(p):
+        try:
+            return os.path.getsize(p)
+        except OSError as ex:
+            return ex
+    sizes = list(pool.map(size, paths)) if pool is not None else [size(p) for p in paths]
+    errors = {i: s for i, s in enumerate(sizes) if not isinstance(s, int)}
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([s if isinstance(s, int) else 0 for s in sizes], out=offsets[1:])
+    total = int(offsets[-1])
+    buf = _staging_buffer(device, total + PAD, slot)
+    host = buf.numpy()
+
+    def fill(i):
+        if i in errors or offsets[i] == offsets[i + 1]:
+            return None
+        try:
+            with open(paths[i], "rb", buffering=0) as f:
+                view = memoryview(host)[offsets[i]: offsets[i + 1]]
+                got = 0
+                while got < len(view):
+                    k = f.readinto(view[got:])
+                    if not k:
+                        raise OSError(f"short read: {got} of {len(view)} bytes")
+                    got += k
+        except OSError as ex:
+            return ex
+        return None
+    res = list(pool.map(fill, range(n))) if pool is not None else [fill(i) for i in range(n)]
+    for i, r in enumerate(res):
+        if r is not None:
+            errors[i] = r
+            host[offsets[i]: offsets[i + 1]] = 0      # not a JPEG any more: the parse kernel reports it, nothing decodes it
+    host[total: total + PAD] = 0
+    return StagedFiles(buf, offsets, errors)
 
 
 def _upload(blobs, device):
-    """concatenate into a pinned staging buffer (reused, grown geometrically) and upload once"""
+    """concatenate bytes objects into the pinned staging buffer and upload once"""
     sizes = np.fromiter((len(b) for b in blobs), dtype=np.int64, count=len(blobs))
     offsets = np.zeros(len(blobs) + 1, dtype=np.int64)
     np.cumsum(sizes, out=offsets[1:])
     total = int(offsets[-1])
-    key = str(device)
-    buf = _staging.get(key)
-    if buf is None or buf.numel() < total + 64:
-        buf = torch.empty(max(total + 64, 2 * (buf.numel() if buf is not None else 0)), dtype=torch.uint8).pin_memory()
-        _staging[key] = buf
+    buf = _staging_buffer(device, total + PAD)
     host = buf.numpy()
     for b, o in zip(blobs, offsets[:-1]):
         host[o: o + len(b)] = np.frombuffer(b, dtype=np.uint8)
-    host[total: total + 64] = 0                       # the bit reader's read-ahead window looks up to 32 bytes past a file
-    data = buf[: total + 64].to(device, non_blocking=True)
+    host[total: total + PAD] = 0
+    data = buf[: total + PAD].to(device, non_blocking=True)
     return data, offsets
 
 
 def decode_files(blobs, device="cuda", check_scan: bool = True) -> DecodedBatch:
-    """``blobs``: list of bytes objects (whole files).  All arithmetic runs in libdomainrag_hip.so.  ``check_scan``: read the
-    per-file end-of-scan flags back (one more synchronisation) and mark files whose entropy data does not end at EOI."""
+    """``blobs``: list of bytes objects (whole files), or a ``StagedFiles`` (``stage_paths``).  All arithmetic runs in
+    libdomainrag_hip.so.  ``check_scan``: read the per-file end-of-scan flags back (one more synchronisation) and mark files
+    whose entropy data does not end at EOI."""
     lib = _lib.load()
     n = len(blobs)
     if n == 0:
@@ -94,7 +159,11 @@ def decode_files(blobs, device="cuda", check_scan: bool = True) -> DecodedBatch:
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("decode_files: the JPEG decoder is a GPU path (domain-rag_amd has no CPU fallback)")
-    data, offsets = _upload(blobs, device)
+    if isinstance(blobs, StagedFiles):
+        offsets = blobs.offsets
+        data = blobs.buf[: int(offsets[-1]) + PAD].to(device, non_blocking=True)
+    else:
+        data, offsets = _upload(blobs, device)
     d_off = torch.from_numpy(offsets).to(device)
     d_info = torch.empty((n, INFO_WORDS), dtype=torch.int32, device=device)
     check(lib.drag_jpeg_parse(_p(data), _p(d_off), n, _p(d_info), _stream()), "drag_jpeg_parse")

@@ -359,85 +359,64 @@ def allgather_rows(local: torch.Tensor, n_total: int, group=None, force: bool = 
 
 
 def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch.Tensor, ok: torch.Tensor, batch: int,
-                            files_per_batch: int = 4096, readers: int = 16) -> dict:
-    """corpus rows of this rank with the JPEG decode on the GPU: reader threads only READ the files; a batch of files is
-    uploaded as one blob, decoded (``jpeg.decode_files``: byte-identical to ``Image.open(f).convert("RGB")``), resized + centre-
-    cropped per size class by the PIL-exact resample kernel and embedded.  Files outside the device decoder's coverage
-    (progressive, CMYK, PNG, damaged, ...) go through PIL on the host, one by one, like the reference does for every file;
-    what PIL cannot open is skipped with the reference's message (:290-292).  Returns counters."""
+                            files_per_batch: int = 16384, readers: int = 32) -> dict:
+    """corpus rows of this rank with the JPEG decode on the GPU.  Reader threads put the FILES of a chunk straight into a pinned
+    buffer (``jpeg.stage_paths``), the chunk is uploaded as one blob, decoded (``jpeg.decode_files``: byte-identical to
+    ``Image.open(f).convert("RGB")``), resized + centre-cropped per size class by the PIL-exact resample kernel and embedded.
+    The entropy decoder runs one image per LANE (~0.15 s for a 125-KiB file whatever the batch), so its throughput is its batch:
+    16384 files are 256 waves = every CU once; the reads of chunk c + 1 overlap the GPU work of chunk c.
+    Files outside the device decoder's coverage (progressive, CMYK, PNG, damaged, ...) go through PIL on the host, one by one, like
+    the reference does for every file; what PIL cannot open is skipped with the reference's message (:290-292).  Returns counters."""
     import concurrent.futures as cf
     import io
     from PIL import Image
     from . import jpeg, resample
     dev = model.device
     stats = {"gpu_decoded": 0, "host_decoded": 0, "failed": 0}
-
-    def read(p):
-        try:
-            with open(clean_image_path(p), "rb") as f:
-                return f.read()
-        except OSError as ex:
-            return ex
-
     chunks = [list(range(i, min(i + files_per_batch, len(mine)))) for i in range(0, len(mine), files_per_batch)]
-    main = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(dev)              # decode + resize of chunk c+1 run here while the tower embeds chunk c on `main`
 
-    def decode_chunk(rows, blobs):
-        """files -> uint8 crops [m, 224, 224, 3] on the side stream; returns (crops, global row per crop, done event)"""
-        good = [k for k, b in enumerate(blobs) if isinstance(b, bytes) and len(b) > 0]
-        for k, b in enumerate(blobs):
-            if not (isinstance(b, bytes) and len(b) > 0):
-                print(f"处理图像 {mine[rows[k]]} 时出错: {b if not isinstance(b, bytes) else 'empty file'}")
+    def embed_chunk(rows, staged):
+        for k, ex in sorted(staged.errors.items()):
+            print(f"处理图像 {mine[rows[k]]} 时出错: {ex}")
+            stats["failed"] += 1
+        dec = jpeg.decode_files(staged, dev)
+        n = len(rows)
+        crops = torch.empty((n, 224, 224, 3), dtype=torch.uint8, device=dev)
+        have = np.zeros(n, dtype=bool)
+        for (_h, _w), idx, imgs in dec.groups():
+            crops[torch.from_numpy(idx).to(dev)] = resample.clip_preprocess_u8(imgs)
+            have[idx] = True
+        stats["gpu_decoded"] += int(have.sum())
+        for g in np.nonzero(~have)[0].tolist():             # the device decoder declined: PIL decides (same bytes by definition)
+            if g in staged.errors:
+                continue
+            try:
+                img = Image.open(io.BytesIO(staged.file_bytes(g))).convert("RGB")
+                crops[g] = clip_preprocess_device(img, dev)
+                have[g] = True
+                stats["host_decoded"] += 1
+            except Exception as ex:
+                print(f"处理图像 {mine[rows[g]]} 时出错: {ex}")
                 stats["failed"] += 1
-        if not good:
-            return None
-        with torch.cuda.stream(side):
-            dec = jpeg.decode_files([blobs[k] for k in good], dev)
-            crops = torch.empty((len(good), 224, 224, 3), dtype=torch.uint8, device=dev)
-            have = np.zeros(len(good), dtype=bool)
-            for (_h, _w), idx, imgs in dec.groups():
-                crops[torch.from_numpy(idx).to(dev)] = resample.clip_preprocess_u8(imgs)
-                have[idx] = True
-            stats["gpu_decoded"] += int(have.sum())
-            for g in np.nonzero(~have)[0].tolist():         # the device decoder declined: PIL decides (same bytes by definition)
-                try:
-                    img = Image.open(io.BytesIO(blobs[good[g]])).convert("RGB")
-                    crops[g] = clip_preprocess_device(img, dev)
-                    have[g] = True
-                    stats["host_decoded"] += 1
-                except Exception as ex:
-                    print(f"处理图像 {mine[rows[good[g]]]} 时出错: {ex}")
-                    stats["failed"] += 1
-            keep = np.nonzero(have)[0]
-            if len(keep) == 0:
-                return None
-            if len(keep) < len(good):
-                crops = crops[torch.from_numpy(keep).to(dev)]
-            done = torch.cuda.Event()
-            done.record(side)
-        crops.record_stream(main)                           # allocated on `side`, consumed on `main`
-        return crops, [rows[good[g]] for g in keep.tolist()], done
-
-    def embed_chunk(job):
-        crops, grows, done = job
-        main.wait_event(done)
+        keep = np.nonzero(have)[0]
+        if len(keep) == 0:
+            return
+        if len(keep) < n:
+            crops = crops[torch.from_numpy(keep).to(dev)]
         emb = embed_images(model, crops, batch)
-        ii = torch.tensor(grows, device=dev)
+        ii = torch.tensor([rows[g] for g in keep.tolist()], device=dev)
         feats[ii] = emb
         ok[ii] = 1.0
 
-    with cf.ThreadPoolExecutor(max_workers=max(1, readers)) as pool:
-        pending = [pool.submit(read, mine[j]) for j in chunks[0]] if chunks else []
-        prev = None
+    with cf.ThreadPoolExecutor(max_workers=max(1, readers)) as pool, cf.ThreadPoolExecutor(max_workers=1) as stager:
+        def stage(ci):
+            return jpeg.stage_paths([clean_image_path(mine[j]) for j in chunks[ci]], dev, slot=ci & 1, pool=pool)
+        nxt = stager.submit(stage, 0) if chunks else None
         for ci, rows in enumerate(chunks):
-            blobs = [f.result() for f in pending]
-            pending = [pool.submit(read, mine[j]) for j in chunks[ci + 1]] if ci + 1 < len(chunks) else []   # next chunk reads ahead
-            if prev is not None:
-                embed_chunk(prev)                           # enqueue the tower for chunk c-1, THEN block in chunk c's decode
-            prev = decode_chunk(rows, blobs)
-        if prev is not None:
-            embed_chunk(prev)
+            staged = nxt.result()
+            # slot (ci + 1) & 1 was uploaded one chunk ago and that upload was waited for (descriptor read-back): free to refill
+            nxt = stager.submit(stage, ci + 1) if ci + 1 < len(chunks) else None
+            embed_chunk(rows, staged)
     torch.cuda.synchronize(dev)
     return stats
 

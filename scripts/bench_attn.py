@@ -30,5 +30,5 @@ for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
             for k, v in env.items(): ops.set_option(k, v)
             if rep == 0: bench(run, 3)
             t[name].append(bench(run))
-    ops.set_option("attn_sched", 1); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 0)
+    ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2)
     print(f"attn B={B} S={S} H={H}: " + " | ".join(f"{k} {fl/statistics.median(v)/1e9:.0f} TF/s" for k, v in t.items()), flush=True)
