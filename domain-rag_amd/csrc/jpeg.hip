@@ -9,7 +9,7 @@
 //                          offsets, scan offset, status).  The host reads the descriptors back once to size the outputs.
 //   jpeg_huffman_kernel    one image per LANE, one wave per workgroup.  Entropy decoding is inherently serial per image (COCO
 //                          files carry no restart markers), so the parallelism is ACROSS images: 64 bit-streams per wave, every
-//                          lane with its own four code tables in LDS (direct table + packed length limits + symbols, 131 KiB per
+//                          lane with its own four code tables in LDS (direct table + packed length limits + symbols, 85 KiB per
 //                          wave, lane-interleaved so a lookup is bank-conflict free whatever the codes are; no per-symbol access
 //                          leaves LDS / registers), coefficients scattered into a zeroed int16
 //                          buffer in natural order.  A 4096-image batch is 64 waves on 64 CUs; the other CUs keep running the
@@ -24,7 +24,7 @@
 namespace {
 
 // Per-lane decoding tables in LDS, element e of lane l at base[e * 64 + l] (the 64 lanes of an access hit 64 consecutive
-// elements: no bank conflicts whatever the codes are).  DC tables: 6-bit direct table, 16 symbols; AC: 8-bit, 256 symbols.
+// elements: no bank conflicts whatever the codes are).  6-bit direct tables; 16 symbols per DC table, 256 per AC table.
 template <int LB_, int NV_>
 struct LdsTable {
   enum { LB = LB_, NV = NV_ };
@@ -36,7 +36,7 @@ struct LdsTable {
   __device__ __forceinline__ DRAG_LDS uint8_t& val(int i) const { return v[i * 64]; }
 };
 typedef LdsTable<6, 16> DcTable;
-typedef LdsTable<8, 256> AcTable;
+typedef LdsTable<6, 256> AcTable;      // 6-bit direct tables keep the wave at 85 KiB of LDS: see JPEG_HUFF_LDS
 
 struct JpegArgs {
   const uint8_t* data;
@@ -73,13 +73,17 @@ struct LdsNat {                      // zigzag -> natural order, one copy per wa
   __device__ __forceinline__ DRAG_LDS uint8_t& operator[](int k) const { return t[k]; }
 };
 
-// LDS carve (bytes): u16 direct tables [2 x 64 DC + 2 x 256 AC][64 lanes] | u32 limit/first words [4 x 17][64] |
+// LDS carve (bytes): u16 direct tables [4 x 64][64 lanes] | u32 limit/first words [4 x 17][64] |
 //                    u8 symbols [2 x 16 DC + 2 x 256 AC][64] | natural order [80]
-constexpr int JPEG_LUT_ELEMS = 2 * 64 + 2 * 256;
-constexpr int JPEG_LUT_BYTES = JPEG_LUT_ELEMS * 64 * 2;        //  81 920
+// The direct tables are deliberately short (6 bits): with 64 streams per wave some lane is on a longer code at almost every
+// symbol, so the long-code path (16 packed words, fetched unconditionally) runs anyway and a bigger table buys nothing — while
+// 85 KiB instead of 131 lets the wave share a CU's 160 KiB with the embedding tower's workgroups, so that the decode of one
+// chunk overlaps the tower of the previous one instead of waiting for a CU to drain completely.
+constexpr int JPEG_LUT_ELEMS = 4 * 64;
+constexpr int JPEG_LUT_BYTES = JPEG_LUT_ELEMS * 64 * 2;        //  32 768
 constexpr int JPEG_LIMK_BYTES = 4 * 17 * 64 * 4;               //  17 408
 constexpr int JPEG_VAL_BYTES = (2 * 16 + 2 * 256) * 64;        //  34 816
-constexpr int JPEG_HUFF_LDS = JPEG_LUT_BYTES + JPEG_LIMK_BYTES + JPEG_VAL_BYTES + 128;   // 134 272: one wave per CU
+constexpr int JPEG_HUFF_LDS = JPEG_LUT_BYTES + JPEG_LIMK_BYTES + JPEG_VAL_BYTES + 128;   // 85 120
 
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
   DRAG_LDS uint8_t* const V = (DRAG_LDS uint8_t*)(lds + JPEG_LUT_BYTES + JPEG_LIMK_BYTES) + lane;
   // table id 0 / 1 of each class
   const DcTable dct[2] = {{L, K, V}, {L + 64 * 64, K + 17 * 64, V + 16 * 64}};
-  const AcTable act[2] = {{L + 128 * 64, K + 34 * 64, V + 32 * 64}, {L + (128 + 256) * 64, K + 51 * 64, V + (32 + 256) * 64}};
+  const AcTable act[2] = {{L + 128 * 64, K + 34 * 64, V + 32 * 64}, {L + (128 + 64) * 64, K + 51 * 64, V + (32 + 256) * 64}};
 #pragma unroll
   for (int id = 0; id < 2; ++id) {
     if (o.dht_off[id] >= 0) jpeg_build_huff(d + o.dht_off[id], dct[id]);
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
       for (int c = 0; c < 3; ++c) {
         // the view of table id 1 is the view of id 0 plus constant offsets: select by arithmetic, not by indexing an array
         const DcTable dc{L + td[c] * (64 * 64), K + td[c] * (17 * 64), V + td[c] * (16 * 64)};
-        const AcTable ac{L + (128 + ta[c] * 256) * 64, K + (34 + ta[c] * 17) * 64, V + (32 + ta[c] * 256) * 64};
+        const AcTable ac{L + (128 + ta[c] * 64) * 64, K + (34 + ta[c] * 17) * 64, V + (32 + ta[c] * 256) * 64};
         for (int v = 0; v < vs[c]; ++v)
           for (int h = 0; h < hs[c]; ++h) {
             int16_t* blk = cbase[c] + ((long long)(my * vs[c] + v) * bw[c] + mx * hs[c] + h) * 64;
@@ -226,7 +230,7 @@ extern "C" int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, co
   a.coef = (int16_t*)coef_ws; a.planes = (uint8_t*)plane_ws; a.qtab = (uint16_t*)qtab_ws; a.out = (uint8_t*)out_rgb; a.scan_status = scan_status; a.n = n;
   hipError_t e = hipMemsetAsync(coef_ws, 0, (size_t)coef_bytes, st);     // blocks are sparse: only non-zero coefficients are stored
   DRAG_CHECK(e == hipSuccess, "drag_jpeg_decode_rgb: memset failed");
-  const int lds = JPEG_HUFF_LDS;                                          // 128 KiB + 128 B: one wave per CU
+  const int lds = JPEG_HUFF_LDS;                                          // 85 KiB per wave
   static bool lds_ok = false;
   if (!lds_ok) {
     e = hipFuncSetAttribute((const void*)jpeg_huffman_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

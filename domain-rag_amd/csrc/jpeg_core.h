@@ -33,6 +33,7 @@ enum {
   JPEG_ERR_MULTISCAN = 7,        // a scan that does not carry all components, or spectral selection / successive approximation
   JPEG_ERR_TABLES = 8,           // a referenced Huffman / quantisation table was never defined
   JPEG_ERR_TOO_SMALL = 9,        // subsampled chroma at most 2 samples wide (libjpeg switches to box replication there)
+  JPEG_ERR_TOO_LARGE = 11,       // more than 2^26 pixels (a header can claim 65535 x 65535: the caller's decoder has its own bomb limit)
 };
 
 struct JpegInfo {               // == drag_jpeg_info (include/domainrag_hip.h): 48 x int32
@@ -159,6 +160,7 @@ JHD void jpeg_parse(const uint8_t* d, int64_t len, JpegInfo* o) {
       o->status = JPEG_ERR_SAMPLING; return;
     }
   }
+  if ((int64_t)o->width * o->height > ((int64_t)1 << 26)) { o->status = JPEG_ERR_TOO_LARGE; return; }
   o->hmax = o->hs[0]; o->vmax = o->vs[0];
   o->mcus_x = (o->width + 8 * o->hmax - 1) / (8 * o->hmax);
   o->mcus_y = (o->height + 8 * o->vmax - 1) / (8 * o->vmax);

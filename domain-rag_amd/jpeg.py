@@ -24,7 +24,7 @@ from .ops import _p, _stream, check
 INFO_WORDS = 48
 STATUS_TEXT = {0: "ok", 1: "not a JPEG", 2: "truncated header", 3: "progressive / arithmetic / lossless", 4: "not 8-bit",
                5: "not grey or YCbCr", 6: "sampling other than 4:4:4 / 4:2:2 / 4:2:0", 7: "multi-scan", 8: "table problem",
-               9: "chroma at most 2 samples wide", 10: "entropy-coded data does not end at EOI (cut short / trailing data / damaged)"}
+               9: "chroma at most 2 samples wide", 11: "more than 2^26 pixels", 10: "entropy-coded data does not end at EOI (cut short / trailing data / damaged)"}
 
 
 class DecodedBatch:

@@ -375,36 +375,49 @@ def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch
     stats = {"gpu_decoded": 0, "host_decoded": 0, "failed": 0}
     chunks = [list(range(i, min(i + files_per_batch, len(mine)))) for i in range(0, len(mine), files_per_batch)]
 
-    def embed_chunk(rows, staged):
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)       # decode + resize of chunk c + 1 run here, under the tower of chunk c on `main`
+
+    def decode_chunk(rows, staged):
+        """files -> uint8 crops on the side stream (the host blocks in the decoder's two read-backs; the GPU does not)"""
         for k, ex in sorted(staged.errors.items()):
             print(f"处理图像 {mine[rows[k]]} 时出错: {ex}")
             stats["failed"] += 1
-        dec = jpeg.decode_files(staged, dev)
         n = len(rows)
-        crops = torch.empty((n, 224, 224, 3), dtype=torch.uint8, device=dev)
-        have = np.zeros(n, dtype=bool)
-        for (_h, _w), idx, imgs in dec.groups():
-            crops[torch.from_numpy(idx).to(dev)] = resample.clip_preprocess_u8(imgs)
-            have[idx] = True
-        stats["gpu_decoded"] += int(have.sum())
-        for g in np.nonzero(~have)[0].tolist():             # the device decoder declined: PIL decides (same bytes by definition)
-            if g in staged.errors:
-                continue
-            try:
-                img = Image.open(io.BytesIO(staged.file_bytes(g))).convert("RGB")
-                crops[g] = clip_preprocess_device(img, dev)
-                have[g] = True
-                stats["host_decoded"] += 1
-            except Exception as ex:
-                print(f"处理图像 {mine[rows[g]]} 时出错: {ex}")
-                stats["failed"] += 1
-        keep = np.nonzero(have)[0]
-        if len(keep) == 0:
-            return
-        if len(keep) < n:
-            crops = crops[torch.from_numpy(keep).to(dev)]
-        emb = embed_images(model, crops, batch)
-        ii = torch.tensor([rows[g] for g in keep.tolist()], device=dev)
+        with torch.cuda.stream(side):
+            dec = jpeg.decode_files(staged, dev)
+            crops = torch.empty((n, 224, 224, 3), dtype=torch.uint8, device=dev)
+            have = np.zeros(n, dtype=bool)
+            for (_h, _w), idx, imgs in dec.groups():
+                crops[torch.from_numpy(idx).to(dev)] = resample.clip_preprocess_u8(imgs)
+                have[idx] = True
+            stats["gpu_decoded"] += int(have.sum())
+            for g in np.nonzero(~have)[0].tolist():         # the device decoder declined: PIL decides (same bytes by definition)
+                if g in staged.errors:
+                    continue
+                try:
+                    img = Image.open(io.BytesIO(staged.file_bytes(g))).convert("RGB")
+                    crops[g] = clip_preprocess_device(img, dev)
+                    have[g] = True
+                    stats["host_decoded"] += 1
+                except Exception as ex:
+                    print(f"处理图像 {mine[rows[g]]} 时出错: {ex}")
+                    stats["failed"] += 1
+            keep = np.nonzero(have)[0]
+            if len(keep) == 0:
+                return None
+            if len(keep) < n:
+                crops = crops[torch.from_numpy(keep).to(dev)]
+            done = torch.cuda.Event()
+            done.record(side)
+        crops.record_stream(main)                           # allocated on `side`, consumed on `main`
+        return crops, [rows[g] for g in keep.tolist()], done
+
+    def embed_chunk(job):
+        crops, grows, done = job
+        main.wait_event(done)
+        emb = embed_images(model, crops, batch)             # asynchronous: the next chunk's decode starts while this runs
+        ii = torch.tensor(grows, device=dev)
         feats[ii] = emb
         ok[ii] = 1.0
 
@@ -416,7 +429,9 @@ def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch
             staged = nxt.result()
             # slot (ci + 1) & 1 was uploaded one chunk ago and that upload was waited for (descriptor read-back): free to refill
             nxt = stager.submit(stage, ci + 1) if ci + 1 < len(chunks) else None
-            embed_chunk(rows, staged)
+            job = decode_chunk(rows, staged)
+            if job is not None:
+                embed_chunk(job)
     torch.cuda.synchronize(dev)
     return stats
 

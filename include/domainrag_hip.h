@@ -332,7 +332,7 @@ int drag_attention_small_f32(const float* qkv, float* out, int32_t B, int32_t T,
  *   drag_jpeg_parse: data = concatenated files, offsets int64 [n+1] (device); writes one descriptor per file (device).
  *     status 0 = decodable here; 1 not a JPEG, 2 truncated header, 3 progressive / arithmetic / lossless, 4 not 8-bit,
  *     5 not grey / YCbCr, 6 sampling other than 4:4:4 / 4:2:2 / 4:2:0, 7 multi-scan, 8 table problem, 9 chroma <= 2 samples
- *     wide.  Files with a non-zero status are skipped by drag_jpeg_decode_rgb (the caller decodes those few elsewhere).
+ *     wide, 11 more than 2^26 pixels.  Files with a non-zero status are skipped by drag_jpeg_decode_rgb (the caller decodes those few elsewhere).
  *   drag_jpeg_decode_rgb: plan int64 [n, 3] (device) = per file: offset into coef_ws (int16 elements), into plane_ws
  *     (bytes), into out_rgb (bytes); a file needs 64 * blocks int16 of coefficients and 64 * blocks bytes of planes where
  *     blocks = sum over components of (mcus_x * hs) * (mcus_y * vs), and width * height * 3 output bytes ([H, W, 3]).

@@ -23,7 +23,7 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* file, int64_t len, uint8_t* r
   if (o.status) return o.status;
   // one table view per (component, class): plain arrays on the host
   struct HostTable {
-    enum { LB = 8, NV = 256 };
+    enum { LB = 6, NV = 256 };      // the kernel's table geometry (csrc/jpeg.hip)
     uint16_t* l; uint32_t* k; uint8_t* v;
     uint16_t& lut(int i) const { return l[i]; }
     uint32_t& limk(int i) const { return k[i]; }
