@@ -468,6 +468,295 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// EXPERIMENT (drag_set_option "attn_q64"): 4 waves x 64 queries, ONE wave per SIMD with the whole 512-entry register file.
+// Each wave owns two 32-query groups and runs both against every K / V^T fragment it reads, which halves the LDS fragment
+// reads per flop (the 8-wave kernel's other cost besides the exp stream).  Same arithmetic per query group, same deferred-
+// rescale decisions (taken per group), so the outputs equal the 8-wave kernel's bit for bit.  Schedule = SCHED 1 + PMAX.
+// --------------------------------------------------------------------------------------------
+// MFMAs of the 64-query kernel are inline asm so that the operand FILES are fixed: O accumulators and the Q fragments live
+// in the AGPR half (only MFMAs touch them), the S accumulators in arch VGPRs (the softmax reads them).  With builtins hipcc
+// puts S into AGPRs as well and copies 200-400 registers per KV tile back and forth (measured: 473-668 v_accvgpr / scratch
+// instructions per 64 MFMAs).  hipcc neither counts nor pads what is inside an asm statement (guide 5.7):
+//   * a VALU-written B operand (packed P) needs 2 wait states before the MFMA reads it: `s_nop 1` opens the P V statement;
+//   * an MFMA result needs 18 wait states (16-pass op) before anything but the next MFMA of its chain touches it: Q64_SETTLE
+//     passes the registers through a nop statement before compiler-generated code may read them.
+#define Q64_MFMA_S0(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b))
+#define Q64_MFMA_S(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b))
+#define Q64_MFMA_O(d, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b))
+#define Q64_SETTLE_S(s4) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s4[0][0]), "+v"(s4[0][1]), "+v"(s4[1][0]), "+v"(s4[1][1]))
+#define Q64_SETTLE_O(o, qg) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[qg][0]), "+a"(o[qg][1]), "+a"(o[qg][2]), "+a"(o[qg][3]))
+
+template <bool QPREP>
+__global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
+  const int w = wave_id(), l = lane_id();
+  const int hh = l >> 5;
+  constexpr int QB = 256, CPW = 4;
+  const int nqb = (p.S + QB - 1) / QB;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int bh = (loc / nqb) * 8 + xcd;
+  if (bh >= p.B * p.H) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (loc - (loc / nqb) * nqb) * QB + w * 64;        // group qg: queries q0 + 32 qg + (l & 31)
+
+  bf16x8_t qf[2][8];
+  const bf16_t* kbase = p.k + (long long)b * p.qk_bs + h * 128;
+  const bf16_t* vbase = p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
+  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.vt_bytes, 0x00020000);
+  int krow[4];
+  unsigned kslot[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = w * CPW + i;
+    krow[i] = c * 4 + (l >> 4);
+    kslot[i] = (unsigned)(((l & 15) ^ (krow[i] & 15)) * 16);
+    const int vrow = c * 8 + (l >> 3);
+    const int vslot = (l & 7) ^ ((vrow >> 1) & 7);
+    voff[i] = (unsigned)(((long long)vrow * p.s_pad + vslot * 8) * 2);
+  }
+  auto stage_k1 = [&](int buf, int kv0, int i) {
+    const int c = w * CPW + i;
+    const int kr = min(kv0 + krow[i], p.S - 1);
+    const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024), 16, ko, 0, 0, 0);
+  };
+  auto stage_v1 = [&](int buf, int kv0, int i) {
+    const int c = w * CPW + i;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)((DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024),
+                                             16, voff[i], kv0 * 2, 0, 0);
+  };
+  const int krd = (l & 31) * 256, kx = l & 15;
+  const int vrd = (l & 31) * 128, vx = ((l & 31) >> 1) & 7;
+  int ak[8], av[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) ak[ks] = krd + (((2 * ks + hh) ^ kx) << 4);
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) av[s2] = vrd + (((2 * s2 + hh) ^ vx) << 4);
+
+  f32x16_t oacc[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qg][i][r] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  const int nkv = p.s_pad / 64;
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) stage_k1(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) stage_v1(0, 0, i);
+  if (nkv > 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_k1(1, 64, i);
+  }
+  // Q load (+ RMSNorm / RoPE when QPREP) while those tiles are in flight
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int qr = min(q0 + 32 * qg + (l & 31), p.S - 1);
+    const bf16_t* qp = p.q + (long long)b * p.qk_bs + (long long)qr * p.ld_qk + h * 128 + hh * 8;
+    if constexpr (!QPREP) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[qg][ks] = *(const bf16x8_t*)(qp + ks * 16);
+    } else {
+      const bf16_t* wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
+      const float* cp = p.cosT + (long long)qr * 64 + hh * 4;
+      const float* sp = p.sinT + (long long)qr * 64 + hh * 4;
+      u32x4_t raw[8], wr[8];
+      f32x4_t c4[8], s4[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        raw[ks] = *(const u32x4_t*)(qp + ks * 16);
+        wr[ks] = *(const u32x4_t*)(wsel + ks * 16);
+        c4[ks] = *(const f32x4_t*)(cp + ks * 8);
+        s4[ks] = *(const f32x4_t*)(sp + ks * 8);
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+          ss += a0 * a0;
+          ss += a1 * a1;
+        }
+      ss += __shfl_xor(ss, 32, 64);
+      const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a0 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] & 0xffff)) * rs) * bf2f((bf16_t)(wr[ks][j] & 0xffff)));
+          const float a1 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] >> 16)) * rs) * bf2f((bf16_t)(wr[ks][j] >> 16)));
+          o[j] = pack2bf(a0 * c4[ks][j] - a1 * s4[ks][j], a1 * c4[ks][j] + a0 * s4[ks][j]);
+        }
+        qf[qg][ks] = __builtin_bit_cast(bf16x8_t, o);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16_t scur[2][2], snext[2][2];          // [query group][key half]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[ks] + t * (32 * 256)));
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg) {
+        if (ks == 0) Q64_MFMA_S0(scur[qg][t], kf, qf[qg][ks]);
+        else Q64_MFMA_S(scur[qg][t], kf, qf[qg][ks]);
+      }
+    }
+  Q64_SETTLE_S(scur);
+  auto mask_and_max = [&](f32x16_t (&sx)[2], const int kvs) -> float {
+    if (kvs + 64 > p.S) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kvs + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= p.S) sx[t][r] = -INFINITY;
+        }
+    }
+    float m = sx[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sx[t][r]);
+    return fmaxf(m, __shfl_xor(m, 32, 64));
+  };
+  float mt_carry[2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(scur[qg], 0);
+
+  auto body = [&](const int it, auto par, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2]) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr int KN = ((PAR + 1) & 1) * KT_BYTES;
+    constexpr int VB = 2 * KT_BYTES + PAR * VT_BYTES;
+    const int kv0 = it * 64;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float nmc[2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const float mt = mt_carry[qg];
+      if (!__all((mt - m_run[qg]) * p.c <= DEFER_THR)) {
+        Q64_SETTLE_O(oacc, qg);
+        const float m_new = fmaxf(m_run[qg], mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qg] - m_new) * p.c);
+        l_run[qg] *= alpha;
+        m_run[qg] = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[qg][i][r] *= alpha;
+      }
+      nmc[qg] = -(m_run[qg] * p.c);
+    }
+    float ps[2] = {0.f, 0.f};
+    u32x4_t pk[2][4];
+    {
+      bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[0] + KN));
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const bf16x8_t kcur = kf;
+        if (g < 15) {
+          const int t1 = (g + 1) >> 3, ks1 = (g + 1) & 7;
+          kf = *(const bf16x8_t*)(smem + (ak[ks1] + (KN + t1 * (32 * 256))));
+        }
+        bf16x8_t vfg;
+        if (g >= 4) vfg = *(const bf16x8_t*)(smem + (av[(g >> 2) - 1] + (VB + (g & 3) * (32 * 128))));
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
+          if ((g & 7) == 0) Q64_MFMA_S0(sn[qg][g >> 3], kcur, qf[qg][g & 7]);
+          else Q64_MFMA_S(sn[qg][g >> 3], kcur, qf[qg][g & 7]);
+        }
+        if (g < CPW) stage_k1(PAR, kv0 + 128, g);
+        else if (g < 2 * CPW) stage_v1((PAR + 1) & 1, kv0 + 64, g - CPW);
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
+          float y0, y1;
+          asm volatile("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %5"
+                       : "=&v"(y0), "=&v"(y1) : "v"(sc[qg][g >> 3][(2 * g) & 15]), "v"(sc[qg][g >> 3][((2 * g) & 15) + 1]), "s"(p.c), "v"(nmc[qg]));
+          const float e0 = __builtin_amdgcn_exp2f(y0);
+          const float e1 = __builtin_amdgcn_exp2f(y1);
+          ps[qg] += e0 + e1;
+          uint32_t wd = pack2bf(e0, e1);
+          asm volatile("" : "+v"(wd), "+v"(ps[qg]));
+          pk[qg][g >> 2][g & 3] = wd;
+        }
+        if (g >= 4) {
+#pragma unroll
+          for (int qg = 0; qg < 2; ++qg) {
+            const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pk[qg][(g >> 2) - 1]);
+            Q64_MFMA_O(oacc[qg][g & 3], vfg, pfr);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) l_run[qg] += ps[qg];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8_t vf = *(const bf16x8_t*)(smem + (av[3] + (VB + dt * (32 * 128))));
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg) {
+        const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pk[qg][3]);
+        Q64_MFMA_O(oacc[qg][dt], vf, pfr);
+      }
+    }
+    Q64_SETTLE_S(sn);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(sn[qg], kv0 + 64);
+  };
+  for (int it = 0; it < nkv; it += 2) {
+    body(it, std::integral_constant<int, 0>{}, scur, snext);
+    if (it + 1 < nkv) body(it + 1, std::integral_constant<int, 1>{}, snext, scur);
+  }
+
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    Q64_SETTLE_O(oacc, qg);
+    const float lt = l_run[qg] + __shfl_xor(l_run[qg], 32, 64);
+    const float inv = 1.0f / lt;
+    const int qrow = q0 + 32 * qg + (l & 31);
+    if (p.tune & 2) {
+      bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 8 * hh;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          uint32_t a0 = pack2bf(oacc[qg][dt][4 * g] * inv, oacc[qg][dt][4 * g + 1] * inv);
+          uint32_t a1 = pack2bf(oacc[qg][dt][4 * g + 2] * inv, oacc[qg][dt][4 * g + 3] * inv);
+          uint32_t b0 = pack2bf(oacc[qg][dt][4 * g + 4] * inv, oacc[qg][dt][4 * g + 5] * inv);
+          uint32_t b1 = pack2bf(oacc[qg][dt][4 * g + 6] * inv, oacc[qg][dt][4 * g + 7] * inv);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
+          if (qrow < p.S) *(u32x4_t*)(op + 32 * dt + 8 * g) = o;
+        }
+    } else if (qrow < p.S) {
+      bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 4 * hh;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2_t o;
+          o[0] = pack2bf(oacc[qg][dt][4 * g] * inv, oacc[qg][dt][4 * g + 1] * inv);
+          o[1] = pack2bf(oacc[qg][dt][4 * g + 2] * inv, oacc[qg][dt][4 * g + 3] * inv);
+          *(u32x2_t*)(op + 32 * dt + 8 * g) = o;
+        }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt, const void* wk_txt,
@@ -557,7 +846,7 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
   const int groups = (B * H + 7) / 8;
   const bool w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
-  const int QB = w8 ? 256 : 128;
+  const int QB = (w8 || (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024)) ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
   const int sched = drag_opt(DRAG_OPT_ATTN_SCHED);          // 0, 1, or 2 = schedule 1 + pipelined row maxima
@@ -572,7 +861,10 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
     else if (sched == 1) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, false); else DRAG_ATTN_LAUNCH(NW, 1, false, false); } \
     else { if (qprep) DRAG_ATTN_LAUNCH(NW, 0, true, false); else DRAG_ATTN_LAUNCH(NW, 0, false, false); }                 \
   } while (0)
-  if (w8) DRAG_ATTN_PICK(8); else DRAG_ATTN_PICK(4);
+  if (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024) {
+    if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attention_q64_kernel<false>), grid, dim3(256), 0, st, p);
+  } else if (w8) DRAG_ATTN_PICK(8); else DRAG_ATTN_PICK(4);
 #undef DRAG_ATTN_PICK
 #undef DRAG_ATTN_LAUNCH
   DRAG_LAUNCH_CHECK();

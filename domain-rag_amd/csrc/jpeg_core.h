@@ -33,7 +33,7 @@ enum {
   JPEG_ERR_MULTISCAN = 7,        // a scan that does not carry all components, or spectral selection / successive approximation
   JPEG_ERR_TABLES = 8,           // a referenced Huffman / quantisation table was never defined
   JPEG_ERR_TOO_SMALL = 9,        // subsampled chroma at most 2 samples wide (libjpeg switches to box replication there)
-  JPEG_ERR_TOO_LARGE = 11,       // more than 2^26 pixels (a header can claim 65535 x 65535: the caller's decoder has its own bomb limit)
+  JPEG_ERR_TOO_LARGE = 11,       // more than 2^24 pixels (a header can claim 65535 x 65535; a batch path plans memory per file: the caller decodes giants singly)
 };
 
 struct JpegInfo {               // == drag_jpeg_info (include/domainrag_hip.h): 48 x int32
@@ -160,7 +160,7 @@ JHD void jpeg_parse(const uint8_t* d, int64_t len, JpegInfo* o) {
       o->status = JPEG_ERR_SAMPLING; return;
     }
   }
-  if ((int64_t)o->width * o->height > ((int64_t)1 << 26)) { o->status = JPEG_ERR_TOO_LARGE; return; }
+  if ((int64_t)o->width * o->height > ((int64_t)1 << 24)) { o->status = JPEG_ERR_TOO_LARGE; return; }
   o->hmax = o->hs[0]; o->vmax = o->vs[0];
   o->mcus_x = (o->width + 8 * o->hmax - 1) / (8 * o->hmax);
   o->mcus_y = (o->height + 8 * o->vmax - 1) / (8 * o->vmax);
@@ -375,7 +375,7 @@ template <typename TDC, typename TAC, typename NAT>
 JHD void jpeg_decode_block(JpegBits* b, TDC dc, TAC ac, NAT nat, int* dc_pred, int16_t* coef) {
   jpeg_bits_fill(b);
   int s = jpeg_decode_symbol(b, dc) & 15;
-  if (s) *dc_pred += jpeg_receive_extend(b, s);     // a fill leaves >= 33 bits: enough for a 16-bit code + 16 extra bits
+  if (s) *dc_pred = (int)((uint32_t)*dc_pred + (uint32_t)jpeg_receive_extend(b, s));   // (wraps, defined, on a hostile stream)
   coef[0] = (int16_t)*dc_pred;
   for (int k = 1; k < 64; ++k) {
     jpeg_bits_fill(b);
@@ -397,26 +397,32 @@ JHD void jpeg_decode_block(JpegBits* b, TDC dc, TAC ac, NAT nat, int* dc_pred, i
 // in: 64 coefficients (natural order), q: 64 quantisation values (natural order); out: 8 rows of 8 samples, row stride `ld`.
 // Final clamp = saturation to [0, 255] after the +128 level shift: what libjpeg-turbo's SIMD kernels compute (the C code's
 // masked table lookup differs only for |value| > 511, which no encoder produces).
-JHD int jpeg_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// All sums and products are taken modulo 2^32 (unsigned arithmetic, reinterpreted as two's complement where a sign matters):
+// what libjpeg-turbo's 32-bit SIMD lanes compute, identical to its C code whenever nothing overflows — i.e. for every
+// stream an encoder can produce — and DEFINED behaviour for the garbage coefficients of a damaged file.
+typedef uint32_t ju32;
+JHD int jpeg_descale(ju32 x, int n) { return (int)(int32_t)(x + ((ju32)1 << (n - 1))) >> n; }
 JHD uint8_t jpeg_clamp255(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
 JHD void jpeg_idct_1d(const int in[8], int out[8], int shift, bool first) {
-  const int C0298 = 2446, C0390 = 3196, C0541 = 4433, C0765 = 6270, C0899 = 7373, C1175 = 9633, C1501 = 12299, C1847 = 15137,
-            C1961 = 16069, C2053 = 16819, C2562 = 20995, C3072 = 25172;
+  const ju32 C0298 = 2446, C0390 = 3196, C0541 = 4433, C0765 = 6270, C0899 = 7373, C1175 = 9633, C1501 = 12299, C1847 = 15137,
+             C1961 = 16069, C2053 = 16819, C2562 = 20995, C3072 = 25172;
   (void)first;
-  int z2 = in[2], z3 = in[6];
-  int z1 = (z2 + z3) * C0541;
-  int tmp2 = z1 + z3 * (-C1847);
-  int tmp3 = z1 + z2 * C0765;
-  int tmp0 = (in[0] + in[4]) * 8192;          // << CONST_BITS (13), written as a multiply: defined for negative values
-  int tmp1 = (in[0] - in[4]) * 8192;
-  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  const ju32 i0 = (ju32)in[0], i1 = (ju32)in[1], i2 = (ju32)in[2], i3 = (ju32)in[3], i4 = (ju32)in[4], i5 = (ju32)in[5],
+             i6 = (ju32)in[6], i7 = (ju32)in[7];
+  ju32 z2 = i2, z3 = i6;
+  ju32 z1 = (z2 + z3) * C0541;
+  ju32 tmp2 = z1 - z3 * C1847;
+  ju32 tmp3 = z1 + z2 * C0765;
+  ju32 tmp0 = (i0 + i4) << 13;                 // << CONST_BITS
+  ju32 tmp1 = (i0 - i4) << 13;
+  const ju32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = i7; tmp1 = i5; tmp2 = i3; tmp3 = i1;
   z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-  int z4 = tmp1 + tmp3;
-  const int z5 = (z3 + z4) * C1175;
+  ju32 z4 = tmp1 + tmp3;
+  const ju32 z5 = (z3 + z4) * C1175;
   tmp0 *= C0298; tmp1 *= C2053; tmp2 *= C3072; tmp3 *= C1501;
-  z1 *= -C0899; z2 *= -C2562; z3 *= -C1961; z4 *= -C0390;
+  z1 = (ju32)0 - z1 * C0899; z2 = (ju32)0 - z2 * C2562; z3 = (ju32)0 - z3 * C1961; z4 = (ju32)0 - z4 * C0390;
   z3 += z5; z4 += z5;
   tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
   out[0] = jpeg_descale(tmp10 + tmp3, shift); out[7] = jpeg_descale(tmp10 - tmp3, shift);
@@ -431,7 +437,7 @@ JHD void jpeg_idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, i
   for (int c = 0; c < 8; ++c) {               // pass 1: columns, scaled up by 2^PASS1_BITS (2)
     int in[8], o[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) in[r] = (int)coef[r * 8 + c] * (int)q[r * 8 + c];
+    for (int r = 0; r < 8; ++r) in[r] = (int)((ju32)(int32_t)coef[r * 8 + c] * (ju32)q[r * 8 + c]);
     jpeg_idct_1d(in, o, 13 - 2, true);
 #pragma unroll
     for (int r = 0; r < 8; ++r) ws[r * 8 + c] = o[r];
@@ -443,7 +449,7 @@ JHD void jpeg_idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, i
     for (int c = 0; c < 8; ++c) in[c] = ws[r * 8 + c];
     jpeg_idct_1d(in, o, 13 + 2 + 3, false);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) out[r * ld + c] = jpeg_clamp255(o[c] + 128);
+    for (int c = 0; c < 8; ++c) out[r * ld + c] = jpeg_clamp255((int)((ju32)o[c] + 128u));
   }
 }
 

@@ -24,7 +24,7 @@ from .ops import _p, _stream, check
 INFO_WORDS = 48
 STATUS_TEXT = {0: "ok", 1: "not a JPEG", 2: "truncated header", 3: "progressive / arithmetic / lossless", 4: "not 8-bit",
                5: "not grey or YCbCr", 6: "sampling other than 4:4:4 / 4:2:2 / 4:2:0", 7: "multi-scan", 8: "table problem",
-               9: "chroma at most 2 samples wide", 11: "more than 2^26 pixels", 10: "entropy-coded data does not end at EOI (cut short / trailing data / damaged)"}
+               9: "chroma at most 2 samples wide", 11: "more than 2^24 pixels", 10: "entropy-coded data does not end at EOI (cut short / trailing data / damaged)"}
 
 
 class DecodedBatch:
@@ -88,45 +88,28 @@ class StagedFiles:
         return self.buf.numpy()[self.offsets[i]: self.offsets[i + 1]].tobytes()
 
 
-def stage_paths(paths, device="cuda", slot: int = 0, pool=None) -> StagedFiles:
-    """read files straight into the pinned staging buffer (no intermediate bytes objects, no concatenation pass): sizes first,
-    then ``readinto`` at each file's offset — both on ``pool`` (a ThreadPoolExecutor; file I/O releases the GIL)"""
+def stage_paths(paths, device="cuda", slot: int = 0, threads: int = 32) -> StagedFiles:
+    """read files straight into the pinned staging buffer (no bytes objects, no concatenation pass) with the library's native
+    reader threads (``drag_file_sizes`` / ``drag_read_files``): sizes first, then every file at its offset"""
     import os
+    lib = _lib.load()
     n = len(paths)
-
-    def size(p):
-        try:
-            return os.path.getsize(p)
-        except OSError as ex:
-            return ex
-    sizes = list(pool.map(size, paths)) if pool is not None else [size(p) for p in paths]
-    errors = {i: s for i, s in enumerate(sizes) if not isinstance(s, int)}
+    enc = [os.fsencode(p) for p in paths]
+    arr = (ctypes.c_char_p * n)(*enc)
+    sizes = np.empty(n, dtype=np.int64)
+    check(lib.drag_file_sizes(arr, n, sizes.ctypes.data, threads), "drag_file_sizes")
+    errors = {int(i): OSError(int(-sizes[i]), os.strerror(int(-sizes[i])), paths[i]) for i in np.nonzero(sizes < 0)[0]}
     offsets = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum([s if isinstance(s, int) else 0 for s in sizes], out=offsets[1:])
+    np.cumsum(np.maximum(sizes, 0), out=offsets[1:])
     total = int(offsets[-1])
     buf = _staging_buffer(device, total + PAD, slot)
     host = buf.numpy()
-
-    def fill(i):
-        if i in errors or offsets[i] == offsets[i + 1]:
-            return None
-        try:
-            with open(paths[i], "rb", buffering=0) as f:
-                view = memoryview(host)[offsets[i]: offsets[i + 1]]
-                got = 0
-                while got < len(view):
-                    k = f.readinto(view[got:])
-                    if not k:
-                        raise OSError(f"short read: {got} of {len(view)} bytes")
-                    got += k
-        except OSError as ex:
-            return ex
-        return None
-    res = list(pool.map(fill, range(n))) if pool is not None else [fill(i) for i in range(n)]
-    for i, r in enumerate(res):
-        if r is not None:
-            errors[i] = r
-            host[offsets[i]: offsets[i + 1]] = 0      # not a JPEG any more: the parse kernel reports it, nothing decodes it
+    status = np.zeros(n, dtype=np.int32)
+    check(lib.drag_read_files(arr, n, host.ctypes.data, offsets.ctypes.data, status.ctypes.data, threads), "drag_read_files")
+    for i in np.nonzero(status != 0)[0].tolist():
+        code = int(status[i])
+        errors[i] = OSError(code, os.strerror(code), paths[i]) if code > 0 else OSError(f"short read: {paths[i]}")
+        host[offsets[i]: offsets[i + 1]] = 0          # not a JPEG any more: the parse kernel reports it, nothing decodes it
     host[total: total + PAD] = 0
     return StagedFiles(buf, offsets, errors)
 

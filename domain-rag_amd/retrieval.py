@@ -421,9 +421,9 @@ def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch
         feats[ii] = emb
         ok[ii] = 1.0
 
-    with cf.ThreadPoolExecutor(max_workers=max(1, readers)) as pool, cf.ThreadPoolExecutor(max_workers=1) as stager:
+    with cf.ThreadPoolExecutor(max_workers=1) as stager:       # one Python thread drives the library's native reader threads
         def stage(ci):
-            return jpeg.stage_paths([clean_image_path(mine[j]) for j in chunks[ci]], dev, slot=ci & 1, pool=pool)
+            return jpeg.stage_paths([clean_image_path(mine[j]) for j in chunks[ci]], dev, slot=ci & 1, threads=readers)
         nxt = stager.submit(stage, 0) if chunks else None
         for ci, rows in enumerate(chunks):
             staged = nxt.result()

@@ -26,8 +26,9 @@ int drag_version(void);
 const char* drag_last_error(void);
 /* Measurement switches (A/B of kernel variants inside one process; every setting computes the same function):
  *   "attn_sched" 0 | 1 | 2 (schedule of the attention kernel's KV-tile loop), "attn_w4" 0 | 1 (128-query blocks at any
- *   length), "attn_tune" bit 0: static wave priority, bit 1: 16-byte epilogue stores.
- * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE.  Returns 0, or -1 for an unknown name. */
+ *   length), "attn_tune" bit 0: static wave priority, bit 1: 16-byte epilogue stores, "attn_q64" 0 | 1 (the 4-wave x 64-query
+ *   experiment kernel for S >= 1024).
+ * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 
 /* activation codes used by epilogues */
@@ -332,7 +333,7 @@ int drag_attention_small_f32(const float* qkv, float* out, int32_t B, int32_t T,
  *   drag_jpeg_parse: data = concatenated files, offsets int64 [n+1] (device); writes one descriptor per file (device).
  *     status 0 = decodable here; 1 not a JPEG, 2 truncated header, 3 progressive / arithmetic / lossless, 4 not 8-bit,
  *     5 not grey / YCbCr, 6 sampling other than 4:4:4 / 4:2:2 / 4:2:0, 7 multi-scan, 8 table problem, 9 chroma <= 2 samples
- *     wide, 11 more than 2^26 pixels.  Files with a non-zero status are skipped by drag_jpeg_decode_rgb (the caller decodes those few elsewhere).
+ *     wide, 11 more than 2^24 pixels.  Files with a non-zero status are skipped by drag_jpeg_decode_rgb (the caller decodes those few elsewhere).
  *   drag_jpeg_decode_rgb: plan int64 [n, 3] (device) = per file: offset into coef_ws (int16 elements), into plane_ws
  *     (bytes), into out_rgb (bytes); a file needs 64 * blocks int16 of coefficients and 64 * blocks bytes of planes where
  *     blocks = sum over components of (mcus_x * hs) * (mcus_y * vs), and width * height * 3 output bytes ([H, W, 3]).
@@ -358,6 +359,12 @@ int drag_jpeg_parse(const void* data, const int64_t* offsets, int32_t n, drag_jp
 int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jpeg_info* info, const int64_t* plan, int32_t n,
                          int64_t max_blocks, int64_t max_pixels, void* coef_ws, int64_t coef_bytes, void* plane_ws,
                          void* qtab_ws, void* out_rgb, int32_t* scan_status, void* stream);
+
+/* Host-side batch file reader feeding drag_jpeg_* (no device work): native threads do the per-file system calls that cost the
+ * interpreter ~80 us each.  drag_file_sizes: sizes[i] = bytes of paths[i] or -errno.  drag_read_files: paths[i] -> dst[offsets[i]
+ * .. offsets[i+1]) in plain host (ideally pinned) memory; status[i] = 0, errno, or -1 for a file shorter than its slot. */
+int drag_file_sizes(const char* const* paths, int64_t n, int64_t* sizes, int32_t threads);
+int drag_read_files(const char* const* paths, int64_t n, void* dst, const int64_t* offsets, int32_t* status, int32_t threads);
 
 #ifdef __cplusplus
 }

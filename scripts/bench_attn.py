@@ -10,8 +10,8 @@ def bench(fn, iters=10):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-VARIANTS = {"sched0": {"attn_sched": 0}, "sched1": {"attn_sched": 1}, "sched2": {"attn_sched": 2}, "sched2+prio": {"attn_sched": 2, "attn_tune": 1},
-            "sched2+wide": {"attn_sched": 2, "attn_tune": 2}, "sched2+both": {"attn_sched": 2, "attn_tune": 3}}
+VARIANTS = {"sched0": {"attn_sched": 0}, "sched2": {"attn_sched": 2}, "sched2+wide": {"attn_sched": 2, "attn_tune": 2},
+            "q64+wide": {"attn_q64": 1, "attn_tune": 2}}
 for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
     D = H * 128
     qkv = torch.randn(B, S, 3 * D, device=dev).bfloat16()
@@ -26,9 +26,9 @@ for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
     t = {k: [] for k in VARIANTS}
     for rep in range(6):
         for name, env in VARIANTS.items():
-            for k in ("attn_sched", "attn_w4", "attn_tune"): ops.set_option(k, 0)
+            for k in ("attn_sched", "attn_w4", "attn_tune", "attn_q64"): ops.set_option(k, 0)
             for k, v in env.items(): ops.set_option(k, v)
             if rep == 0: bench(run, 3)
             t[name].append(bench(run))
-    ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2)
+    ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2); ops.set_option("attn_q64", 0)
     print(f"attn B={B} S={S} H={H}: " + " | ".join(f"{k} {fl/statistics.median(v)/1e9:.0f} TF/s" for k, v in t.items()), flush=True)

@@ -19,8 +19,9 @@ python "$R/scripts/rocpd_stats.py" "$OUT/retr_results.db" > "$OUT/kernel_stats_b
 run rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT" -o fetch -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
 run rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT" -o write -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
 python "$R/scripts/rocpd_pmc.py" "$OUT/fetch_results.db" "$OUT/write_results.db" "$OUT/pmc_traffic.json" > "$OUT/pmc_passes_summary.txt" 2>&1
-run rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT" -o rfetch -- python "$R/bench.py" --workload retrieval --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_rfetch.log" 2>&1
-run rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT" -o rwrite -- python "$R/bench.py" --workload retrieval --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_rwrite.log" 2>&1
+# (rocprofv3 --pmc segfaults under the full retrieval bench's ~20 k dispatches; the scan / select kernels are the same in the small top-k script)
+run rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT" -o rfetch -- python "$R/scripts/bench_topk.py" > "$OUT/pmc_rfetch.log" 2>&1
+run rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT" -o rwrite -- python "$R/scripts/bench_topk.py" > "$OUT/pmc_rwrite.log" 2>&1
 python "$R/scripts/rocpd_pmc.py" "$OUT/rfetch_results.db" "$OUT/rwrite_results.db" "$OUT/pmc_traffic_retrieval.json" > "$OUT/pmc_passes_summary_retrieval.txt" 2>&1
 # the databases are tens of MB each and gpurun merges at most 64 MiB back: keep the summaries, drop the raw traces
 rm -f "$OUT"/*_results.db

@@ -92,3 +92,20 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* file, int64_t len, uint8_t* r
     }
   return 0;
 }
+
+// decode with the output allocated from the PARSED size (mutated headers change it); returns a checksum, or -status.
+// Used by the fuzz driver (tests/helpers/jpeg_fuzz.cpp, built with -fsanitize=address): whatever the bytes are, the shared
+// arithmetic must stay inside its buffers — on the GPU an out-of-bounds access is a memory fault, not an exception.
+extern "C" long long jpeg_host_decode_checked(const uint8_t* file, int64_t len, int64_t max_pixels) {
+  int32_t info[48];
+  const int st = jpeg_host_info(file, len, info);
+  if (st) return -st;
+  const int64_t px = (int64_t)info[1] * info[2];
+  if (px > max_pixels) return -100;
+  std::vector<uint8_t> rgb((size_t)px * 3);
+  const int rc = jpeg_host_decode_rgb(file, len, rgb.data());
+  if (rc) return -rc;
+  long long sum = 0;
+  for (size_t i = 0; i < rgb.size(); i += 97) sum += rgb[i];
+  return sum;
+}

@@ -105,3 +105,48 @@ def test_argument_errors(gpu):
         jpeg.decode_files([b"x"], "cpu")
     b = jpeg.decode_files([b"not a jpeg at all"], gpu)
     assert b.status.tolist() == [1] and b.image(0) is None and list(b.groups()) == []
+
+
+def test_damaged_files_never_fault_the_gpu(gpu):
+    """1 500 mutated files in one batch (byte flips, damaged headers, truncations, stray markers): every one gets a status, the
+    kernels stay inside their buffers (a fault would take the process down), and what is reported decodable has its header's
+    size.  The same mutations run under AddressSanitizer on the host build (tests/test_jpeg_core_host.py)."""
+    from domain_rag_amd import jpeg
+    rng = np.random.default_rng(11)
+    seeds = [encode(natural_image(rng, h, w), quality=int(rng.integers(20, 98)), subsampling=sub, **kw)
+             for (w, h) in ((64, 48), (33, 17), (120, 90)) for sub in (0, 1, 2) for kw in ({}, {"optimize": True}, {"restart_marker_blocks": 2})]
+    files = []
+    for i in range(1500):
+        f = bytearray(seeds[int(rng.integers(len(seeds)))])
+        kind = i % 5
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 9))):
+                f[int(rng.integers(len(f)))] = int(rng.integers(256))
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 7))):
+                f[int(rng.integers(min(len(f), 700)))] = int(rng.integers(256))
+        elif kind == 2:
+            f = f[: int(rng.integers(1, len(f)))]
+        elif kind == 3:
+            for _ in range(int(rng.integers(1, 7))):
+                p = len(f) // 2 + int(rng.integers(len(f) // 2))
+                f[p] = 0xFF
+                if p + 1 < len(f) and rng.integers(2):
+                    f[p + 1] = 0xC0 + int(rng.integers(0x40))
+        else:
+            a, n = int(rng.integers(len(f))), int(rng.integers(300))
+            f = f[:a] + f[a: a + n] + f[a:]
+        files.append(bytes(f))
+    batch = jpeg.decode_files(files, gpu)
+    torch.cuda.synchronize()
+    assert set(batch.status.tolist()) <= set(jpeg.STATUS_TEXT)
+    n_ok = 0
+    for i in range(len(files)):
+        img = batch.image(i)
+        if img is not None:
+            assert img.shape == (int(batch.height[i]), int(batch.width[i]), 3) and img.numel() <= 3 * (1 << 24)
+            n_ok += 1
+    assert 0 < n_ok < len(files)
+    # the device is still healthy and a clean file still decodes to PIL's bytes afterwards
+    good = jpeg.decode_files([seeds[0]], gpu)
+    assert np.array_equal(good.image(0).cpu().numpy(), pil_rgb(seeds[0]))

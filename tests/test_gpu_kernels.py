@@ -205,14 +205,17 @@ def test_attention_schedules_are_bit_identical(gpu):
     ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
     outs = {}
     try:
-        for sched, w4, tune in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 3), (1, 0, 2), (0, 1, 0), (1, 1, 0), (2, 1, 3)):
+        for sched, w4, tune, q64 in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 0, 3, 0), (1, 0, 2, 0), (0, 1, 0, 0), (1, 1, 0, 0),
+                                     (2, 1, 3, 0), (2, 0, 0, 1), (2, 0, 2, 1)):
             ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4); ops.set_option("attn_tune", tune)
+            ops.set_option("attn_q64", q64)
             o = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
             ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
-            outs[(sched, w4, tune)] = o.cpu()
+            outs[(sched, w4, tune, q64)] = o.cpu()
     finally:
         ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2)   # the library's defaults
-    ref = outs[(0, 0, 0)]
+        ops.set_option("attn_q64", 0)
+    ref = outs[(0, 0, 0, 0)]
     assert torch.isfinite(ref.float()).all()
     for key, o in outs.items():
         assert torch.equal(o, ref), key

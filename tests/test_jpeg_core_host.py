@@ -112,3 +112,29 @@ def test_truncated_scan_does_not_crash_and_keeps_the_decoded_part(host):
     assert host.jpeg_host_decode_rgb(cut, len(cut), out.ctypes.data) == 0
     full = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
     assert np.array_equal(out[:16], full[:16])          # the first MCU rows come from intact data
+
+
+def test_mutation_fuzz_under_address_sanitizer(tmp_path):
+    """whatever the bytes are, the decoder's shared arithmetic stays inside its buffers and away from undefined behaviour
+    (on the GPU an out-of-bounds access is a memory fault, not an exception): tests/helpers/jpeg_fuzz.cpp mutates valid files
+    (byte flips, header damage, truncation, stray markers, duplicated slices) under -fsanitize=address,undefined"""
+    exe = str(tmp_path / "jpeg_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-o", exe,
+                        os.path.join(ROOT, "tests", "helpers", "jpeg_fuzz.cpp")], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(7)
+    seeds = []
+    for k, (w, h) in enumerate([(64, 48), (33, 17), (120, 90)]):
+        for sub in (0, 1, 2):
+            for j, kw in enumerate(({}, {"optimize": True}, {"restart_marker_blocks": 2})):
+                p = tmp_path / f"s{k}{sub}{j}.jpg"
+                p.write_bytes(encode(natural_image(rng, h, w), quality=int(rng.integers(20, 98)), subsampling=sub, **kw))
+                seeds.append(str(p))
+        p = tmp_path / f"g{k}.jpg"
+        p.write_bytes(encode(natural_image(rng, h, w).convert("L"), quality=70))
+        seeds.append(str(p))
+    r = subprocess.run([exe, "6000"] + seeds, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert "iterations 6000" in r.stdout
