@@ -599,6 +599,14 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       }
     }
   }
+  // From here on the Q fragments exist ONLY in the AGPR half: the tied operand makes hipcc copy each fragment into an AGPR
+  // tuple once; a fragment that merely gets "a"-constrained at its uses stays in VGPRs and is re-copied before every use
+  // (64 v_accvgpr_write per KV tile and 64 VGPRs gone).
+  bf16x8_t qa[2][8];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("; q fragment -> AGPR" : "=a"(qa[qg][ks]) : "0"(qf[qg][ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16_t scur[2][2], snext[2][2];          // [query group][key half]
@@ -609,8 +617,8 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       const bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[ks] + t * (32 * 256)));
 #pragma unroll
       for (int qg = 0; qg < 2; ++qg) {
-        if (ks == 0) Q64_MFMA_S0(scur[qg][t], kf, qf[qg][ks]);
-        else Q64_MFMA_S(scur[qg][t], kf, qf[qg][ks]);
+        if (ks == 0) Q64_MFMA_S0(scur[qg][t], kf, qa[qg][ks]);
+        else Q64_MFMA_S(scur[qg][t], kf, qa[qg][ks]);
       }
     }
   Q64_SETTLE_S(scur);
@@ -674,8 +682,8 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
         if (g >= 4) vfg = *(const bf16x8_t*)(smem + (av[(g >> 2) - 1] + (VB + (g & 3) * (32 * 128))));
 #pragma unroll
         for (int qg = 0; qg < 2; ++qg) {
-          if ((g & 7) == 0) Q64_MFMA_S0(sn[qg][g >> 3], kcur, qf[qg][g & 7]);
-          else Q64_MFMA_S(sn[qg][g >> 3], kcur, qf[qg][g & 7]);
+          if ((g & 7) == 0) Q64_MFMA_S0(sn[qg][g >> 3], kcur, qa[qg][g & 7]);
+          else Q64_MFMA_S(sn[qg][g >> 3], kcur, qa[qg][g & 7]);
         }
         if (g < CPW) stage_k1(PAR, kv0 + 128, g);
         else if (g < 2 * CPW) stage_v1((PAR + 1) & 1, kv0 + 64, g - CPW);
