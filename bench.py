@@ -56,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--denoise-steps", type=int, default=30)
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the BASELINE configs[1] side measurement (N = 1 only)")
     ap.add_argument("--roofline-every", type=int, default=5, help="bracket the GEMMs of every n-th denoise step with events")
     ap.add_argument("--corpus", type=int, default=118287, help="retrieval: corpus images in total (BASELINE configs[4])")
     ap.add_argument("--queries", type=int, default=64, help="retrieval: queries in total (sharded over ranks)")
@@ -371,9 +372,44 @@ def run_generate(args, d: Dist):
                                                               for k, v in bk.items()}},
                      "e2e_mfma_frac": job.flops_per_image() * images / d.world / dt / (MFMA_BF16_PEAK_TF * 1e12)},
     }
+    if not args.no_side_configs and d.world == 1:
+        del job
+        torch.cuda.empty_cache()
+        out["side_configs"] = {"configs1": side_config1(d.dev)}
     if not args.no_cpu_baseline and d.world == 1:
         out["cpu_baseline"] = cpu_baseline_generate(args.res, args.denoise_steps)
     return out
+
+
+def side_config1(dev) -> dict:
+    """BASELINE configs[1] as a side field (a parity-test configuration, not the bench line): Flux-schnell shape (no guidance
+    embedding, 512 T5 tokens), 512x512, 4 denoise steps, batch 1, VAE decode included; outside the timed region."""
+    from domain_rag_amd import vae as vae_mod
+    from domain_rag_amd.engine import FluxTxt2ImgHIP, generator_noise, pack_noise
+    from domain_rag_amd.flux import FluxTransformerHIP
+    from domain_rag_amd.flux_params import FluxConfig, init_params
+    cfg = FluxConfig(in_channels=64, guidance_embeds=False)
+    tr = FluxTransformerHIP(cfg, init_params(cfg, seed=0, device=dev), dev)
+    vcfg = vae_mod.VaeConfig()
+    pipe = FluxTxt2ImgHIP(tr, vae_mod.FluxVaeHIP(vcfg, vae_mod.init_params(vcfg, seed=1, device=dev), dev))
+    g = torch.Generator(device=dev).manual_seed(2)
+    pe = torch.randn(1, 512, 4096, device=dev, generator=g).bfloat16()
+    pp = torch.randn(1, 768, device=dev, generator=g).bfloat16()
+    noise = pack_noise(generator_noise(0, 1, 512, 512, 1)[0])
+    run = lambda: pipe(pe, pp, height=512, width=512, guidance_scale=0.0, num_inference_steps=4, noise_tokens=noise)   # noqa: E731
+    run(); run()
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    S = 512 + 1024
+    flops = 4 * (57 * (2 * 12 * 3072 * 3072 * S + 2 * 2 * S * S * 3072)) + 2.6e12
+    return {"workload": "BASELINE configs[1]: Flux-schnell shape 512x512, 4 steps, batch=1 (latency case: 1536 joint rows)",
+            "value": 1.0 / dt, "unit": "images/s", "ms_per_image": dt * 1e3, "achieved_tflops": flops / dt / 1e12,
+            "mfma_frac": flops / dt / (MFMA_BF16_PEAK_TF * 1e12)}
 
 
 def synthetic_crops(lo: int, hi: int, device, chunk: int = 2048) -> torch.Tensor:

@@ -72,7 +72,8 @@ def test_full_size_attention_properties(gpu):
 
 def test_corpus_scale_topk_properties(gpu):
     """N = 118 287 x 512 (242 MB): planted neighbours come back first, scores descend, results equal the oracle on a
-    sampled query, and sharded all-gather order == single order (indices are global rows)."""
+    sampled query, the call is deterministic.  (Sharded all-gather order == single order at this size:
+    tests/test_gpu_fullsize2.py::test_sharded_gather_order_equals_single_order.)"""
     from domain_rag_amd import ops
     from oracle import retrieval as oret
     N = 118287
