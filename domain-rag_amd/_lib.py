@@ -93,6 +93,7 @@ SIGNATURES = {
     "drag_clip_embed_ln_f32": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_float, c_void_p]),
     "drag_attention_small_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     "drag_lama_blend_u8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "drag_cv_resize_linear_u8_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "drag_file_sizes": (c_int, [c_void_p, c_int64, c_void_p, c_int]),
     "drag_read_files": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int]),
     "drag_jpeg_parse": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

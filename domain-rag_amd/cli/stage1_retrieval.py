@@ -71,6 +71,8 @@ def style_cache_meta(stem) -> dict:
         backend = "cv2"
     except ImportError:
         backend = "cv2-restated"
+    if getattr(stem, "gpu_files", False):
+        backend = "cv2-restated"            # the device route and its host detour both use the restated tables
     return {"stem": tensor_fingerprint([stem.state[k] for k in sorted(stem.state)]), "resize": backend}
 
 
@@ -361,6 +363,7 @@ def main(argv=None):
     if not args.host_preprocess:
         preprocess = R.load_clip_device_preprocess(device)
     stem = R.StemStyle(torch.load(resnet_w, map_location="cpu") if resnet_w else None, device)
+    stem.gpu_files = args.decode == "gpu"
     feats, paths = {}, {}
     if args.dataset_source in ("coco", "both"):
         f, p = load_or_compute_features(args, "coco", args.coco_dir, None, args.pretrained_coco_features, args.pretrained_coco_paths,

@@ -207,3 +207,58 @@ extern "C" int drag_resample_u8(const drag_resample_args* a, void* stream) {
   }
   return 0;
 }
+
+// --------------------------------------------------------------------------------------------
+// cv2.resize(img, (OW, OH)) with INTER_LINEAR for a BATCH of differently sized RGB images -> float32 NCHW in [0, 1]:
+// the input of the ResNet-stem style vector (compute_resnet_features, retrieval/clip100_resnet_style_all_shots.py:186-196:
+// imread -> cvtColor -> resize(256, 256) -> /255).  The arithmetic is OpenCV's 8-bit linear path as restated in
+// retrieval.cv2_resize_linear_u8 (two taps per axis, 11-bit fixed-point weights, horizontal pass into int32, vertical pass
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2): the HOST builds the per-image tap / weight tables with that very numpy
+// code, this kernel only applies them, so the two agree bit for bit.  One thread per output pixel (3 channels).
+// --------------------------------------------------------------------------------------------
+namespace {
+struct CvResizeArgs {
+  const uint8_t* src;        // blob of RGB images [h, w, 3]
+  const long long* src_off;  // [n] byte offset of each image
+  const int* hw;             // [n, 2] (h, w)
+  const int* tab;            // [n, 7, OW|OH]: sx, sx1, a0, a1 (length OW) then y0, y1, b0|b1 packed ... see host
+  float* dst;                // [n, 3, OH, OW]
+  int n, OH, OW;
+};
+
+__global__ __launch_bounds__(256) void cv_resize_linear_kernel(CvResizeArgs p) {
+  const int i = blockIdx.y;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= p.OH * p.OW) return;
+  const int y = px / p.OW, x = px - y * p.OW;
+  const int w = p.hw[2 * i + 1];
+  const int L = p.OW > p.OH ? p.OW : p.OH;
+  const int* t = p.tab + (long long)i * 8 * L;
+  const int sx = t[x], sx1 = t[L + x], a0 = t[2 * L + x], a1 = t[3 * L + x];
+  const int y0 = t[4 * L + y], y1 = t[5 * L + y], b0 = t[6 * L + y], b1 = t[7 * L + y];
+  const uint8_t* s = p.src + p.src_off[i];
+  const uint8_t* r0 = s + (long long)y0 * w * 3;
+  const uint8_t* r1 = s + (long long)y1 * w * 3;
+  float* d = p.dst + (long long)i * 3 * p.OH * p.OW + px;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int S0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+    const int S1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+    int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : v > 255 ? 255 : v;
+    d[(long long)c * p.OH * p.OW] = (float)v / 255.0f;
+  }
+}
+}  // namespace
+
+extern "C" int drag_cv_resize_linear_u8_f32(const void* src, const int64_t* src_off, const int32_t* hw, const int32_t* tab, float* dst,
+                                            int32_t n, int32_t out_h, int32_t out_w, void* stream) {
+  DRAG_CHECK(src && src_off && hw && tab && dst, "drag_cv_resize_linear_u8_f32: null pointer");
+  DRAG_CHECK(n > 0 && n <= 65535 && out_h > 0 && out_w > 0, "drag_cv_resize_linear_u8_f32: bad shape");
+  CvResizeArgs p;
+  p.src = (const uint8_t*)src; p.src_off = (const long long*)src_off; p.hw = hw; p.tab = tab; p.dst = dst;
+  p.n = n; p.OH = out_h; p.OW = out_w;
+  hipLaunchKernelGGL(cv_resize_linear_kernel, dim3((out_h * out_w + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, p);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}

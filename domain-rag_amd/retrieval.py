@@ -73,16 +73,9 @@ def clip_preprocess_device(pil_image, device="cuda", size: int = 224) -> torch.T
     return resample.clip_preprocess_u8(raw, size)
 
 
-def cv2_resize_linear_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
-    """``cv2.resize(img, (out_w, out_h))`` (INTER_LINEAR) for uint8 HWC, restated from OpenCV's published algorithm
-    (imgproc/resize.cpp): half-pixel centres, two taps per axis, 11-bit fixed-point weights; horizontal pass into int32, vertical
-    pass ``((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2``.  PARITY UNPINNED: cv2 is not importable in the build container (and
-    opencv-python may route this call through IPP); what matters for the style statistics is that, like cv2 and unlike PIL's
-    BILINEAR, it does not low-pass when shrinking."""
-    h, w = img.shape[:2]
-    if (w, h) == (out_w, out_h):
-        return img.copy()
-
+def cv2_linear_tables(h: int, w: int, out_w: int, out_h: int):
+    """OpenCV's 8-bit INTER_LINEAR tap tables (imgproc/resize.cpp): half-pixel centres, two taps per axis, 11-bit fixed-point
+    weights.  Returns (sx, sx1, a0, a1) per output column and (y0, y1, b0, b1) per output row, int64 arrays."""
     def axis(n_in, n_out):
         f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
@@ -97,12 +90,25 @@ def cv2_resize_linear_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
     a1 = np.rint(fx * 2048.0).astype(np.int64)
     a0 = np.rint((1.0 - fx) * 2048.0).astype(np.int64)
     sx1 = np.minimum(sx + 1, w - 1)
-    src = img.astype(np.int64)
-    rows = src[:, sx] * a0[None, :, None] + src[:, sx1] * a1[None, :, None]            # [h, out_w, c] int
     sy, fy = axis(h, out_h)
     b1 = np.rint(fy * 2048.0).astype(np.int64)
     b0 = np.rint((1.0 - fy) * 2048.0).astype(np.int64)
     y0, y1 = np.clip(sy, 0, h - 1), np.clip(sy + 1, 0, h - 1)
+    return (sx, sx1, a0, a1), (y0, y1, b0, b1)
+
+
+def cv2_resize_linear_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """``cv2.resize(img, (out_w, out_h))`` (INTER_LINEAR) for uint8 HWC, restated from OpenCV's published algorithm
+    (imgproc/resize.cpp): horizontal pass into int32, vertical pass ``((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2``.
+    PARITY UNPINNED: cv2 is not importable in the build container (and opencv-python may route this call through IPP); what
+    matters for the style statistics is that, like cv2 and unlike PIL's BILINEAR, it does not low-pass when shrinking.
+    ``drag_cv_resize_linear_u8_f32`` applies the same tables on the GPU (``StemStyle.features_from_files``)."""
+    h, w = img.shape[:2]
+    if (w, h) == (out_w, out_h):
+        return img.copy()
+    (sx, sx1, a0, a1), (y0, y1, b0, b1) = cv2_linear_tables(h, w, out_w, out_h)
+    src = img.astype(np.int64)
+    rows = src[:, sx] * a0[None, :, None] + src[:, sx1] * a1[None, :, None]            # [h, out_w, c] int
     out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
     return np.clip(out, 0, 255).astype(np.uint8)
 
@@ -221,16 +227,66 @@ class StemStyle:
         self.w = self.state["conv1.weight"].contiguous().to(dev)
         self.scale, self.shift = scale.contiguous().to(dev), shift.contiguous().to(dev)
         self.device = dev
+        self.gpu_files = False      # set by stage 1 (--decode gpu): candidate files are decoded / resized on the device in batches
 
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
         """fp32 [B,3,H,W] in [0,1] -> fp32 [B,128] = cat(mean, std)   (ref :197-200)"""
         return ops.resnet_stem_style(img.to(self.device).float().contiguous(), self.w, self.scale, self.shift, 1e-5)
 
-    def features_from_path(self, image_path: str):
+    def features_from_files(self, image_paths: list, chunk: int = 2048) -> list:
+        """style vectors of many files with everything on the GPU: native file reads -> JPEG decode (``jpeg.decode_files``,
+        PIL's bytes) -> OpenCV-linear resize to 256x256 + /255 (``drag_cv_resize_linear_u8_f32``) -> stem.  Returns one float32
+        [128] vector (numpy) or None per path, in order.  Files the device decoder declines (PNG, progressive, damaged, EXIF-
+        rotated, ...) take ``features_from_path`` on the host with the SAME restated resize, so a cache never mixes algorithms."""
+        import ctypes
+        from . import _lib, jpeg
+        lib = _lib.load()
+        out: list = [None] * len(image_paths)
+        paths = [clean_image_path(p) for p in image_paths]
+        for c0 in range(0, len(paths), chunk):
+            sub = paths[c0: c0 + chunk]
+            staged = jpeg.stage_paths(sub, self.device, slot=2)
+            host = staged.buf.numpy()
+            rotated = set()
+            for k in range(len(sub)):          # cv2.imread applies the EXIF orientation: such files go the host way
+                o0, o1 = int(staged.offsets[k]), int(staged.offsets[k + 1])
+                if o1 > o0 and host[o0: min(o1, o0 + 65536)].tobytes().find(b"Exif\x00\x00") >= 0:
+                    rotated.add(k)
+            dec = jpeg.decode_files(staged, self.device)
+            idx = [k for k in range(len(sub)) if dec.status[k] == 0 and k not in rotated and k not in staged.errors]
+            if idx:
+                n = len(idx)
+                L = 256
+                tab = np.zeros((n, 8, L), dtype=np.int32)
+                hw = np.zeros((n, 2), dtype=np.int32)
+                off = np.zeros(n, dtype=np.int64)
+                base = dec._out.data_ptr()
+                for r, k in enumerate(idx):
+                    h, w = int(dec.height[k]), int(dec.width[k])
+                    (sx, sx1, a0, a1), (y0, y1, b0, b1) = cv2_linear_tables(h, w, L, L)
+                    tab[r] = np.stack([sx, sx1, a0, a1, y0, y1, b0, b1]).astype(np.int32)
+                    hw[r] = (h, w)
+                    off[r] = int(dec._off[k])
+                d_tab, d_hw, d_off = (torch.from_numpy(a).to(self.device) for a in (tab, hw, off))
+                x = torch.empty((n, 3, L, L), dtype=torch.float32, device=self.device)
+                ops.check(lib.drag_cv_resize_linear_u8_f32(ctypes.c_void_p(base), ops._p(d_off), ops._p(d_hw), ops._p(d_tab), ops._p(x),
+                                                           n, L, L, ops._stream()), "drag_cv_resize_linear_u8_f32")
+                vec = torch.cat([self(x[b: b + 256]) for b in range(0, n, 256)], 0).cpu().numpy()
+                for r, k in enumerate(idx):
+                    out[c0 + k] = vec[r]
+            done = set(idx)
+            for k in range(len(sub)):
+                if k not in done:
+                    out[c0 + k] = self.features_from_path(sub[k], restated_resize=True)
+        return out
+
+    def features_from_path(self, image_path: str, restated_resize: bool = False):
         """compute_resnet_features (ref :180-203): imread -> RGB -> resize 256x256 (bilinear) -> /255"""
         image_path = clean_image_path(image_path)
         try:
             try:
+                if restated_resize:
+                    raise ImportError("restated resize requested")
                 import cv2
                 img = cv2.imread(image_path)
                 if img is None:
@@ -287,16 +343,25 @@ def resnet_second_stage_rerank(query_image_path, first_stage_results, stem: Stem
     """ref :454-497 — L2 distance between style vectors, stable ascending sort, similarity = 1/(1+d), rank = i+1.
     Candidates whose image cannot be read are dropped; ``style_cache`` (path -> vector) avoids re-reading candidates."""
     query_image_path = clean_image_path(query_image_path)
-    qf = stem.features_from_path(query_image_path)
+    gpu_files = getattr(stem, "gpu_files", False)
+    qf = stem.features_from_path(query_image_path, restated_resize=True) if gpu_files else stem.features_from_path(query_image_path)
     if qf is None:
         print(f"警告：无法计算查询图像的ResNet特征: {query_image_path}")
         return first_stage_results
     rer = []
+    batch: dict = {}
+    if gpu_files:                                # the uncached candidates of this query in ONE device batch
+        need = [clean_image_path(r["image_path"]) for r in first_stage_results]
+        need = [p for p in dict.fromkeys(need) if style_cache is None or style_cache.get(p) is None]
+        if need:
+            batch = dict(zip(need, stem.features_from_files(need)))
+            if style_cache is not None:
+                style_cache.update({p: f for p, f in batch.items() if f is not None})
     for r in first_stage_results:
         path = clean_image_path(r["image_path"])
         f = style_cache.get(path) if style_cache is not None else None
         if f is None:
-            f = stem.features_from_path(path)
+            f = batch[path] if path in batch else stem.features_from_path(path)
             if style_cache is not None and f is not None:
                 style_cache[path] = f
         if f is not None:

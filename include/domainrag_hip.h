@@ -360,6 +360,14 @@ int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jp
                          int64_t max_blocks, int64_t max_pixels, void* coef_ws, int64_t coef_bytes, void* plane_ws,
                          void* qtab_ws, void* out_rgb, int32_t* scan_status, void* stream);
 
+/* cv2.resize(img, (out_w, out_h)) (INTER_LINEAR, 8-bit path) of n differently sized RGB images + /255 -> f32 [n, 3, out_h, out_w]:
+ * the input of the stem style vector (compute_resnet_features, retrieval/clip100_resnet_style_all_shots.py:186-196).  src: blob of
+ * [h, w, 3] uint8 images at byte offsets src_off[n]; hw int32 [n, 2]; tab int32 [n, 8, L], L = max(out_h, out_w): per image the
+ * rows sx, sx+1 (clamped), a0, a1 (per output column), y0, y1, b0, b1 (per output row) of OpenCV's fixed-point tap tables, built
+ * by the host (retrieval.cv2_linear_tables) so that host and device agree bit for bit. */
+int drag_cv_resize_linear_u8_f32(const void* src, const int64_t* src_off, const int32_t* hw, const int32_t* tab, float* dst,
+                                 int32_t n, int32_t out_h, int32_t out_w, void* stream);
+
 /* Host-side batch file reader feeding drag_jpeg_* (no device work): native threads do the per-file system calls that cost the
  * interpreter ~80 us each.  drag_file_sizes: sizes[i] = bytes of paths[i] or -errno.  drag_read_files: paths[i] -> dst[offsets[i]
  * .. offsets[i+1]) in plain host (ideally pinned) memory; status[i] = 0, errno, or -1 for a file shorter than its slot. */

@@ -120,3 +120,44 @@ def test_corpus_features_same_bits_through_decode_processes(gpu, tmp_path):
     e, ve = R.compute_corpus_features(model, host_pre, more, batch=5, decode_workers=2)
     assert vd == ve == [p for p in more if "bad" not in p] and d.shape == (26, 512)
     assert np.array_equal(d, e) and np.array_equal(d[:24], a)
+
+
+def test_style_vectors_of_files_on_the_gpu_equal_the_host_route(gpu, tmp_path):
+    """StemStyle.features_from_files (native reads -> GPU JPEG decode -> OpenCV-linear resize kernel -> stem) against
+    features_from_path with the same restated resize on the host (PIL decode -> numpy tables): same bits, per file; files the
+    device decoder declines (PNG, progressive) and unreadable ones behave like the host route; the re-rank built on either
+    route is the same list (compute_resnet_features / resnet_second_stage_rerank, retrieval/…:180-203,454-497)"""
+    import numpy as np
+    from PIL import Image
+    from domain_rag_amd import retrieval as R
+    rng = np.random.default_rng(9)
+    paths = []
+    for i, (h, w) in enumerate([(480, 640), (640, 480), (256, 256), (225, 300), (97, 61), (333, 777), (1000, 400), (64, 64)] * 2):
+        base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+        a = np.asarray(Image.fromarray(base).resize((w, h), Image.BICUBIC)).astype(np.int16) + rng.integers(-25, 25, (h, w, 3))
+        p = tmp_path / f"{i:03d}.jpg"
+        Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(p, quality=int(rng.integers(40, 97)), subsampling=int(rng.integers(0, 3)))
+        paths.append(str(p))
+    Image.open(paths[0]).save(tmp_path / "plain.png")
+    Image.open(paths[1]).save(tmp_path / "prog.jpg", quality=90, progressive=True)
+    paths += [str(tmp_path / "plain.png"), str(tmp_path / "prog.jpg"), str(tmp_path / "missing.jpg")]
+    stem = R.StemStyle(None, gpu, seed=3)
+    got = stem.features_from_files(paths)
+    want = [stem.features_from_path(p, restated_resize=True) for p in paths]
+    assert got[-1] is None and want[-1] is None
+    for g, w_, p in zip(got[:-1], want[:-1], paths):
+        assert g is not None and g.shape == (128,) and np.array_equal(g, w_), p
+    # the re-rank: device-batched candidates vs one file at a time
+    first = [{"similarity": 1.0 - 0.01 * i, "image_path": p, "source_dataset": "coco", "index": i} for i, p in enumerate(paths[1:12])]
+    stem.gpu_files = True
+    a = R.resnet_second_stage_rerank(paths[0], first, stem, style_cache={})
+    stem.gpu_files = False
+    stem_host = R.StemStyle(None, gpu, seed=3)
+    b = []
+    qf = stem_host.features_from_path(paths[0], restated_resize=True)
+    for r in first:
+        f = stem_host.features_from_path(r["image_path"], restated_resize=True)
+        b.append((float(np.linalg.norm(qf - f)), r["image_path"]))
+    b.sort(key=lambda t: t[0])
+    assert [r["image_path"] for r in a] == [p for _, p in b]
+    assert [r["similarity"] for r in a] == [float(1.0 / (1.0 + d)) for d, _ in b]
