@@ -33,7 +33,7 @@ ORACLE_THREADS = 64      # the oracle's convolutions / GEMMs scale badly past th
 def _tol(e_bf16_oracle, floor):
     """The reference computes in torch.bfloat16 (batch_generate_flux_kshot.py:49, outpainting_updown_sampling_redux.py:28), so
     its own arithmetic sits e_bf16_oracle away from the float32 truth (2e-2 for the VAE with random weights — measured,
-    scripts/explore_fullsize_errors.py).  Stated bar: HIP within max(floor, 2.5 x that distance) of float32."""
+    tests/tools/explore_fullsize_errors.py).  Stated bar: HIP within max(floor, 2.5 x that distance) of float32."""
     return max(floor, 2.5 * e_bf16_oracle)
 
 

@@ -1,6 +1,7 @@
-"""Prints the HIP-vs-oracle error levels and oracle timings at full size (sets the tolerances of tests/test_gpu_fullsize2.py)."""
+"""Prints the HIP-vs-oracle error levels and oracle timings at full size (sets the tolerances of tests/test_gpu_fullsize2.py).
+Test infrastructure (it runs the oracle), hence under tests/: python tests/tools/explore_fullsize_errors.py on the GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import __graft_entry__ as ge
 ge.build()
