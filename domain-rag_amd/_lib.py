@@ -19,6 +19,7 @@ class GemmArgs(ctypes.Structure):
         ("lda", c_int), ("a_rows_per_batch", c_int), ("a_batch_stride", c_int64),
         ("ldc", c_int), ("c_rows_per_batch", c_int), ("c_batch_stride", c_int64),
         ("ldg", c_int), ("act", c_int), ("act_n0", c_int), ("out_f32", c_int),
+        ("C2", c_void_p), ("ldc2", c_int), ("n_split", c_int),
     ]
 
 

@@ -68,7 +68,21 @@ struct GemmKArgs {
   unsigned a_bytes, w_bytes;
   int tiles_m, tiles_n;
   int wide;       // C / resid / gate rows are 16-B aligned and N % 8 == 0: staged epilogue
+  // optional second destination: output columns >= n_split go to C2 (dense rows of ld2 elements, column n -> C2[n - n_split]).
+  // Lets two Linears over the same input run as ONE launch into two buffers (Flux single blocks: to_q|k|v and proj_mlp).
+  void* C2;
+  int ld2, n_split;
 };
+
+// the arguments as the epilogue of the tile at column n0 sees them
+__device__ __forceinline__ GemmKArgs dest_of(const GemmKArgs& p, int n0) {
+  GemmKArgs q = p;
+  if (p.C2 != nullptr && n0 >= p.n_split) {
+    q.C = (void*)((bf16_t*)p.C2 - p.n_split);
+    q.cm.ld = p.ld2;
+  }
+  return q;
+}
 
 
 // per-column epilogue operands of one 4-wide column group, loaded once per tile column (not once per row)
@@ -421,8 +435,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
   }
 
   // ---- epilogue: lane holds C[m = .. + (l&15)][n = .. + (l>>4)*4 + 0..3] ----
-  if (p.wide) staged_epilogue<4, BM>(p, m0, m0 + wr * 64, n0, n0 + wc * 64, l, acc, smem + 4 * TILE_BYTES + w * 2048);
-  else wave_epilogue<4, BM>(p, m0, m0 + wr * 64 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
+  const GemmKArgs pd = dest_of(p, n0);
+  if (p.wide) staged_epilogue<4, BM>(pd, m0, m0 + wr * 64, n0, n0 + wc * 64, l, acc, smem + 4 * TILE_BYTES + w * 2048);
+  else wave_epilogue<4, BM>(pd, m0, m0 + wr * 64 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
 }
 
 
@@ -631,8 +646,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
     int tm, tn;
     pick_tile(p, vb, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
-    if (p.wide) staged_epilogue<8, 256>(p, m0, m0 + wr * 128, n0, n0 + wc * 64, l, acc, smem + 2 * T2_BUF + w * 2048);
-    else wave_epilogue<8, 256>(p, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
+    const GemmKArgs pd = dest_of(p, n0);
+    if (p.wide) staged_epilogue<8, 256>(pd, m0, m0 + wr * 128, n0, n0 + wc * 64, l, acc, smem + 2 * T2_BUF + w * 2048);
+    else wave_epilogue<8, 256>(pd, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
     if (!have_next) break;
     after_interior_epilogue = m0 + 256 <= p.M && n0 + 256 <= p.N;
     vb += P;
@@ -686,6 +702,7 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   k.cm.rpb = c_rpb > 0 ? c_rpb : M; k.cm.bs = c_bs; k.cm.ld = ldc;
   k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
   k.a_bytes = 0; k.w_bytes = 0;
+  k.C2 = nullptr; k.ld2 = 0; k.n_split = 0;
   static const bool narrow = env_flag("DRAG_GEMM_NARROW");
   k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&
            (!resid || ((uintptr_t)resid & 15) == 0) && (!gate || (((uintptr_t)gate & 15) == 0 && ldg % 8 == 0)) &&
@@ -716,6 +733,14 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   DRAG_CHECK(((long long)BM * a->lda + a->K) * 2 < (1ll << 30) && (long long)BN * a->K * 2 < (1ll << 31) &&
                  (k.am.rpb >= a->M || (k.am.bs - (long long)(k.am.rpb - 1) * k.am.ld) * 2 < (1ll << 30)),
              "drag_gemm_bf16: tile span too large for 32-bit offsets");
+  if (a->C2 != nullptr) {
+    DRAG_CHECK(a->n_split > 0 && a->n_split < a->N && a->n_split % 256 == 0, "drag_gemm_bf16: n_split must be a multiple of 256 inside (0, N)");
+    DRAG_CHECK(!a->out_f32 && !a->gate && !a->resid && a->c_rows_per_batch <= 0, "drag_gemm_bf16: the two-destination form takes dense bf16 outputs without gate / residual");
+    DRAG_CHECK(a->ldc2 >= a->N - a->n_split && a->ldc >= a->n_split, "drag_gemm_bf16: ldc / ldc2 too small for their column ranges");
+    k.C2 = a->C2; k.ld2 = a->ldc2; k.n_split = a->n_split;
+    k.wide = k.wide && a->ldc2 % 8 == 0 && ((uintptr_t)a->C2 & 15) == 0;
+    DRAG_CHECK(k.wide || a->ldc2 % 4 == 0, "drag_gemm_bf16: ldc2 % 4 required");
+  }
   if (use_t256(a->M, a->N, a->K)) {
     k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
     hipLaunchKernelGGL(gemm_bf16_t256<0>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);

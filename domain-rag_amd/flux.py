@@ -112,11 +112,13 @@ class FluxTransformerHIP:
         self.single = []
         for i in range(cfg.num_single_layers):
             p = f"single_transformer_blocks.{i}."
+            # to_q | to_k | to_v | proj_mlp stacked: ONE GEMM over the normalised rows writes q/k/v into the qkv buffer and the
+            # GELU'd MLP hidden into the [attn | mlp] buffer (two-destination epilogue): 54.8 tile rounds instead of 23.5 + 31.3,
+            # each rounded up (the last partial round of a persistent launch idles part of the chip)
             self.single.append(dict(
-                wqkv=cat([p + "attn.to_q.weight", p + "attn.to_k.weight", p + "attn.to_v.weight"]),
-                bqkv=cat([p + "attn.to_q.bias", p + "attn.to_k.bias", p + "attn.to_v.bias"]),
+                wqkvm=cat([p + "attn.to_q.weight", p + "attn.to_k.weight", p + "attn.to_v.weight", p + "proj_mlp.weight"]),
+                bqkvm=cat([p + "attn.to_q.bias", p + "attn.to_k.bias", p + "attn.to_v.bias", p + "proj_mlp.bias"]),
                 nq=g(p + "attn.norm_q.weight"), nk=g(p + "attn.norm_k.weight"),
-                wm=g(p + "proj_mlp.weight"), bm=g(p + "proj_mlp.bias"),
                 wo=g(p + "proj_out.weight"), bo=g(p + "proj_out.bias")))
         self._ws_key = None
         self._rope_key = None
@@ -268,8 +270,12 @@ class FluxTransformerHIP:
             mo = self.mod_off[("s", i)]      # shift, scale, gate
             ops.layernorm(x, nrm, M, D, scale=modv[mo + D:], shift=modv[mo:], ldx=D, ld_mod=LM, rows_per_batch=S,
                           x_batch_stride=S * D)
-            ops.gemm(nrm, blk["wqkv"], out=qkv, bias=blk["bqkv"], M=M, lda=D, ldc=3 * D)
-            ops.gemm(nrm, blk["wm"], out=cat_mlp, bias=blk["bm"], act=ops.ACT_GELU_TANH, M=M, lda=D, ldc=D + F)
+            if (3 * D) % 256 == 0:
+                ops.gemm(nrm, blk["wqkvm"], out=qkv, bias=blk["bqkvm"], act=ops.ACT_GELU_TANH, act_n0=3 * D, M=M, lda=D, ldc=3 * D,
+                         out2=cat_mlp, ldc2=D + F, n_split=3 * D)
+            else:       # (test-sized widths whose q|k|v block does not end on a tile boundary)
+                ops.gemm(nrm, blk["wqkvm"][: 3 * D], out=qkv, bias=blk["bqkvm"][: 3 * D], M=M, lda=D, ldc=3 * D)
+                ops.gemm(nrm, blk["wqkvm"][3 * D:], out=cat_mlp, bias=blk["bqkvm"][3 * D:], act=ops.ACT_GELU_TANH, M=M, lda=D, ldc=D + F)
             if _SEPARATE_QPREP:
                 ops.qk_norm_rope_vt(qkv, vt, blk["nq"], blk["nk"], blk["nq"], blk["nk"], cos, sin, B, S, H, 3 * D, 0)
                 ops.attention(qkv, qkv.view(-1)[D:], vt, catb, B, S, H, 3 * D, S * 3 * D, D + F, S * (D + F), scale)

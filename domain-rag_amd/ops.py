@@ -98,8 +98,10 @@ def _need(t: torch.Tensor, dtype, name: str):
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, bias=None, act: int = ACT_NONE,
          act_n0: int = 0, gate=None, resid=None, out_f32: bool = False, M: int | None = None,
          a_rows_per_batch: int = 0, a_batch_stride: int = 0, lda: int | None = None,
-         c_rows_per_batch: int = 0, c_batch_stride: int = 0, ldc: int | None = None, ldg: int = 0) -> torch.Tensor:
-    """out = epi(a @ w.T).  ``a`` / ``out`` may be views into larger buffers: pass the logical row
+         c_rows_per_batch: int = 0, c_batch_stride: int = 0, ldc: int | None = None, ldg: int = 0,
+         out2: torch.Tensor | None = None, ldc2: int = 0, n_split: int = 0) -> torch.Tensor:
+    """out = epi(a @ w.T) (``out2``: output columns >= ``n_split`` are written there instead, as dense rows of ``ldc2``
+    elements).  ``a`` / ``out`` may be views into larger buffers: pass the logical row
     count ``M`` and the batched-row addressing (rows_per_batch, batch_stride, ld) explicitly; by
     default ``a`` is a dense [M, K] matrix and ``out`` a dense [M, N] one."""
     lib = _lib.load()
@@ -129,6 +131,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, b
     args.lda, args.a_rows_per_batch, args.a_batch_stride = lda, a_rows_per_batch, a_batch_stride
     args.ldc, args.c_rows_per_batch, args.c_batch_stride = ldc, c_rows_per_batch, c_batch_stride
     args.ldg, args.act, args.act_n0, args.out_f32 = ldg, act, act_n0, int(out_f32)
+    if out2 is not None:        # columns >= n_split go to out2 (dense rows of ldc2 elements)
+        _need(out2, torch.bfloat16, "gemm.out2")
+        args.C2, args.ldc2, args.n_split = out2.data_ptr(), ldc2, n_split
     if _recorder is not None:
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_ev.record()

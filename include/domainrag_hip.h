@@ -66,6 +66,11 @@ typedef struct drag_gemm_args {
   int32_t ldg;
   int32_t act, act_n0;
   int32_t out_f32;
+  /* optional second destination (NULL = none): output columns >= n_split are written to C2 as dense rows of ldc2 elements
+   * (column n -> C2[m * ldc2 + n - n_split]); columns < n_split go to C as usual.  n_split % 256 == 0; bf16 outputs, dense rows,
+   * no gate / residual.  Two Linears over one input as ONE launch (Flux single block: to_q|k|v and proj_mlp + GELU via act_n0). */
+  void* C2;
+  int32_t ldc2, n_split;
 } drag_gemm_args;
 int drag_gemm_bf16(const drag_gemm_args* args, void* stream);
 

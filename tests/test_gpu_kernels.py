@@ -373,3 +373,29 @@ def test_gemm_staged_epilogue_equals_fragment_epilogue(gpu):
             return xd
         both(run)
         both(lambda: ops.gemm(aa.view(-1, Kk), ww, resid=x.to(gpu).view(-1, D)))
+
+
+@pytest.mark.parametrize("M", [300, 2500])
+def test_gemm_two_destinations_equals_two_gemms(gpu, M):
+    """one launch over stacked weights writing columns < n_split to one buffer and the rest (with the fused activation, via
+    act_n0) to another — the Flux single block's to_q|k|v + proj_mlp — must give exactly the bits of the two separate GEMMs,
+    leave both buffers' other columns alone, and reject what the form does not cover"""
+    from domain_rag_amd import ops
+    K, N1, N2 = 384, 512, 768
+    a = _randn((M, K), 21).to(gpu)
+    w = _randn((N1 + N2, K), 22, 0.05).to(gpu)
+    b = _randn((N1 + N2,), 23).to(gpu)
+    ld1, ld2 = N1 + 64, N2 + 256                          # both destinations are wider than what is written
+    ref1 = torch.full((M, ld1), 7.0, dtype=torch.bfloat16, device=gpu)
+    ref2 = torch.full((M, ld2), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(a, w[:N1], out=ref1, bias=b[:N1], M=M, lda=K, ldc=ld1)
+    ops.gemm(a, w[N1:], out=ref2.view(-1)[256:], bias=b[N1:], act=ops.ACT_GELU_TANH, M=M, lda=K, ldc=ld2)
+    o1 = torch.full((M, ld1), 7.0, dtype=torch.bfloat16, device=gpu)
+    o2 = torch.full((M, ld2), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(a, w, out=o1, bias=b, act=ops.ACT_GELU_TANH, act_n0=N1, M=M, lda=K, ldc=ld1, out2=o2.view(-1)[256:], ldc2=ld2, n_split=N1)
+    assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
+    assert (o1[:, N1:] == 7.0).all() and (o2[:, :256] == 7.0).all()
+    with pytest.raises(RuntimeError, match="n_split"):
+        ops.gemm(a, w, out=o1, bias=b, M=M, lda=K, ldc=ld1, out2=o2, ldc2=ld2, n_split=100)
+    with pytest.raises(RuntimeError, match="two-destination"):
+        ops.gemm(a, w, out=o1, bias=b, M=M, lda=K, ldc=ld1, out2=o2, ldc2=ld2, n_split=N1, resid=o1)
