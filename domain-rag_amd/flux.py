@@ -26,7 +26,8 @@ import os
 from . import ops
 from .flux_params import FluxConfig
 
-_SEPARATE_QPREP = os.environ.get("DRAG_QPREP_SEPARATE", "") not in ("", "0")     # measurement switch, read once
+_SEPARATE_QPREP = os.environ.get("DRAG_QPREP_SEPARATE", "") not in ("", "0")     # measurement switches, read once
+_SEPARATE_QKV_MLP = os.environ.get("DRAG_QKV_MLP_SEPARATE", "") not in ("", "0")
 
 
 def rope_tables(ids: torch.Tensor, axes_dims=(16, 56, 56), theta: float = 10000.0):
@@ -270,7 +271,7 @@ class FluxTransformerHIP:
             mo = self.mod_off[("s", i)]      # shift, scale, gate
             ops.layernorm(x, nrm, M, D, scale=modv[mo + D:], shift=modv[mo:], ldx=D, ld_mod=LM, rows_per_batch=S,
                           x_batch_stride=S * D)
-            if (3 * D) % 256 == 0:
+            if (3 * D) % 256 == 0 and not _SEPARATE_QKV_MLP:
                 ops.gemm(nrm, blk["wqkvm"], out=qkv, bias=blk["bqkvm"], act=ops.ACT_GELU_TANH, act_n0=3 * D, M=M, lda=D, ldc=3 * D,
                          out2=cat_mlp, ldc2=D + F, n_split=3 * D)
             else:       # (test-sized widths whose q|k|v block does not end on a tile boundary)
