@@ -27,7 +27,9 @@ from . import ops
 from .flux_params import FluxConfig
 
 _SEPARATE_QPREP = os.environ.get("DRAG_QPREP_SEPARATE", "") not in ("", "0")     # measurement switches, read once
-_SEPARATE_QKV_MLP = os.environ.get("DRAG_QKV_MLP_SEPARATE", "") not in ("", "0")
+# single blocks: to_q|k|v + proj_mlp as ONE two-destination launch (54.8 tile rounds instead of 24 + 32).  Measured same-box A/B,
+# two rounds: fused 0.4440 / 0.4435 vs separate 0.4468 / 0.4454 images/s -> the saved partial round does not pay; off by default.
+_FUSED_QKV_MLP = os.environ.get("DRAG_QKV_MLP_FUSED", "") not in ("", "0")
 
 
 def rope_tables(ids: torch.Tensor, axes_dims=(16, 56, 56), theta: float = 10000.0):
@@ -113,9 +115,8 @@ class FluxTransformerHIP:
         self.single = []
         for i in range(cfg.num_single_layers):
             p = f"single_transformer_blocks.{i}."
-            # to_q | to_k | to_v | proj_mlp stacked: ONE GEMM over the normalised rows writes q/k/v into the qkv buffer and the
-            # GELU'd MLP hidden into the [attn | mlp] buffer (two-destination epilogue): 54.8 tile rounds instead of 23.5 + 31.3,
-            # each rounded up (the last partial round of a persistent launch idles part of the chip)
+            # to_q | to_k | to_v | proj_mlp stacked in one weight: either two GEMMs over its row ranges (default) or ONE two-destination
+            # launch ($DRAG_QKV_MLP_FUSED=1: q/k/v into the qkv buffer, the GELU'd MLP hidden into the [attn | mlp] buffer)
             self.single.append(dict(
                 wqkvm=cat([p + "attn.to_q.weight", p + "attn.to_k.weight", p + "attn.to_v.weight", p + "proj_mlp.weight"]),
                 bqkvm=cat([p + "attn.to_q.bias", p + "attn.to_k.bias", p + "attn.to_v.bias", p + "proj_mlp.bias"]),
@@ -271,7 +272,7 @@ class FluxTransformerHIP:
             mo = self.mod_off[("s", i)]      # shift, scale, gate
             ops.layernorm(x, nrm, M, D, scale=modv[mo + D:], shift=modv[mo:], ldx=D, ld_mod=LM, rows_per_batch=S,
                           x_batch_stride=S * D)
-            if (3 * D) % 256 == 0 and not _SEPARATE_QKV_MLP:
+            if (3 * D) % 256 == 0 and _FUSED_QKV_MLP:
                 ops.gemm(nrm, blk["wqkvm"], out=qkv, bias=blk["bqkvm"], act=ops.ACT_GELU_TANH, act_n0=3 * D, M=M, lda=D, ldc=3 * D,
                          out2=cat_mlp, ldc2=D + F, n_split=3 * D)
             else:       # (test-sized widths whose q|k|v block does not end on a tile boundary)
