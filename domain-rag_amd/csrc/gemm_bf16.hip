@@ -175,7 +175,7 @@ __device__ __forceinline__ void epi_row(const GemmKArgs& p, long long coff, int 
 }
 
 // whole-wave epilogue: MI row groups x 4 column groups; rows m = mrow0 + 16*mi, columns nbase + 16*ni
-template <int MI, int TM>
+template <int MI, int TM, int TN = TM>
 __device__ __forceinline__ void wave_epilogue(const GemmKArgs& p, int m0, int mrow0, int n0, int nbase, f32x4_t (*acc)[4]) {
   const int b_first = m0 / p.cm.rpb;
   const bool gate_uniform = b_first == (min(m0 + TM, p.M) - 1) / p.cm.rpb;     // whole tile inside one batch
@@ -183,7 +183,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmKArgs& p, int m0, int mr
   ColOps co[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) load_colops(p, nbase + ni * 16, b_first, gate_uniform, co[ni]);
-  const bool interior = m0 + TM <= p.M && n0 + TM <= p.N;
+  const bool interior = m0 + TM <= p.M && n0 + TN <= p.N;
   if (interior) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -318,10 +318,10 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
   }
 }
 
-template <int MI, int TM>
+template <int MI, int TM, int TN = TM>
 __device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[4],
                                                 char* scr) {
-  if (m0 + TM <= p.M && n0 + TM <= p.N) staged_rows<MI, TM, false>(p, m0, mw0, n0, nw0, l, acc, scr);
+  if (m0 + TM <= p.M && n0 + TN <= p.N) staged_rows<MI, TM, false>(p, m0, mw0, n0, nw0, l, acc, scr);
   else staged_rows<MI, TM, true>(p, m0, mw0, n0, nw0, l, acc, scr);
 }
 
@@ -440,6 +440,116 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
   else wave_epilogue<4, BM>(pd, m0, m0 + wr * 64 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
 }
 
+
+// --------------------------------------------------------------------------------------------
+// gemm_bf16_deep — (32*MI) x 128 x 64 tile, 4 waves (2x2), wave tile (16*MI) x 64, ST-stage LDS-DMA ring with COUNTED waits.
+// For the launches that cannot fill the chip with 256x256 tiles (BASELINE configs[1]: 512 / 1024 / 1536 rows): there a
+// workgroup's K loop is a latency chain — the double-buffered t128 loop above exposes one L2/HBM round trip per K-step
+// (0.9 us per step measured at K = 12288 / 15360, 28 % of a CU's MFMA rate) — so the ring keeps ST-1 K-steps in flight per
+// workgroup and smaller M tiles put more workgroups on the chip.  Same MFMA, same k order per output element as the other
+// two kernels: bit-identical results, so the choice may depend on the launch's shape (batch invariance is kept).
+// Stage = A tile (32*MI rows) then W tile (128 rows), 128 B per row, same XOR swizzle as t128.  Per stage a wave issues
+// MI A chunks... (32*MI / 8 / 4) + 4 W chunks of 8 rows.  The epilogue slabs alias stage memory after the loop's last barrier.
+// --------------------------------------------------------------------------------------------
+template <int MI, int ST>
+__global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
+  constexpr int TBM = 32 * MI;
+  constexpr int A_BYTES = TBM * 128, W_BYTES = 128 * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int CA = TBM / 32;                 // A chunks (8 rows, 1 KiB) per wave per stage
+  constexpr int CH = CA + 4;                   // DMA instructions per wave per stage
+  static_assert(ST >= 2 && ST <= 4 && ST * STAGE >= 4 * 2048, "ring depth");
+  __shared__ __attribute__((aligned(16))) char smem[ST * STAGE];
+  const int w = wave_id();
+  const int l = lane_id();
+  const int wr = w >> 1, wc = w & 1;
+  int tm, tn;
+  pick_tile(p, (int)blockIdx.x, tm, tn);
+  const int m0 = tm * TBM, n0 = tn * 128;
+
+  const long long a0 = p.am.off(m0);
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a0), 0, 0x7ffffff0u, 0x00020000);
+  const int wrows = min(128, p.N - n0);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0,
+                                                                 (unsigned)((long long)wrows * p.K * 2), 0x00020000);
+  unsigned voffA[4], voffW[4];      // (voffA[CA]: an array of dependent bound captured by the lambda below loses the host stub in hipcc 7.2)
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int row = (w * CA + i) * 8 + (l >> 3);
+    const int slot = (l & 7) ^ ((row >> 1) & 7);
+    const int ra = min(m0 + row, p.M - 1);                 // clamp: rows past the edge are never stored
+    voffA[i] = (unsigned)((p.am.off(ra) - a0 + slot * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (w * 4 + i) * 8 + (l >> 3);
+    const int slot = (l & 7) ^ ((row >> 1) & 7);
+    const int rw = min(row, wrows - 1);
+    voffW[i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
+  }
+  auto stage = [&](int buf, int kt) {
+    const int soff = kt * (BK * 2);
+    DRAG_LDS char* d = (DRAG_LDS char*)smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < CA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + (w * CA + i) * 1024), 16, voffA[i], soff, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + A_BYTES + (w * 4 + i) * 1024), 16, voffW[i], soff, 0, 0);
+  };
+
+  const int p0 = (l >> 4) ^ ((l & 15) >> 1);
+  const int fa = (wr * (TBM / 2) + (l & 15)) * 128;            // + mi*2048
+  const int fb = A_BYTES + (wc * 64 + (l & 15)) * 128;         // + ni*2048
+
+  f32x4_t acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int s2 = 0; s2 < ST - 1; ++s2)
+    if (s2 < nk) stage(s2, s2);
+  int buf = 0, nbuf = ST - 1;                    // buffer of K-step kt / of K-step kt + ST - 1
+  for (int kt = 0; kt < nk; ++kt) {
+    // K-step kt landed; K-steps kt+1 .. min(kt+ST-2, nk-1) may stay in flight
+    const int younger = min(ST - 2, nk - 1 - kt);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... for every wave; and every wave is done reading buffer nbuf (K-step kt-1: its ds_reads were consumed by MFMAs).
+    // A bare s_barrier: __syncthreads() carries a release fence, i.e. s_waitcnt vmcnt(0), which would drain the ring.
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + ST - 1 < nk) stage(nbuf, kt + ST - 1);
+    const char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ((p0 ^ (ks * 4)) << 4);
+      bf16x8_t xa[MI], wb[4];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xa[i] = *(const bf16x8_t*)(sb + fa + i * 2048 + so);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wb[i] = *(const bf16x8_t*)(sb + fb + i * 2048 + so);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ni], xa[mi], acc[mi][ni], 0, 0, 0);
+    }
+    buf = buf + 1 == ST ? 0 : buf + 1;
+    nbuf = nbuf + 1 == ST ? 0 : nbuf + 1;
+  }
+  const GemmKArgs pd = dest_of(p, n0);
+  if (p.wide) {
+    __syncthreads();                              // the slabs alias the ring
+    staged_epilogue<MI, TBM, 128>(pd, m0, m0 + wr * (TBM / 2), n0, n0 + wc * 64, l, acc, smem + w * 2048);
+  } else {
+    wave_epilogue<MI, TBM, 128>(pd, m0, m0 + wr * (TBM / 2) + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
+  }
+}
 
 // --------------------------------------------------------------------------------------------
 // gemm_bf16_t256 — 256x256x64 tile, 8 waves (2 along M x 4 along N), wave tile 128x64 as 8x4
@@ -678,6 +788,20 @@ static bool use_t256(long long M, int N, int K) {
   return tiles * 10 >= rounds * 256 * 7;              // last-round efficiency >= 0.7
 }
 
+// which gemm_bf16_deep<MI, ST> (10*MI + ST) a launch the 256x256 kernel does not take should use; 0 = the t128 kernel
+// Measured (scripts/bench_gemm_small_m.py, TFLOP/s, t128 -> pick): (512, 3072, 3072) 267 -> 416, (512, 3072, 12288) 310 -> 504,
+// (1024, 3072, 3072) 525 -> 625, (1024, 3072, 12288) 608 -> 715; with more than 256 128x128 tiles t128's two workgroups per CU win.
+// (8, 18432, 3072) — the AdaLN modulation Linears at batch 8, an HBM stream of the weight — 27 -> 46 (5.7 TB/s), (64, 3072, 3072) 38 -> 68.
+static int deep_policy(long long M, int N, int K) {
+  (void)K;
+  const long long tn = (N + 127) / 128;
+  if (M <= 32 || ((M + 63) / 64) * tn < 64) return 14;     // 32-row tiles: no MFMA work on rows that do not exist, more workgroups
+  const long long tiles128 = ((M + 127) / 128) * tn;
+  if (tiles128 <= 128) return 24;        // <= 256 workgroups of 64 x 128: one per CU, 4-stage ring (96 KiB)
+  if (tiles128 <= 256) return 23;        // <= 512 workgroups: two per CU, 3-stage ring (72 KiB each)
+  return 0;
+}
+
 // persistent grid of the 256x256 kernel: one workgroup per CU (128 KiB of LDS each), fewer when there are fewer tiles
 static int t256_grid(int ntiles) {
   static int ncu = 0;
@@ -741,9 +865,28 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
     k.wide = k.wide && a->ldc2 % 8 == 0 && ((uintptr_t)a->C2 & 15) == 0;
     DRAG_CHECK(k.wide || a->ldc2 % 4 == 0, "drag_gemm_bf16: ldc2 % 4 required");
   }
-  if (use_t256(a->M, a->N, a->K)) {
+  // "gemm_kernel" (drag_set_option, measurement only): 0 = policy, 1 = t128, 2 = t256, 10*MI + ST = gemm_bf16_deep<MI, ST>
+  const int force = drag_opt(DRAG_OPT_GEMM_KERNEL);
+  int deep = force >= 10 ? force : 0;
+  const bool t256 = force == 2 ? (a->N >= 256 && a->K >= 256) : (force == 0 && use_t256(a->M, a->N, a->K));
+  if (force == 0 && !t256) deep = deep_policy(a->M, a->N, a->K);
+  if (t256) {
     k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
     hipLaunchKernelGGL(gemm_bf16_t256<0>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
+  } else if (deep) {
+    const int mi = deep / 10, st = deep % 10;
+    DRAG_CHECK((mi == 1 || mi == 2 || mi == 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2 or 10*{1,2,4} + {2,3,4}");
+    k.tiles_m = (a->M + 32 * mi - 1) / (32 * mi); k.tiles_n = (a->N + 127) / 128;
+    const dim3 g(k.tiles_m * k.tiles_n);
+    const hipStream_t st_ = (hipStream_t)stream;
+#define DRAG_DEEP(MI_, ST_) case 10 * MI_ + ST_: hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_>), g, dim3(256), 0, st_, k); break
+    switch (deep) {
+      DRAG_DEEP(4, 2); DRAG_DEEP(4, 3);
+      DRAG_DEEP(2, 2); DRAG_DEEP(2, 3); DRAG_DEEP(2, 4);
+      DRAG_DEEP(1, 3); DRAG_DEEP(1, 4);
+      default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel names a gemm_bf16_deep<MI, ST> that is not built (42 43 22 23 24 13 14)");
+    }
+#undef DRAG_DEEP
   } else {
     hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
   }

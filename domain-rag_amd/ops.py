@@ -37,7 +37,7 @@ class GemmRecorder:
 
     @staticmethod
     def kernel_of(shape, conv=False):
-        """the dispatch rule of drag_gemm_bf16 / drag_conv3x3_bf16 (csrc/gemm_bf16.hip: use_t256)"""
+        """the dispatch rule of drag_gemm_bf16 / drag_conv3x3_bf16 (csrc/gemm_bf16.hip: use_t256, deep_policy)"""
         if conv == "f32":
             return "conv2d_f32_kernel"
         M, N, K = shape
@@ -46,7 +46,18 @@ class GemmRecorder:
             tiles = ((M + 255) // 256) * ((N + 255) // 256)
             rounds = (tiles + 255) // 256
             big = M >= 2048 or (M >= 1024 and tiles >= 128 and (tiles <= 256 or tiles * 10 >= rounds * 256 * 7))
-        return ("gemm_bf16_t256" if big else "gemm_bf16_t128") + ("<1>" if conv else "<0>")
+        if big:
+            return "gemm_bf16_t256" + ("<1>" if conv else "<0>")
+        if not conv:                                         # deep_policy
+            tn = (N + 127) // 128
+            if M <= 32 or ((M + 63) // 64) * tn < 64:
+                return "gemm_bf16_deep<1, 4>"
+            tiles128 = ((M + 127) // 128) * tn
+            if tiles128 <= 128:
+                return "gemm_bf16_deep<2, 4>"
+            if tiles128 <= 256:
+                return "gemm_bf16_deep<2, 3>"
+        return "gemm_bf16_t128" + ("<1>" if conv else "<0>")
 
     def by_kernel(self):
         """{kernel name: (launches, total_ms, flops)}"""

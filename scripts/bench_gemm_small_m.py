@@ -1,4 +1,6 @@
-"""tile policy at small M (BASELINE configs[1]: 1536 joint rows): 128x128 kernel vs the 256x256 one"""
+"""GEMM kernels at small M (BASELINE configs[1]: 512 text / 1024 image / 1536 joint rows): t128 (double-buffered 128x128), t256
+(persistent 256x256), gemm_bf16_deep<MI, ST> ((32 MI) x 128 tiles, ST-stage ring; option value 10 MI + ST), the policy's pick
+(option 0) and torch.matmul (hipBLASLt) as the yardstick.  Every variant must produce the same bits as t128."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,18 +12,30 @@ def bench(fn, iters=20):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-for M in (1024, 1536, 1753):
-    for (N, K) in [(3072, 3072), (9216, 3072), (12288, 3072), (21504, 3072), (3072, 12288), (3072, 15360)]:
-        A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
-        C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        t = {"t128": [], "t256": []}
-        for rep in range(5):
-            os.environ["DRAG_GEMM_T128"] = "1"; os.environ.pop("DRAG_GEMM_T256_MIN_M", None)
-            if rep == 0: bench(lambda: ops.gemm(A, W, out=C), 3)
-            t["t128"].append(bench(lambda: ops.gemm(A, W, out=C)))
-            os.environ.pop("DRAG_GEMM_T128"); os.environ["DRAG_GEMM_T256_MIN_M"] = "1"
-            if rep == 0: bench(lambda: ops.gemm(A, W, out=C), 3)
-            t["t256"].append(bench(lambda: ops.gemm(A, W, out=C)))
-        os.environ.pop("DRAG_GEMM_T256_MIN_M", None)
-        fl = 2 * M * N * K / 1e9
-        print(f"M={M} N={N} K={K} tiles256={((M+255)//256)*((N+255)//256)}: " + " | ".join(f"{k} {fl/statistics.median(v):.0f} TF/s" for k, v in t.items()), flush=True)
+VARIANTS = [("t128", 1), ("t256", 2)] + [(f"d{c}", c) for c in (42, 43, 22, 23, 24, 13, 14)] + [("policy", 0)]
+SHAPES = [(8, 18432, 3072), (8, 9216, 3072), (8, 3072, 256), (64, 3072, 3072), (729, 4096, 1152), (1458, 4304, 1152), (1458, 1152, 4352),
+          (512, 3072, 3072), (512, 9216, 3072), (512, 12288, 3072), (512, 3072, 12288),
+          (1024, 3072, 3072), (1024, 9216, 3072), (1024, 12288, 3072), (1024, 3072, 12288),
+          (1536, 9216, 3072), (1536, 12288, 3072), (1536, 21504, 3072), (1536, 3072, 15360)]
+if os.environ.get("SHAPES"):
+    SHAPES = [tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(",")]
+for (M, N, K) in SHAPES:
+    A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    bias = torch.randn(N, device=dev).bfloat16()
+    t = {k: [] for k, _ in VARIANTS}; t["hipblaslt"] = []
+    outs = {}
+    for rep in range(5):
+        for name, code in VARIANTS:
+            ops.set_option("gemm_kernel", code)
+            C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            run = lambda: ops.gemm(A, W, out=C, bias=bias)
+            if rep == 0:
+                bench(run, 3); outs[name] = C.clone()
+            t[name].append(bench(run))
+        if rep == 0: bench(lambda: torch.matmul(A, W.t()), 3)
+        t["hipblaslt"].append(bench(lambda: torch.matmul(A, W.t())))
+    ops.set_option("gemm_kernel", 0)
+    same = all(torch.equal(outs["t128"], o) for o in outs.values())
+    fl = 2 * M * N * K / 1e9
+    best = min((statistics.median(v), k) for k, v in t.items() if k not in ("hipblaslt", "policy"))
+    print(f"M={M} N={N} K={K} bits_equal={same} best={best[1]}: " + " | ".join(f"{k} {fl/statistics.median(v):.0f}" for k, v in t.items()) + " TF/s", flush=True)

@@ -375,6 +375,44 @@ def test_gemm_staged_epilogue_equals_fragment_epilogue(gpu):
         both(lambda: ops.gemm(aa.view(-1, Kk), ww, resid=x.to(gpu).view(-1, D)))
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 3072, 1024), (1000, 1536, 512), (8, 4608, 256), (77, 136, 192), (1536, 768, 2048), (130, 128, 64)])
+def test_gemm_kernels_are_bit_identical(gpu, M, N, K):
+    """every GEMM kernel (t128, t256, gemm_bf16_deep<MI, ST>) runs the same MFMA in the same k order per output element, so
+    the tile policy may depend on the launch's shape without changing a bit: plain, activation, gate + residual in batched
+    rows, f32 output and the narrow (fragment) epilogue"""
+    from domain_rag_amd import ops
+    a, w, b = _randn((M, K), 1).to(gpu), _randn((N, K), 2, 0.05).to(gpu), _randn((N,), 3).to(gpu)
+    rpb = M // 2 if M % 2 == 0 else M
+    nb = M // rpb
+    gate, resid = _randn((nb, N), 4).to(gpu), _randn((M, N), 5).to(gpu)
+
+    def run_all():
+        outs = [ops.gemm(a, w, bias=b), ops.gemm(a, w, bias=b, act=ops.ACT_GELU_TANH, act_n0=(N // 2) // 4 * 4),
+                ops.gemm(a, w, out_f32=True)]
+        x = resid.clone()
+        ops.gemm(a, w, out=x, bias=b, M=M, lda=K, ldc=N, c_rows_per_batch=rpb, c_batch_stride=rpb * N, gate=gate, resid=x, ldg=N)
+        outs.append(x)
+        y = torch.zeros((M, N + 4), dtype=torch.bfloat16, device=gpu)        # ldc % 8 != 0: fragment epilogue
+        ops.gemm(a, w, out=y, bias=b, M=M, lda=K, ldc=N + 4)
+        outs.append(y)
+        return [o.cpu() for o in outs]
+
+    codes = [1, 42, 43, 22, 23, 24, 13, 14, 0] + ([2] if N >= 256 and K >= 256 else [])
+    try:
+        res = {}
+        for code in codes:
+            ops.set_option("gemm_kernel", code)
+            res[code] = run_all()
+        ops.set_option("gemm_kernel", 44)
+        with pytest.raises(RuntimeError, match="not built"):
+            ops.gemm(a, w)
+    finally:
+        ops.set_option("gemm_kernel", 0)
+    for code in codes[1:]:
+        for i, (x, y) in enumerate(zip(res[1], res[code])):
+            assert torch.equal(x, y), (code, i)
+
+
 @pytest.mark.parametrize("M", [300, 2500])
 def test_gemm_two_destinations_equals_two_gemms(gpu, M):
     """one launch over stacked weights writing columns < n_split to one buffer and the rest (with the fused activation, via
