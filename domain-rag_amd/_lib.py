@@ -99,6 +99,8 @@ SIGNATURES = {
     "drag_read_files": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int]),
     "drag_jpeg_parse": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "drag_jpeg_decode_rgb": (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int64, c_void_p, c_int64] + [c_void_p] * 5),
+    "drag_png_plan": (c_int, [c_int] * 4 + [c_void_p, c_void_p]),
+    "drag_png_encode": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 _lib = None

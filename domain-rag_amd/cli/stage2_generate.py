@@ -45,6 +45,9 @@ def build_parser():
     p.add_argument("--num_inference_steps", type=int, default=STEPS)
     p.add_argument("--size", type=int, default=SIZE)
     p.add_argument("--io_workers", type=int, default=4, help="background PNG encoder processes (0 = write inline like the reference)")
+    p.add_argument("--png", choices=["gpu", "host"], default="gpu",
+                   help="generated_image_rank{r}.png: 'gpu' = encoded on the device (domain_rag_amd.png: same pixels, not Pillow's bytes), "
+                        "'host' = Pillow (zlib level 6) in the --io_workers processes")
     p.add_argument("--ref_batch", type=int, default=8, help="references of one target generated per batch (1 = one at a time like the reference)")
     p.add_argument("--fallback-seed", type=int, default=None, help="seed the random-COCO fallback (reference: unseeded)")
     return p
@@ -82,8 +85,13 @@ def generate_ranked(engine: Engine, target_path, items, sdir, args, database):
         try:
             pe, pp = torch.cat([c[3][0] for c in chunk], 0), torch.cat([c[3][1] for c in chunk], 0)
             noise = pack_noise(generator_noise(SEED, 1, args.size, args.size, 1)[0]).expand(len(chunk), -1, -1).contiguous()   # seed 0 every time (:468)
-            imgs = engine.pipe(pe, pp, height=args.size, width=args.size, guidance_scale=GUIDANCE,
-                               num_inference_steps=args.num_inference_steps, noise_tokens=noise).cpu().numpy()
+            imgs_dev = engine.pipe(pe, pp, height=args.size, width=args.size, guidance_scale=GUIDANCE,
+                                   num_inference_steps=args.num_inference_steps, noise_tokens=noise)
+            if getattr(args, "png", "host") == "gpu":       # whole .png files come back instead of raw pixels
+                from .. import png as gpu_png
+                imgs = gpu_png.encode(imgs_dev)
+            else:
+                imgs = imgs_dev.cpu().numpy()
         except Exception as e:
             print(f"生成图像时出错: {str(e)}")
             bad += len(chunk)
@@ -93,7 +101,10 @@ def generate_ranked(engine: Engine, target_path, items, sdir, args, database):
             try:
                 img_path = os.path.join(sdir, f"generated_image_rank{rank}.png")
                 writer = getattr(args, "writer", None)
-                if writer is None:
+                if isinstance(arr, bytes):
+                    with open(img_path, "wb") as f:
+                        f.write(arr)
+                elif writer is None:
                     Image.fromarray(arr).save(img_path)
                 else:
                     writer.save(Image.fromarray(arr), img_path)          # PNG encode off the generation thread

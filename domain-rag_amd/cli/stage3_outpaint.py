@@ -57,6 +57,9 @@ def build_parser():
     p.add_argument("--tiny", action="store_true", help="test hook: tiny architectures, min_dimension 64")
     p.add_argument("--num_inference_steps", type=int, default=H.NUM_INFERENCE_STEPS)
     p.add_argument("--io_workers", type=int, default=4, help="background PNG encoder processes (0 = write inline like the reference)")
+    p.add_argument("--png", choices=["gpu", "host"], default="gpu",
+                   help="*_hires_result_* / *_final_result_*: 'gpu' = encoded on the device (domain_rag_amd.png: same pixels, not "
+                        "Pillow's bytes), 'host' = Pillow (zlib level 6) in the --io_workers processes; masks and copies stay with Pillow")
     p.add_argument("--bg_batch", type=int, default=8, help="backgrounds of one sample composited per batch (1 = one at a time like the reference)")
     return p
 
@@ -181,18 +184,33 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
             enc_n = torch.cat([d[0] for d in draws], 0)
             noise = torch.cat([pack_noise(d[1]) for d in draws], 0)
             menc_n = torch.cat([d[2] for d in draws], 0)
-            outs = engine.pipe(img_u8.expand(n, -1, -1, -1).contiguous(), msk_u8.expand(n, -1, -1).contiguous(), pe, pp,
-                               guidance_scale=guidance, num_inference_steps=args.num_inference_steps, strength=strength,
-                               enc_noise=enc_n.to(engine.dev), masked_enc_noise=menc_n.to(engine.dev),
-                               noise_tokens=noise.to(engine.dev)).cpu().numpy()
-            for jb, arr in zip(chunk, outs):
+            outs_dev = engine.pipe(img_u8.expand(n, -1, -1, -1).contiguous(), msk_u8.expand(n, -1, -1).contiguous(), pe, pp,
+                                   guidance_scale=guidance, num_inference_steps=args.num_inference_steps, strength=strength,
+                                   enc_noise=enc_n.to(engine.dev), masked_enc_noise=menc_n.to(engine.dev),
+                                   noise_tokens=noise.to(engine.dev))
+            gpu_png = None
+            if getattr(args, "png", "host") == "gpu":
+                from .. import png as gpu_png
+                hires_files = gpu_png.encode(outs_dev)
+            outs = outs_dev.cpu().numpy()
+            for k_out, (jb, arr) in enumerate(zip(chunk, outs)):
                 bg_idx, bg_path, name, suffix, mask_path, bg_saved, seed = (jb[k] for k in ("bg_idx", "bg_path", "name", "suffix", "mask_path", "bg_saved", "seed"))
                 result = Image.fromarray(arr)
                 hires_path = os.path.join(out_dir, f"{prefix}_hires_result{suffix}.png")
-                save(result, hires_path)
                 final = H.downscale_image(result, up) if wu else (H.upscale_image(result, 1.0 / down) if wd else result)
                 final_path = os.path.join(out_dir, f"{prefix}_final_result{suffix}.png")
-                save(final, final_path)
+                if gpu_png is not None:
+                    with open(hires_path, "wb") as f:
+                        f.write(hires_files[k_out])
+                    if final is result:
+                        final_file = hires_files[k_out]
+                    else:                     # the resize back to the original resolution is the host's (PIL); its pixels go up once
+                        final_file = gpu_png.encode(torch.from_numpy(np.ascontiguousarray(np.asarray(final.convert("RGB")))).to(engine.dev))[0]
+                    with open(final_path, "wb") as f:
+                        f.write(final_file)
+                else:
+                    save(result, hires_path)
+                    save(final, final_path)
                 params = {"categories": cats, "image_scale": 1.0, "prompt_scale": 1.0, "image_prompt_scale": ips,
                           "guidance_scale": guidance, "num_inference_steps": args.num_inference_steps, "strength": strength,
                           "redux_prompt": prompt, "seed": seed, "process_id": process_id, "shot_number": shot, "bg_index": bg_idx,

@@ -373,6 +373,19 @@ int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jp
 int drag_cv_resize_linear_u8_f32(const void* src, const int64_t* src_off, const int32_t* hw, const int32_t* tab, float* dst,
                                  int32_t n, int32_t out_h, int32_t out_w, void* stream);
 
+/* uint8 images in HBM -> complete PNG files in HBM; replaces the host-side `image.save(path)` of the reference's large RGB
+ * results (batch_generate_flux_kshot.py:480 generated_image_rank{r}.png, outpainting_updown_sampling_redux.py:1262 / :1278
+ * *_hires_result_* / *_final_result_*).  The contract is the PNG format's: any reader (PIL / libpng) decodes exactly the input
+ * array.  Adaptive row filters (libpng's minimum-sum heuristic) + ONE dynamic-Huffman DEFLATE block of literals (no LZ77
+ * matches) + Adler-32 + CRC-32, all on the device, stream-ordered, no host round trip.
+ *   drag_png_plan:   sizes for a batch of n dense images [H, W, C] (C = 1 grey, 3 RGB; fewer than 2^26 filtered bytes each):
+ *                    *workspace_bytes of scratch, *out_stride bytes per image in the output buffer (worst case).
+ *   drag_png_encode: images uint8 [n, H, W, C] -> file i at out + i * out_stride, its length in sizes[i] (device int64);
+ *                    workspace 256-byte aligned. */
+int drag_png_plan(int32_t n, int32_t H, int32_t W, int32_t C, int64_t* workspace_bytes, int64_t* out_stride);
+int drag_png_encode(const void* images, int32_t n, int32_t H, int32_t W, int32_t C, void* workspace, int64_t workspace_bytes,
+                    void* out, int64_t out_stride, int64_t* sizes, void* stream);
+
 /* Host-side batch file reader feeding drag_jpeg_* (no device work): native threads do the per-file system calls that cost the
  * interpreter ~80 us each.  drag_file_sizes: sizes[i] = bytes of paths[i] or -errno.  drag_read_files: paths[i] -> dst[offsets[i]
  * .. offsets[i+1]) in plain host (ideally pinned) memory; status[i] = 0, errno, or -1 for a file shorter than its slot. */

@@ -146,6 +146,17 @@ def test_stage3_background_writer_matches_inline_files(gpu, tmp_path):
     for f in pngs:
         assert (da / f).read_bytes() == (db / f).read_bytes(), f
     assert len(list((root / "final_results" / "process_b" / "1_shot" / ds / "1_shot").glob("*_final_result*.png"))) == 2
+    # --png host (Pillow's zlib, the reference's encoder) vs the default device encoder: other bytes for the hires / final
+    # results, the same pixels in every file
+    _run("domain_rag_amd.cli.stage3_outpaint", ["--process_id", "c"] + common + ["--png", "host"], cwd=root)
+    dc = root / "outpaint_hires" / "process_c" / ds / "1_shot" / name
+    assert pngs == sorted(f for f in os.listdir(dc) if f.endswith(".png"))
+    differ = 0
+    for f in pngs:
+        a, c = Image.open(da / f), Image.open(dc / f)
+        assert a.mode == c.mode and a.size == c.size and np.array_equal(np.asarray(a), np.asarray(c)), f
+        differ += (da / f).read_bytes() != (dc / f).read_bytes()
+    assert differ == 4          # 2 x (hires, final)
 
 
 def test_stage3_downscale_branch(gpu, tmp_path):
