@@ -205,7 +205,7 @@ def process_sample(engine: Engine, args, dataset, sample_id, sample_dir, shot, p
                     if final is result:
                         final_file = hires_files[k_out]
                     else:                     # the resize back to the original resolution is the host's (PIL); its pixels go up once
-                        final_file = gpu_png.encode(torch.from_numpy(np.ascontiguousarray(np.asarray(final.convert("RGB")))).to(engine.dev))[0]
+                        final_file = gpu_png.encode(torch.from_numpy(np.array(final.convert("RGB"))).to(engine.dev))[0]
                     with open(final_path, "wb") as f:
                         f.write(final_file)
                 else:

@@ -1,6 +1,6 @@
 """Wall-clock of stage 3's per-sample loop on one GPU, full-size synthetic weights: 500x375 originals (-> 1365x1024 frames),
-5 backgrounds per sample, strength 0.6 x 50 = 30 steps (Camouflage settings), PNGs encoded inline (the reference's pattern)
-vs in background worker processes.  Prints seconds per sample and per composite for both."""
+5 backgrounds per sample, strength 0.6 x 50 = 30 steps (Camouflage settings), PNGs encoded inline (the reference's pattern),
+in background worker processes, and on the device (--png gpu, the CLI's default).  Prints seconds per sample and per composite."""
 import argparse
 import json
 import os
@@ -73,7 +73,8 @@ def main():
             return out
 
         engine.pipe, engine.prior_embeds = TimedPipe(), timed_prior
-        for label, workers in (("inline Image.save", 0), ("background encoders", 4)):
+        for label, workers, png_mode in (("inline Image.save", 0, "host"), ("background encoders", 4, "host"), ("device PNG encoder", 4, "gpu")):
+            args.png = png_mode
             w = ImageWriter(workers)
             acc["pipe"] = acc["prior"] = 0.0
             torch.cuda.synchronize()
