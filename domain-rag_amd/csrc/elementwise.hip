@@ -20,6 +20,62 @@ struct LnArgs {
   float eps;
 };
 
+// AdaLN fast path for D = NIT * 512 (the DiT's 3072): the generic kernel below guards every 16-byte piece with `c < D`, which
+// makes each piece its own basic block — hipcc then waits for each load before issuing the next (six serial round trips per row
+// for x, six more for scale / shift).  Here every load of a phase is issued before the first use: x up front, scale / shift while
+// the statistics are reduced.  Same arithmetic in the same order as the generic kernel: identical bits.
+template <int NIT>
+__global__ __launch_bounds__(256) void layernorm_modulate_fixed_kernel(LnArgs p) {
+  const int w = wave_id(), l = lane_id();
+  const int row = blockIdx.x * 4 + w;
+  if (row >= p.M) return;
+  const int b = row / p.rpb, s = row - b * p.rpb;
+  const bf16_t* xr = p.x + (long long)b * p.x_bs + (long long)s * p.ldx;
+  u32x4_t raw[NIT], sc[NIT], sh[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) raw[it] = *(const u32x4_t*)(xr + (it * 64 + l) * 8);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    sc[it] = *(const u32x4_t*)(p.scale + (long long)b * p.ld_mod + (it * 64 + l) * 8);
+    sh[it] = *(const u32x4_t*)(p.shift + (long long)b * p.ld_mod + (it * 64 + l) * 8);
+  }
+  float v[NIT][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[it][2 * j] = bf2f((bf16_t)(raw[it][j] & 0xffff));
+      v[it][2 * j + 1] = bf2f((bf16_t)(raw[it][j] >> 16));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[it][j];
+  }
+  const float mean = wave_sum(sum) / (float)p.D;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = v[it][j] - mean;
+      sq += d * d;
+    }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+  bf16_t* yr = p.y + (long long)row * p.ldy;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    u32x4_t pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // torch bf16 graph: n = LN(x) (bf16); t = 1 + scale (bf16); y = n * t (bf16) + shift (bf16)
+      const float n0 = rbf((v[it][2 * j] - mean) * rstd), n1 = rbf((v[it][2 * j + 1] - mean) * rstd);
+      const float t0 = rbf(1.0f + bf2f((bf16_t)(sc[it][j] & 0xffff))), t1 = rbf(1.0f + bf2f((bf16_t)(sc[it][j] >> 16)));
+      pk[j] = pack2bf(rbf(n0 * t0) + bf2f((bf16_t)(sh[it][j] & 0xffff)), rbf(n1 * t1) + bf2f((bf16_t)(sh[it][j] >> 16)));
+    }
+    *(u32x4_t*)(yr + (it * 64 + l) * 8) = pk;
+  }
+}
+
 __global__ __launch_bounds__(256) void layernorm_modulate_kernel(LnArgs p) {
   const int w = wave_id(), l = lane_id();
   const int row = blockIdx.x * 4 + w;
@@ -231,7 +287,10 @@ extern "C" int drag_layernorm_modulate_bf16(const void* x, void* y, const void* 
   p.gamma = (const bf16_t*)gamma; p.beta = (const bf16_t*)beta;
   p.M = M; p.D = D; p.ldx = ldx; p.rpb = rows_per_batch > 0 ? rows_per_batch : M; p.ldy = ldy; p.ld_mod = ld_mod;
   p.x_bs = x_batch_stride; p.eps = eps;
-  hipLaunchKernelGGL(layernorm_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+  if (D == 6 * 512 && scale && !gamma && !drag_opt(DRAG_OPT_LN_GENERIC))
+    hipLaunchKernelGGL(layernorm_modulate_fixed_kernel<6>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(layernorm_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
   DRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -111,6 +111,27 @@ def test_layernorm_modulate(gpu):
     assert _rel(y2.cpu(), ops_ref.layernorm_modulate_ref(x2, gamma=g, beta=b, eps=1e-5).reshape(35, D2)) < 1e-2
 
 
+def test_layernorm_fixed_width_path_equals_generic(gpu):
+    """D = 3072 AdaLN rows take a kernel that issues all its loads up front; same arithmetic order -> same bits as the generic one,
+    for joint-buffer row addressing (batched rows, row stride > D) too"""
+    from domain_rag_amd import ops
+    B, St, S, D = 3, 5, 41, 3072
+    x = _randn((B, S, D), 1, 2.0).to(gpu)
+    mod = _randn((B, 6 * D), 2, 0.3).to(gpu)
+    outs = {}
+    try:
+        for generic in (1, 0):
+            ops.set_option("ln_generic", generic)
+            y = torch.full((B * (S - St), D + 64), 7.0, dtype=torch.bfloat16, device=gpu)
+            ops.layernorm(x.view(-1)[St * D:], y, B * (S - St), D, scale=mod.view(-1)[4 * D:], shift=mod.view(-1)[3 * D:], ldx=D,
+                          rows_per_batch=S - St, x_batch_stride=S * D, ld_mod=6 * D, ldy=D + 64)
+            outs[generic] = y.cpu()
+    finally:
+        ops.set_option("ln_generic", 0)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0][:, D:] == 7.0).all()
+
+
 def test_small_elementwise(gpu):
     from domain_rag_amd import ops
     from oracle import flux as oflux
