@@ -65,6 +65,9 @@ def parse(argv=None):
     ap.add_argument("--clip-precision", choices=("fp32", "bf16"), default="fp32")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU check of the launcher itself: ranks rendezvous over gloo, shard units, all-gather rows; no GPU work")
+    ap.add_argument("--debug-share-gpu", action="store_true",
+                    help="NOT a measurement: all N ranks run on GPU 0 and talk over gloo, so the N > 1 control flow of a workload "
+                         "(sharding, collectives, rank-0-only work) can be exercised on a 1-GPU box; the line says so")
     return ap.parse_args(argv)
 
 
@@ -87,7 +90,7 @@ def self_launch_if_needed(args) -> None:
         sys.exit("bench.py: --gpus must be >= 1")
     if args.gpus == 1:
         return
-    if not args.selftest_launcher:
+    if not args.selftest_launcher and not args.debug_share_gpu:
         n = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if n < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} requested but {n} GPU(s) are visible on this node: one rank per GPU is "
@@ -108,12 +111,15 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.cpu = args.selftest_launcher
+        self.shared = bool(getattr(args, "debug_share_gpu", False)) and not self.cpu
         self.dist = None
         if self.cpu:
             self.dev = torch.device("cpu")
         else:
             if not torch.cuda.is_available():
                 sys.exit("bench.py: no GPU visible (domain-rag_amd has no CPU path)")
+            if self.shared:
+                self.local = 0
             if self.local >= torch.cuda.device_count():
                 sys.exit(f"bench.py: local rank {self.local} has no GPU of its own ({torch.cuda.device_count()} visible)")
             torch.cuda.set_device(self.local)
@@ -122,11 +128,11 @@ class Dist:
         if self.world > 1 or (self.cpu and "MASTER_ADDR" in os.environ):
             import torch.distributed as dist
             self.dist = dist
-            if self.cpu:
+            if self.cpu or self.shared:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.dev)
-            ones = torch.ones(1, device=self.dev)
+            ones = torch.ones(1, device="cpu" if self.shared else self.dev)
             dist.all_reduce(ones)                       # every rank that joined adds 1
             self.rccl_ranks = int(round(ones.item()))
             if self.rccl_ranks != self.world:
@@ -139,7 +145,7 @@ class Dist:
     def max_over_ranks(self, x: float) -> float:
         if self.dist is None:
             return x
-        t = torch.tensor([x], device=self.dev, dtype=torch.float64)
+        t = torch.tensor([x], device="cpu" if self.shared else self.dev, dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return t.item()
 
@@ -546,6 +552,8 @@ def main():
         d.barrier()
         out = run_generate(args, d) if args.workload == "generate" else run_retrieval(args, d)
         if d.rank == 0:
+            if d.shared:
+                out["debug_share_gpu"] = "all ranks on GPU 0 over gloo: control-flow check only, NOT a measurement"
             print(json.dumps(out), flush=True)
     finally:
         d.close()

@@ -415,6 +415,11 @@ def allgather_rows(local: torch.Tensor, n_total: int, group=None, force: bool = 
     if world == 1 and not force:
         return local
     send = pack_shard(local, n_total, world, rank)
+    if local.is_cuda and dist.get_backend(group) == "gloo":       # gloo gathers host tensors only (bench.py --debug-share-gpu)
+        host = send.cpu()
+        recv = torch.empty((world,) + tuple(host.shape), dtype=local.dtype)
+        dist.all_gather(list(recv.unbind(0)), host, group=group)
+        return unpack_shards(recv.to(local.device), n_total)
     recv = torch.empty((world,) + tuple(send.shape), dtype=local.dtype, device=local.device)
     if local.is_cuda and hasattr(dist, "all_gather_into_tensor"):
         dist.all_gather_into_tensor(recv, send, group=group)

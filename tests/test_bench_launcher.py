@@ -48,3 +48,20 @@ def test_more_ranks_than_gpus_fails_loudly():
 def test_world_size_mismatch_fails_loudly():
     r = _run(["--gpus", "2", "--selftest-launcher"], env_extra={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "n_ranks" not in r.stdout
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_retrieval_workload_with_three_ranks_sharing_one_gpu():
+    """the N > 1 control flow of the retrieval bench line on real kernels: `--debug-share-gpu` puts every rank on GPU 0 and the
+    collectives on gloo (NOT a measurement: the line says so) — corpus and query sharding, the one all-gather into the global row
+    order, rank 0's report; every planted neighbour must come back first on rank 0's query shard"""
+    r = _run(["--gpus", "3", "--debug-share-gpu", "--workload", "retrieval", "--steps", "1", "--warmup", "0", "--corpus", "5000",
+              "--queries", "48", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 3 and out["rccl_ranks"] == 3 and "NOT a measurement" in out["debug_share_gpu"]
+    assert out["planted_neighbour_first"].startswith("16/16")
+    assert out["allgather"]["bytes_received_per_gpu"] == 2 * 1667 * 512 * 4
