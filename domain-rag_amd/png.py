@@ -32,8 +32,9 @@ def _buffers(device, ws_bytes: int, out_bytes: int):
 
 
 def encode(images: torch.Tensor) -> list:
-    """``images``: uint8, on the GPU, ``[n, H, W, 3]`` / ``[H, W, 3]`` (RGB) or ``[n, H, W, 1]`` / ``[n, H, W]`` with
-    ``grey=True`` semantics inferred from the last dimension.  Returns one ``bytes`` object (a whole .png file) per image."""
+    """``images``: uint8, on the GPU: ``[n, H, W, 3]`` / ``[H, W, 3]`` (RGB files) or ``[n, H, W, 1]`` / ``[n, H, W]`` (8-bit grey
+    files).  A 3-D tensor whose last dimension is 1 or 3 is ONE image; any other 3-D tensor is a batch of grey images.
+    Returns one ``bytes`` object (a whole .png file) per image."""
     lib = _lib.load()
     if images.dtype != torch.uint8:
         raise TypeError("png.encode: uint8 images expected")
