@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(PrepArgs p) {
     }
   }
 
+  if (p.vt == nullptr) return;        // k only: the attention kernel reads V row-major
   // ---- v: stage [64 keys][128 d] in LDS, write V^T[d][pos(key)] ----
   for (int i = tid; i < 64 * 16; i += 256) {
     const int r = i >> 4, c = i & 15;
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(PrepArgs p) {
 // --------------------------------------------------------------------------------------------
 struct AttnArgs {
   const bf16_t *q, *k, *vt;
+  const bf16_t* v;            // VROW kernels: V as the Linear wrote it (rows of ld_qk elements, like k); vt is then unused
   bf16_t* out;
   int B, S, H, ld_qk, ld_o, s_pad;
   long long qk_bs, o_bs;
@@ -148,7 +150,14 @@ constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 //          the loop.  Same arithmetic, same order per accumulator: bit-identical outputs.
 // PMAX: the row maxima of S(j+1) are taken at the END of iteration j (next to the trailing P V MFMAs, which need no VALU)
 //       instead of at the start of iteration j+1, where the matrix pipe has nothing to do.  Same values, same order.
-template <int NW, int SCHED, bool QPREP, bool PMAX>   // NW: waves per block (4 or 8), 32 queries each; QPREP: RMSNorm + RoPE of q on load
+// VROW: V is read ROW-MAJOR, straight from the qkv buffer (no V^T pass, no V^T buffer).  The V tile [64 keys][128 d] is staged like
+//       the K tile (4 key rows per LDS-DMA instruction) and the A operand of O^T += V^T P^T — per lane 8 keys of one d — comes from
+//       two ds_read_b64_tr_b16: within a 16-lane group source lane 4j + r supplies 4 consecutive d of key j, result lane 4r + e
+//       receives (key 0..3) at d = 4r + e (probed on the hardware: scripts/probe/probe_tr16.hip).  The first read fetches the key
+//       quad that this half-wave's P registers 0-3 hold, the second the quad of registers 4-7, so the key permutation the V^T
+//       image needed is absorbed by the addresses.  16-byte units of a key row are XOR-swizzled with 4 * (key & 3): the 16 units
+//       (4 keys x 64 B) a 32-lane access touches fall into 16 different bank groups.  Same MFMA operands -> same bits as the V^T kernels.
+template <int NW, int SCHED, bool QPREP, bool PMAX, bool VROW = false>   // NW: waves per block (4 or 8), 32 queries each; QPREP: RMSNorm + RoPE of q on load
 __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
   const int w = wave_id(), l = lane_id();
@@ -169,13 +178,15 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   bf16x8_t qf[8];
   // ---- staging descriptors ----
   const bf16_t* kbase = p.k + (long long)b * p.qk_bs + h * 128;
-  const bf16_t* vbase = p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
+  const bf16_t* vbase = VROW ? p.v + (long long)b * p.qk_bs + h * 128 : p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
   __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.vt_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, VROW ? p.k_bytes : p.vt_bytes, 0x00020000);
   // K chunk c (1 KiB) = key rows 4c..4c+3; lane: row 4c + (l>>4), physical slot l&15
   // V chunk c (1 KiB) = d rows 8c..8c+7;   lane: row 8c + (l>>3), physical slot l&7
   int krow[4];                        // (fixed-size: a template-dependent array bound here makes hipcc drop the host stub)
   unsigned kslot[4], voff[4];
+  // VROW: V chunk c = key rows 4c..4c+3 like K; physical slot l&15 holds logical 16-byte unit (l&15) ^ 4*(key&3)
+  const unsigned vrslot = (unsigned)(((l & 15) ^ (4 * ((l >> 4) & 3))) * 16);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i >= CPW) break;
@@ -205,16 +216,19 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   };
   auto stage_v1 = [&](int buf, int kv0, int i) {
     const int c = w * CPW + i;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)((DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024),
-                                             16, voff[i], kv0 * 2, 0, 0);
+    DRAG_LDS char* dV = (DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024;
+    if constexpr (VROW) {
+      const int vr = min(kv0 + krow[i], p.S - 1);          // rows past S are real rows: finite values under a zero probability
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, (unsigned)((long long)vr * p.ld_qk * 2) + vrslot, 0, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, voff[i], kv0 * 2, 0, 0);
+    }
   };
   auto stage_v = [&](int buf, int kv0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i >= CPW) break;
-      const int c = w * CPW + i;
-      DRAG_LDS char* dV = (DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, voff[i], kv0 * 2, 0, 0);
+      stage_v1(buf, kv0, i);
     }
   };
 
@@ -256,6 +270,27 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   for (int ks = 0; ks < 8; ++ks) ak[ks] = krd + (((2 * ks + hh) ^ kx) << 4);
 #pragma unroll
   for (int s2 = 0; s2 < 4; ++s2) av[s2] = vrd + (((2 * s2 + hh) ^ vx) << 4);
+  // VROW: byte offset of this lane's 8-byte source piece for d block dt (32 rows of V^T): key 4 hh + (si>>2) of a quad pair,
+  // 16-byte unit 4 dt + 2 g1 + ((si>>1)&1) swizzled with 4 * (key & 3), half (si & 1); + 4096 per 16-key group, + 2048 for the second quad
+  int avd[4];
+  {
+    const int si = l & 15, g1 = (l >> 4) & 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      avd[dt] = (4 * hh + (si >> 2)) * 256 + ((4 * (dt ^ (si >> 2)) + 2 * g1 + ((si >> 1) & 1)) << 4) + (si & 1) * 8;
+  }
+  auto read_v = [&](const int s2, const int dt, const int vb) -> bf16x8_t {
+    if constexpr (VROW) {
+      typedef short s16x4_t __attribute__((ext_vector_type(4)));
+      typedef short s16x8_t __attribute__((ext_vector_type(8)));
+      DRAG_LDS char* a = (DRAG_LDS char*)smem + (avd[dt] + (vb + s2 * 4096));
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((DRAG_LDS s16x4_t*)a);
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((DRAG_LDS s16x4_t*)(a + 2048));
+      return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    } else {
+      return *(const bf16x8_t*)(smem + (av[s2] + (vb + dt * (32 * 128))));
+    }
+  };
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   stage_k(0, 0);
   stage_v(0, 0);
@@ -386,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
           kf = *(const bf16x8_t*)(smem + (ak[ks1] + (KN + t1 * (32 * 256))));
         }
         bf16x8_t vfg;
-        if (SCHED == 1 && g >= 4) vfg = *(const bf16x8_t*)(smem + (av[(g >> 2) - 1] + (VB + (g & 3) * (32 * 128))));
+        if (SCHED == 1 && g >= 4) vfg = read_v((g >> 2) - 1, g & 3, VB);
         sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], (g & 7) == 0 ? zero16 : sn[g >> 3], 0, 0, 0);
         // unconditional (no branches: a branch here splits the block and hipcc then hoists the whole softmax out of the
         // interleave): past the last tile the K rows clamp to S-1 and the V^T offsets fall outside the descriptor's range
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     for (int s2 = (SCHED == 1 ? 3 : 0); s2 < 4; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t vf = *(const bf16x8_t*)(smem + (av[s2] + (VB + dt * (32 * 128))));
+        const bf16x8_t vf = read_v(s2, dt, VB);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[dt], 0, 0, 0);
       }
     // S(it+1) is complete: its row maxima now, beside the trailing P V MFMAs (in the last iteration sn is stale and unused)
@@ -792,7 +827,7 @@ extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt
 extern "C" int drag_k_norm_rope_vt_bf16(void* qkv, void* vt, const void* wk_txt, const void* wk_img, const float* rope_cos,
                                         const float* rope_sin, int32_t B, int32_t S, int32_t H, int32_t ld, int32_t s_txt,
                                         float eps, void* stream) {
-  DRAG_CHECK(qkv && vt, "drag_k_norm_rope_vt_bf16: null pointer");
+  DRAG_CHECK(qkv, "drag_k_norm_rope_vt_bf16: null pointer");      // vt == null: k only (drag_attention_v_bf16 reads v as it is)
   DRAG_CHECK((wk_txt == nullptr) == (wk_img == nullptr), "drag_k_norm_rope_vt_bf16: norm weights come in pairs");
   DRAG_CHECK((rope_cos == nullptr) == (rope_sin == nullptr), "drag_k_norm_rope_vt_bf16: cos/sin come in pairs");
   DRAG_CHECK(B > 0 && S > 0 && H > 0 && ld >= 3 * H * 128 && ld % 8 == 0, "drag_k_norm_rope_vt_bf16: bad shape");
@@ -811,7 +846,7 @@ extern "C" int drag_k_norm_rope_vt_bf16(void* qkv, void* vt, const void* wk_txt,
 static int attention_launch(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S, int32_t H,
                             int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
                             const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt,
-                            float eps, void* stream);
+                            float eps, void* stream, bool vrow = false);
 
 extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S,
                                    int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
@@ -834,15 +869,29 @@ extern "C" int drag_attention_qprep_bf16(const void* q, const void* k, const voi
                           rope_sin, s_txt, eps, stream);
 }
 
+// attention over q | k | v AS THE LINEARS WROTE THEM: v is read row-major from the projection buffer (same row stride and batch
+// stride as q / k) — no V^T pass, no V^T buffer.  The q preparation is optional: all four of wq_txt / wq_img / rope_cos /
+// rope_sin, or none of them (then q is used as stored, like drag_attention_bf16).
+extern "C" int drag_attention_v_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t S, int32_t H,
+                                     int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
+                                     const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin,
+                                     int32_t s_txt, float eps, void* stream) {
+  const int given = (wq_txt != nullptr) + (wq_img != nullptr) + (rope_cos != nullptr) + (rope_sin != nullptr);
+  DRAG_CHECK(given == 0 || given == 4, "drag_attention_v_bf16: the fused q preparation takes both norm weights and both RoPE tables, or none");
+  DRAG_CHECK(given == 0 || (s_txt >= 0 && s_txt <= S), "drag_attention_v_bf16: 0 <= s_txt <= S");
+  return attention_launch(q, k, v, out, B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale, wq_txt, wq_img, rope_cos,
+                          rope_sin, s_txt, eps, stream, true);
+}
+
 static int attention_launch(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S, int32_t H,
                             int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
                             const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt,
-                            float eps, void* stream) {
+                            float eps, void* stream, bool vrow) {
   DRAG_CHECK(q && k && vt && out, "drag_attention_bf16: null pointer");
   DRAG_CHECK(B > 0 && S > 0 && H > 0, "drag_attention_bf16: bad shape");
   DRAG_CHECK(ld_qk % 8 == 0 && ld_o % 4 == 0, "drag_attention_bf16: ld_qk %% 8, ld_o %% 4 required");
   AttnArgs p;
-  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.out = (bf16_t*)out;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.v = (const bf16_t*)vt; p.out = (bf16_t*)out;
   p.B = B; p.S = S; p.H = H; p.ld_qk = ld_qk; p.ld_o = ld_o; p.s_pad = (S + 63) / 64 * 64;
   p.qk_bs = qk_batch_stride; p.o_bs = o_batch_stride;
   p.c = scale * 1.4426950408889634f;
@@ -854,7 +903,7 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
   const int groups = (B * H + 7) / 8;
   const bool w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
-  const int QB = (w8 || (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024)) ? 256 : 128;
+  const int QB = (w8 || (!vrow && drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024)) ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
   const int sched = drag_opt(DRAG_OPT_ATTN_SCHED);          // 0, 1, or 2 = schedule 1 + pipelined row maxima
@@ -869,7 +918,12 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
     else if (sched == 1) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, false); else DRAG_ATTN_LAUNCH(NW, 1, false, false); } \
     else { if (qprep) DRAG_ATTN_LAUNCH(NW, 0, true, false); else DRAG_ATTN_LAUNCH(NW, 0, false, false); }                 \
   } while (0)
-  if (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024) {
+  if (vrow) {                   // row-major V: the product schedule only (SCHED 1 + PMAX)
+    if (w8) { if (qprep) hipLaunchKernelGGL((attention_d128_kernel<8, 1, true, true, true>), grid, dim3(512), 0, st, p);
+              else hipLaunchKernelGGL((attention_d128_kernel<8, 1, false, true, true>), grid, dim3(512), 0, st, p); }
+    else { if (qprep) hipLaunchKernelGGL((attention_d128_kernel<4, 1, true, true, true>), grid, dim3(256), 0, st, p);
+           else hipLaunchKernelGGL((attention_d128_kernel<4, 1, false, true, true>), grid, dim3(256), 0, st, p); }
+  } else if (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024) {
     if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attention_q64_kernel<false>), grid, dim3(256), 0, st, p);
   } else if (w8) DRAG_ATTN_PICK(8); else DRAG_ATTN_PICK(4);

@@ -184,7 +184,8 @@ def k_norm_rope_vt(qkv: torch.Tensor, vt: torch.Tensor, wk_txt, wk_img, rope_cos
     """k RMSNorm + RoPE in place and V -> V^T; q is left as projected (``attention_qprep`` prepares it on load)"""
     lib = _lib.load()
     _need(qkv, torch.bfloat16, "qkv")
-    _need(vt, torch.bfloat16, "vt")
+    if vt is not None:              # None: k only (``attention_v`` reads v row-major)
+        _need(vt, torch.bfloat16, "vt")
     check(lib.drag_k_norm_rope_vt_bf16(_p(qkv), _p(vt), _p(wk_txt), _p(wk_img), _p(rope_cos), _p(rope_sin), B, S, H, ld, s_txt,
                                        eps, _stream()), "drag_k_norm_rope_vt_bf16")
 
@@ -201,6 +202,22 @@ def attention_qprep(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: tor
     check(lib.drag_attention_qprep_bf16(_p(q), _p(k), _p(vt), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale,
                                         _p(wq_txt), _p(wq_img), _p(rope_cos), _p(rope_sin), s_txt, eps, _stream()),
           "drag_attention_qprep_bf16")
+
+
+def attention_v(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, ld_qk: int,
+                qk_batch_stride: int, ld_o: int, o_batch_stride: int, scale: float, wq_txt=None, wq_img=None, rope_cos=None,
+                rope_sin=None, s_txt: int = 0, eps: float = 1e-6) -> None:
+    """attention over q | k | v as the Linears wrote them: v is read row-major (no V^T pass / buffer); the q preparation
+    (norm weights + RoPE tables) is optional"""
+    lib = _lib.load()
+    _need(q, torch.bfloat16, "q")
+    _need(v, torch.bfloat16, "v")
+    _need(out, torch.bfloat16, "out")
+    if rope_cos is not None:
+        _need(rope_cos, torch.float32, "rope_cos")
+    check(lib.drag_attention_v_bf16(_p(q), _p(k), _p(v), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale,
+                                    _p(wq_txt), _p(wq_img), _p(rope_cos), _p(rope_sin), s_txt, eps, _stream()),
+          "drag_attention_v_bf16")
 
 
 def layernorm(x: torch.Tensor, y: torch.Tensor, M: int, D: int, *, scale=None, shift=None, gamma=None, beta=None,

@@ -134,6 +134,13 @@ int drag_attention_qprep_bf16(const void* q, const void* k, const void* vt, void
                               int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
                               const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin,
                               int32_t s_txt, float eps, void* stream);
+/* The same attention over q | k | v AS THE LINEARS WROTE THEM: v is read row-major from the projection buffer (row stride
+ * ld_qk, batch stride qk_batch_stride, like q and k) through the LDS transpose read of gfx950 — no V^T pass, no V^T buffer;
+ * drag_k_norm_rope_vt_bf16 is then called with vt = NULL (k only).  The fused q preparation is optional: all four of wq_txt /
+ * wq_img / rope_cos / rope_sin, or none.  Same MFMA operands as the V^T kernels: identical bits. */
+int drag_attention_v_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t S, int32_t H, int32_t ld_qk,
+                          int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale, const void* wq_txt,
+                          const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt, float eps, void* stream);
 
 /* drag_layernorm_modulate_bf16 — y = LN(x) * (1 + scale[b]) + shift[b]   (no affine LN, eps given)
  * or, with gamma/beta != NULL, y = LN(x) * gamma + beta (affine LayerNorm, scale/shift NULL).

@@ -23,12 +23,17 @@ for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
     ops.qk_norm_rope_vt(qkv, vt, wq, wq, wq, wq, cos, sin, B, S, H, 3 * D, 1241)
     fl = 4.0 * S * S * 128 * H * B
     run = lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+    run_v = lambda: ops.attention_v(qkv, qkv.view(-1)[D:], qkv.view(-1)[2 * D:], o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
     t = {k: [] for k in VARIANTS}
+    t["row-major v"] = []
     for rep in range(6):
         for name, env in VARIANTS.items():
             for k in ("attn_sched", "attn_w4", "attn_tune", "attn_q64"): ops.set_option(k, 0)
             for k, v in env.items(): ops.set_option(k, v)
             if rep == 0: bench(run, 3)
             t[name].append(bench(run))
+        ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2); ops.set_option("attn_q64", 0)
+        if rep == 0: bench(run_v, 3)
+        t["row-major v"].append(bench(run_v))
     ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2); ops.set_option("attn_q64", 0)
     print(f"attn B={B} S={S} H={H}: " + " | ".join(f"{k} {fl/statistics.median(v)/1e9:.0f} TF/s" for k, v in t.items()), flush=True)

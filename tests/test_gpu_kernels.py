@@ -244,6 +244,48 @@ def test_attention_schedules_are_bit_identical(gpu):
         ops.set_option("no_such_switch", 1)
 
 
+@pytest.mark.parametrize("B,S,H,s_txt", [(2, 4300, 2, 1241), (1, 5337, 1, 512), (3, 300, 2, 10), (2, 64, 1, 0), (1, 1753, 3, 77), (2, 129, 1, 129)])
+def test_attention_row_major_v_equals_vt_path(gpu, B, S, H, s_txt):
+    """drag_attention_v_bf16 reads v straight from the projection buffer (LDS transpose reads) — same MFMA operands as the V^T
+    kernels, so the outputs must be IDENTICAL, with and without the fused q preparation; the k-only prep pass (vt = None) must
+    leave q and v alone and write the same k as the full pass"""
+    from domain_rag_amd import ops
+    from oracle import flux as oflux
+    D = H * 128
+    qkv = _randn((B, S, 3 * D), 31 + S).to(gpu)
+    g = torch.Generator().manual_seed(S)
+    w = [(1 + 0.1 * torch.randn(128, generator=g)).bfloat16().to(gpu) for _ in range(4)]       # wq_txt, wk_txt, wq_img, wk_img
+    ids = torch.zeros(S, 3); ids[:, 1] = torch.arange(S) // 37; ids[:, 2] = torch.arange(S) % 37
+    cos, sin = (t.to(gpu) for t in oflux.rope_tables(ids))
+    s_pad = (S + 63) // 64 * 64
+    scale = 1 / math.sqrt(128)
+
+    def out_buf():
+        return torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
+
+    # (1) q, k prepared by the pass; V^T path vs row-major path
+    a = qkv.clone()
+    vt = torch.empty((B, H, 128, s_pad), dtype=torch.bfloat16, device=gpu)
+    ops.qk_norm_rope_vt(a, vt, w[0], w[1], w[2], w[3], cos, sin, B, S, H, 3 * D, s_txt)
+    o_vt, o_v = out_buf(), out_buf()
+    ops.attention(a, a.view(-1)[D:], vt, o_vt, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
+    ops.attention_v(a, a.view(-1)[D:], a.view(-1)[2 * D:], o_v, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
+    assert torch.isfinite(o_vt.float()).all() and torch.equal(o_v, o_vt)
+    # (2) k-only pass without a V^T buffer + fused q preparation
+    b2 = qkv.clone()
+    ops.k_norm_rope_vt(b2, None, w[1], w[3], cos, sin, B, S, H, 3 * D, s_txt)
+    assert torch.equal(b2[..., D:2 * D], a[..., D:2 * D]) and torch.equal(b2[..., :D], qkv[..., :D]) and torch.equal(b2[..., 2 * D:], qkv[..., 2 * D:])
+    o_q = out_buf()
+    ops.attention_v(b2, b2.view(-1)[D:], b2.view(-1)[2 * D:], o_q, B, S, H, 3 * D, S * 3 * D, D, S * D, scale,
+                    w[0], w[2], cos, sin, s_txt)
+    o_qvt = out_buf()           # the fused q preparation sums the squares in another order than the pass: compare like with like
+    ops.attention_qprep(b2, b2.view(-1)[D:], vt, o_qvt, B, S, H, 3 * D, S * 3 * D, D, S * D, scale, w[0], w[2], cos, sin, s_txt)
+    assert torch.equal(o_q, o_qvt)
+    assert _rel(o_q.cpu(), o_vt.cpu()) < 1e-2
+    with pytest.raises(RuntimeError, match="or none"):
+        ops.attention_v(b2, b2.view(-1)[D:], b2.view(-1)[2 * D:], o_q, B, S, H, 3 * D, S * 3 * D, D, S * D, scale, w[0], None, cos, sin, s_txt)
+
+
 def test_attention_spike(gpu):
     _attn_case(gpu, 1, 300, 1, 10, seed=5, spike=True)
 
