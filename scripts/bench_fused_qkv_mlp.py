@@ -24,6 +24,15 @@ V = {
     "fused gelu from 9216, two destinations": lambda: ops.gemm(A, W, out=qkv, bias=b, act=ops.ACT_GELU_TANH, act_n0=3 * D, M=M, lda=K, ldc=3 * D,
                                                               out2=cat.view(-1)[D:], ldc2=D + F, n_split=3 * D),
 }
+def split_launches(w0, n, parts, act, out, ldc, col0):
+    def run():
+        step = n // parts
+        for i in range(parts):
+            ops.gemm(A, W[w0 + i * step: w0 + (i + 1) * step], out=out.view(-1)[col0 + i * step:], bias=b[w0 + i * step: w0 + (i + 1) * step], act=act, M=M, lda=K, ldc=ldc)
+    return run
+V["qkv as 3 launches of N = 3072"] = split_launches(0, 3 * D, 3, ops.ACT_NONE, qkv, 3 * D, 0)
+V["mlp (gelu) as 2 launches of N = 6144"] = split_launches(3 * D, F, 2, ops.ACT_GELU_TANH, cat, D + F, D)
+V["mlp (gelu) as 4 launches of N = 3072"] = split_launches(3 * D, F, 4, ops.ACT_GELU_TANH, cat, D + F, D)
 t = {k: [] for k in V}
 for rep in range(7):
     for k, fn in V.items():
@@ -31,6 +40,7 @@ for rep in range(7):
         t[k].append(bench(fn))
 med = {k: statistics.median(v) for k, v in t.items()}
 for k, v in med.items():
-    n = {"separate qkv": 3 * D, "separate mlp (gelu)": F, "separate mlp (plain)": F}.get(k, 3 * D + F)
+    n = {"separate qkv": 3 * D, "separate mlp (gelu)": F, "separate mlp (plain)": F, "qkv as 3 launches of N = 3072": 3 * D,
+         "mlp (gelu) as 2 launches of N = 6144": F, "mlp (gelu) as 4 launches of N = 3072": F}.get(k, 3 * D + F)
     print(f"{k:42s} {v:8.1f} us  {2 * M * n * K / v / 1e6:7.1f} TF/s")
 print(f"separate total (gelu) {med['separate qkv'] + med['separate mlp (gelu)']:.1f} us; rounds: 23.48->24 + 31.31->32 = 56 vs fused 54.80->55")
