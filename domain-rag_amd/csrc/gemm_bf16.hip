@@ -72,6 +72,7 @@ struct GemmKArgs {
   // Lets two Linears over the same input run as ONE launch into two buffers (Flux single blocks: to_q|k|v and proj_mlp).
   void* C2;
   int ld2, n_split;
+  int group_m;    // M tiles per group of the tile walk (8; "gemm_group_m" option for measurements)
 };
 
 // the arguments as the epilogue of the tile at column n0 sees them
@@ -329,7 +330,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int 
 __device__ __forceinline__ void pick_tile(const GemmKArgs& p, int bid, int& tm, int& tn) {
   const int nwg = p.tiles_m * p.tiles_n;
   const int wg = xcd_remap(bid, nwg);
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = p.group_m;
   const int in_group = GROUP_M * p.tiles_n;
   const int gid = wg / in_group;
   const int first_m = gid * GROUP_M;
@@ -827,6 +828,10 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
   k.a_bytes = 0; k.w_bytes = 0;
   k.C2 = nullptr; k.ld2 = 0; k.n_split = 0;
+  // M tiles per group of the tile walk: the 32 concurrent tiles of an XCD form a group_m x (32 / group_m) super-tile.  4 and 8 tie on
+  // the K = 3072 shapes (8 ahead by 1-3 % at N = 3072), 4 is 2-3 % ahead at K >= 12288; 16 / 32 (towards W-stationary) lose 5-10 %
+  // everywhere (scripts/bench_gemm_group_m.py, two boxes).  Order only: the bits do not depend on it.
+  k.group_m = drag_opt(DRAG_OPT_GEMM_GROUP_M) > 0 ? drag_opt(DRAG_OPT_GEMM_GROUP_M) : (K >= 8192 ? 4 : 8);
   static const bool narrow = env_flag("DRAG_GEMM_NARROW");
   k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&
            (!resid || ((uintptr_t)resid & 15) == 0) && (!gate || (((uintptr_t)gate & 15) == 0 && ldg % 8 == 0)) &&
