@@ -36,6 +36,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC only on this driver: RCCL's intra-node transports need it, and the ROCr runtime reads it at its first GPU call —
+# so it is set in EVERY rank, whoever launched it (domain_rag_amd/rccl.py), before torch touches the device
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
@@ -131,7 +134,8 @@ class Dist:
             if self.cpu or self.shared:
                 dist.init_process_group("gloo")
             else:
-                dist.init_process_group("nccl", device_id=self.dev)
+                from domain_rag_amd.rccl import init_rccl
+                init_rccl(self.dev)
             ones = torch.ones(1, device="cpu" if self.shared else self.dev)
             dist.all_reduce(ones)                       # every rank that joined adds 1
             self.rccl_ranks = int(round(ones.item()))
@@ -148,6 +152,15 @@ class Dist:
         t = torch.tensor([x], device="cpu" if self.shared else self.dev, dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return t.item()
+
+    def all_ranks(self, x: float) -> list:
+        """every rank's own value, in rank order (a straggler shows up here; the reported clock is the max)"""
+        if self.dist is None:
+            return [x]
+        t = torch.tensor([x], device="cpu" if self.shared else self.dev, dtype=torch.float64)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.item() for o in out]
 
     def close(self):
         if self.dist is not None:
@@ -345,8 +358,10 @@ def run_generate(args, d: Dist):
     for i in range(args.steps):
         job.run_batch(recorder=rec if i == 0 else None)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0                  # this rank's own clock, before the closing barrier
     d.barrier()
     dt = d.max_over_ranks(time.perf_counter() - t0)
+    per_rank = d.all_ranks(own)
     images = args.steps * args.batch * d.world
     if d.rank != 0:
         return None
@@ -360,6 +375,9 @@ def run_generate(args, d: Dist):
         "metric": f"composited images/sec @{args.res}^2, {args.denoise_steps} Flux-Redux steps", "value": images / dt, "unit": "images/s",
         "n_gpus": d.world, "rccl_ranks": d.rccl_ranks if d.rccl_ranks is not None else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "per_rank": {"seconds": per_rank, "images_per_s": [args.steps * args.batch / t for t in per_rank],
+                     "clock": "value uses the max-over-ranks time between the two barriers; these are each rank's own "
+                              "seconds to finish its batches (before the closing barrier)"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"Flux-Redux outpaint (Fill) {args.res}x{args.res}, {args.denoise_steps} steps, "
                                f"batch={args.batch} per GPU (BASELINE configs[2])",

@@ -7,3 +7,7 @@ There is no CPU or eager-PyTorch fallback: importing :mod:`domain_rag_amd.ops` f
 ``libdomainrag_hip.so`` is missing.
 """
 __version__ = "0.1.0"
+
+# RCCL's platform environment has to be in place before this process first touches the GPU (rccl.py says why)
+import os as _os_env
+_os_env.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -355,7 +355,8 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=device)
+        from ..rccl import init_rccl
+        init_rccl(device)
     rank = dist.get_rank() if world > 1 else 0
     print(f"使用设备: {device}")
     clip_w, resnet_w = resolve_weights(args)

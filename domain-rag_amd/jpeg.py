@@ -45,14 +45,19 @@ class DecodedBatch:
         return self._out[o: o + h * w * 3].view(h, w, 3)
 
     def groups(self):
-        """((h, w), indices int64 array, uint8 [m, h, w, 3] dense device tensor) per distinct size: the output buffer is laid
-        out size class by size class, so a group is one contiguous slab"""
+        """((h, w), indices int64 array, uint8 [m, h, w, 3] dense device tensor) per run of same-size images: the output buffer
+        is laid out size class by size class, so a class is one contiguous slab — EXCEPT where a file was planned a slot and
+        then rejected (status 10: its scan does not end at EOI, known only after the decode).  Such a slot stays in the middle
+        of its class, so a run also ends where the next good image does not start right behind the previous one; a class
+        with rejected files comes out as several groups, every row of every group is exactly ``image(idx[r])``."""
         ok = self._order[self.status[self._order] == 0]
         i = 0
         while i < len(ok):
             h, w = int(self.height[ok[i]]), int(self.width[ok[i]])
-            j = i
-            while j < len(ok) and int(self.height[ok[j]]) == h and int(self.width[ok[j]]) == w:
+            step = h * w * 3
+            j = i + 1
+            while (j < len(ok) and int(self.height[ok[j]]) == h and int(self.width[ok[j]]) == w
+                   and int(self._off[ok[j]]) == int(self._off[ok[j - 1]]) + step):
                 j += 1
             idx = ok[i:j]
             o = int(self._off[idx[0]])

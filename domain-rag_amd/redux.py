@@ -19,6 +19,12 @@ from .vit import VitConfig, VitHIP
 T5_TOKENS, T5_DIM, POOLED_DIM = 512, 4096, 768
 
 
+def param_shapes(siglip_dim: int = 1152, txt_dim: int = T5_DIM) -> dict:
+    """tensor name -> shape of FLUX.1-Redux-dev/image_embedder (ReduxImageEncoder)"""
+    mid = 3 * txt_dim
+    return {"redux_up.weight": (mid, siglip_dim), "redux_up.bias": (mid,), "redux_down.weight": (txt_dim, mid), "redux_down.bias": (txt_dim,)}
+
+
 def init_redux_params(siglip_dim: int = 1152, txt_dim: int = T5_DIM, seed: int = 0, device="cpu", dtype=torch.bfloat16):
     """ReduxImageEncoder: redux_up Linear(siglip_dim, 3*txt_dim), SiLU, redux_down Linear(3*txt_dim, txt_dim)"""
     g = torch.Generator(device=device).manual_seed(seed)

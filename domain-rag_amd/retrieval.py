@@ -130,6 +130,25 @@ class ClipImageModel:
         return ops.l2_normalize_(self.encode_image(image).clone())
 
 
+def weights_fingerprint(g: dict) -> str:
+    """identity of what an embedding depends on (stage 1 stores it next to its feature caches).  Every tensor takes part
+    (a fine-tuned tower that shares its projection and patch embedding with the stock one must not pass for it): small
+    tensors whole, large ones through ~4096 evenly strided elements plus their float64 sum"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(g):
+        if not torch.is_tensor(g[name]):
+            continue
+        a = g[name].detach().to("cpu", torch.float32).contiguous().reshape(-1)
+        h.update(name.encode()); h.update(str(tuple(g[name].shape)).encode())
+        if a.numel() <= 65536:
+            h.update(a.numpy().tobytes())
+        else:
+            h.update(a[:: a.numel() // 4096].contiguous().numpy().tobytes())
+            h.update(a.double().sum().numpy().tobytes())
+    return h.hexdigest()[:16]
+
+
 def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None = None, seed: int = 0, precision: str | None = None):
     """(model, preprocess).  ``weights``: an openai-CLIP state_dict (or a path to one saved with torch.save);
     None -> seeded synthetic weights of the ViT-B/32 architecture (no checkpoints offline).
@@ -155,13 +174,8 @@ def load_clip(name: str = "ViT-B/32", device="cuda", weights: str | dict | None 
         g = init_generic_params(cfg, seed, device=device if str(device) != "cpu" else "cpu")
     tower = ClipVitF32HIP(cfg, g, device) if precision == "fp32" else VitHIP(cfg, g, device)
     model = ClipImageModel(tower)
-    # identity of what an embedding depends on (stage 1 stores it next to its feature caches)
-    import hashlib
-    h = hashlib.sha256()
-    for name in ("proj", "patch.weight", "ln_post.weight"):
-        a = g[name].detach().to("cpu", torch.float32).contiguous().numpy()
-        h.update(name.encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
-    model.fingerprint = ("synthetic-seed%d-" % seed if weights is None else "") + h.hexdigest()[:16]
+    h = weights_fingerprint(g)
+    model.fingerprint = ("synthetic-seed%d-" % seed if weights is None else "") + h
     model.precision = precision
     return model, clip_preprocess
 

@@ -42,7 +42,7 @@ def fill_pipeline(tp, tcfg, vp, vae_kw, image_u8, mask_u8, prompt_embeds, pooled
 
 
 def txt2img_pipeline(tp, tcfg, vp, vae_kw, prompt_embeds, pooled, guidance_scale, num_inference_steps, height, width,
-                     noise_tokens, dtype=torch.bfloat16):
+                     noise_tokens, dtype=torch.bfloat16, taps=None):
     """FluxPipeline.__call__(prompt_embeds=..., pooled_prompt_embeds=..., guidance_scale, num_inference_steps, height,
     width, generator) as stage 2 calls it (batch_generate_flux_kshot.py:467-474); ``noise_tokens`` = packed generator draw."""
     B = prompt_embeds.shape[0]
@@ -56,4 +56,6 @@ def txt2img_pipeline(tp, tcfg, vp, vae_kw, prompt_embeds, pooled, guidance_scale
         v = oflux.flux_forward(tp, tcfg, lat, prompt_embeds.to(dtype), pooled.to(dtype), t, img_ids, txt_ids, guidance,
                                time_dtype=torch.bfloat16)
         lat = oflux.euler_step(lat, v, sigmas[i], sigmas[i + 1])
+        if taps is not None:
+            taps[f"lat.{i}"] = lat.clone()
     return ovae.decode_tokens_to_u8(vp, lat, h, w, **vae_kw)

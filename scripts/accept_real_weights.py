@@ -21,6 +21,9 @@ then runs this repository's HIP path (``domain_rag_amd.compat`` classes — the 
 per-step latent deltas, final-pixel deltas and top-100 index equality to a JSON report with a pass/fail verdict against
 BASELINE.json's bars: top-k indices bit-exact, pixels within 1e-2 (relative to full scale) of the reference on identical seeds.
 
+Before any arithmetic it compares the KEY SETS and shapes of the real checkpoint files (safetensors headers of the transformer, VAE,
+SigLIP image encoder and Redux embedder directories) with what this repository's loaders expect, and stops there if they differ.
+
 Exit codes: 0 all requested sections pass; 1 a section fails; 2 the reference stack / checkpoints are not available here (the
 report lists what is missing — that is the expected outcome inside the build container).
 
@@ -104,6 +107,79 @@ def probe(model_root: str, sections) -> dict:
     if "retrieval" in sections and not os.path.isfile(clip_pt):
         missing.append(f"CLIP checkpoint {clip_pt} (openai-CLIP's download cache, or $DRAG_CLIP_WEIGHTS)")
     return {"missing": sorted(set(missing)), "clip_checkpoint": clip_pt}
+
+
+# --------------------------------------------------------------------------------------------------- checkpoint layout
+def compare_key_sets(found: dict, expected: dict, ignore_prefixes=()) -> dict:
+    """found / expected: tensor name -> shape.  Equality of the KEY SETS and of every shape is the first thing checked against
+    real files, before any arithmetic: a renamed, missing or transposed tensor is a loading bug, not a numerics delta."""
+    fk = {k for k in found if not any(k.startswith(pre) for pre in ignore_prefixes)}
+    ek = set(expected)
+    missing, unexpected = sorted(ek - fk), sorted(fk - ek)
+    shapes = {k: {"file": list(found[k]), "expected": list(expected[k])} for k in sorted(ek & fk) if tuple(found[k]) != tuple(expected[k])}
+    return {"tensors_in_file": len(fk), "tensors_expected": len(ek), "missing_from_file": missing[:20], "n_missing": len(missing),
+            "unexpected_in_file": unexpected[:20], "n_unexpected": len(unexpected), "shape_mismatch": dict(list(shapes.items())[:20]),
+            "n_shape_mismatch": len(shapes), "pass": not missing and not unexpected and not shapes}
+
+
+def safetensors_dir_shapes(path: str) -> dict:
+    """tensor name -> shape of every *.safetensors shard under ``path``, from the file headers alone (no tensor is read)"""
+    from safetensors import safe_open
+    out = {}
+    for f in sorted(os.listdir(path)):
+        if f.endswith(".safetensors"):
+            with safe_open(os.path.join(path, f), framework="pt") as sf:
+                for k in sf.keys():
+                    out[k] = tuple(sf.get_slice(k).get_shape())
+    if not out:
+        raise FileNotFoundError(f"no .safetensors under {path}")
+    return out
+
+
+def expected_siglip_shapes(cfg) -> dict:
+    """transformers SiglipVisionModel names (what FLUX.1-Redux-dev/image_encoder holds and vit.siglip_to_generic consumes)"""
+    D, F, L, T = cfg.hidden, cfg.intermediate, cfg.layers, cfg.tokens
+    p = "vision_model."
+    s = {p + "embeddings.patch_embedding.weight": (D, 3, cfg.patch_size, cfg.patch_size), p + "embeddings.patch_embedding.bias": (D,),
+         p + "embeddings.position_embedding.weight": (T, D), p + "post_layernorm.weight": (D,), p + "post_layernorm.bias": (D,)}
+    for i in range(L):
+        b = f"{p}encoder.layers.{i}."
+        for n in ("layer_norm1", "layer_norm2"):
+            s[b + n + ".weight"], s[b + n + ".bias"] = (D,), (D,)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[b + "self_attn." + n + ".weight"], s[b + "self_attn." + n + ".bias"] = (D, D), (D,)
+        s[b + "mlp.fc1.weight"], s[b + "mlp.fc1.bias"] = (F, D), (F,)
+        s[b + "mlp.fc2.weight"], s[b + "mlp.fc2.bias"] = (D, F), (D,)
+    return s
+
+
+def section_checkpoints(args, info) -> dict:
+    """key-set + shape equality between the real checkpoint files and what this repository's loaders expect
+    (batch_generate_flux_kshot.py:117-153, outpainting_updown_sampling_redux.py:500-543 load the same directories)"""
+    from domain_rag_amd import flux_params, redux, vae, vit
+    out, ok = {}, True
+    sections = info.get("sections", ())
+    kinds = [k for k, sec in (("FLUX.1-dev", "stage2"), ("FLUX.1-Fill-dev", "stage3")) if sec in sections]
+    for d in kinds:
+        root = os.path.join(args.model_root, d)
+        cfg = flux_params.FluxConfig.from_json(os.path.join(root, "transformer", "config.json"))
+        out[d + "/transformer"] = compare_key_sets(safetensors_dir_shapes(os.path.join(root, "transformer")), flux_params.param_shapes(cfg))
+        # the VAE files also carry the encoder's / decoder's mid-block attention under legacy names in some exports and the
+        # (unused here) quant convs: everything the loader needs must be there with the right shape, extras are listed
+        out[d + "/vae"] = compare_key_sets(safetensors_dir_shapes(os.path.join(root, "vae")), vae.param_shapes(vae.VaeConfig()),
+                                           ignore_prefixes=("quant_conv.", "post_quant_conv."))
+    if kinds:
+        root = os.path.join(args.model_root, "FLUX.1-Redux-dev")
+        vcfg = vit.VitConfig.siglip_so400m()
+        # SiglipVisionModel's pooling head is in the file and not on the path (last_hidden_state is what Redux consumes)
+        out["FLUX.1-Redux-dev/image_encoder"] = compare_key_sets(safetensors_dir_shapes(os.path.join(root, "image_encoder")),
+                                                                 expected_siglip_shapes(vcfg), ignore_prefixes=("vision_model.head.",))
+        out["FLUX.1-Redux-dev/image_embedder"] = compare_key_sets(safetensors_dir_shapes(os.path.join(root, "image_embedder")),
+                                                                  redux.param_shapes(vcfg.hidden, 4096))
+    for v in out.values():
+        ok = ok and v["pass"]
+    out["pass"] = ok
+    return out
 
 
 # --------------------------------------------------------------------------------------------------- sections
@@ -292,6 +368,18 @@ def main(argv=None) -> int:
         print(json.dumps(report, indent=2))
         return 2
     ok = True
+    # checkpoint layout first: no arithmetic is compared over weights that did not load the way the reference loads them
+    info["sections"] = sections
+    try:
+        report["checkpoints"] = section_checkpoints(args, info)
+    except Exception as e:  # noqa: BLE001
+        report["checkpoints"] = {"pass": False, "error": f"{type(e).__name__}: {e}"}
+    if not report["checkpoints"]["pass"]:
+        report["verdict"] = "fail: checkpoint key sets / shapes differ from what the loaders expect (arithmetic sections not run)"
+        with open(args.out, "w") as f:
+            json.dump(report, f, indent=2)
+        print(json.dumps(report["checkpoints"], indent=2))
+        return 1
     for s in sections:
         try:
             report[s] = SECTIONS[s](args, info)

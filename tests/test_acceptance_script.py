@@ -48,3 +48,37 @@ def test_without_the_reference_stack_it_says_what_is_missing_and_exits_2(tmp_pat
     rep = json.load(open(out))
     assert rep["verdict"].startswith("not-run")
     assert any("FLUX.1-Fill-dev" in m for m in rep["missing"]) and any("--target" in m for m in rep["missing"])
+
+
+def test_checkpoint_key_sets_are_compared_before_any_arithmetic(tmp_path):
+    """real-checkpoint loading is checked on KEY SETS + shapes first (safetensors headers only): a directory written from this
+    repository's own expected layout passes; a renamed tensor, a missing one and a transposed one are each reported"""
+    import torch
+    from safetensors.torch import save_file
+    from domain_rag_amd import flux_params, redux, vit
+    cfg = flux_params.FluxConfig(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32)
+    exp = flux_params.param_shapes(cfg)
+    d = tmp_path / "transformer"; d.mkdir()
+    names = sorted(exp)
+    half = len(names) // 2                                # two shards, like the real 3-shard transformer directory
+    save_file({k: torch.zeros(exp[k], dtype=torch.bfloat16) for k in names[:half]}, str(d / "a.safetensors"))
+    save_file({k: torch.zeros(exp[k], dtype=torch.bfloat16) for k in names[half:]}, str(d / "b.safetensors"))
+    found = acc.safetensors_dir_shapes(str(d))
+    r = acc.compare_key_sets(found, exp)
+    assert r["pass"] and r["tensors_in_file"] == len(exp) == r["tensors_expected"]
+    bad = dict(found)
+    bad["transformer_blocks.0.attn.to_q.weight_renamed"] = bad.pop("transformer_blocks.0.attn.to_q.weight")
+    del bad["proj_out.bias"]
+    bad["x_embedder.weight"] = tuple(reversed(bad["x_embedder.weight"]))
+    r = acc.compare_key_sets(bad, exp)
+    assert not r["pass"] and r["n_missing"] == 2 and r["n_unexpected"] == 1 and list(r["shape_mismatch"]) == ["x_embedder.weight"]
+    assert "proj_out.bias" in r["missing_from_file"] and r["unexpected_in_file"] == ["transformer_blocks.0.attn.to_q.weight_renamed"]
+    # extras the loaders do not consume are ignored only when named
+    extra = dict(found); extra["vision_model.head.probe"] = (1, 1, 8)
+    assert not acc.compare_key_sets(extra, exp)["pass"] and acc.compare_key_sets(extra, exp, ignore_prefixes=("vision_model.head.",))["pass"]
+    # the SigLIP name table matches what siglip_to_generic reads
+    vc = vit.VitConfig(image_size=56, patch_size=14, hidden=64, heads=2, layers=2, intermediate=96)
+    sd = {k: torch.zeros(s) for k, s in acc.expected_siglip_shapes(vc).items()}
+    g = vit.siglip_to_generic(sd, vc)
+    assert g["patch.weight"].shape == (64, 3 * 14 * 14) and g["l1.fc2.weight"].shape == (64, 96) and g["pos"].shape == (vc.tokens, 64)
+    assert set(redux.param_shapes(64, 32)) == set(redux.init_redux_params(64, 32))

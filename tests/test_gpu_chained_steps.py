@@ -1,0 +1,158 @@
+"""The metric's CHAINED denoise loop against the oracle, step by step: 30 Flux-Fill steps at strength 1.0
+(outpainting_updown_sampling_redux.py:1246-1257; int(50 * 0.6) = 30 is the reference's Camouflage setting, :40) and the 50
+txt2img steps of stage 2 (batch_generate_flux_kshot.py:467-474), identical seeds, at a size the CPU oracle affords: the real
+width (D = 3072, 24 heads x 128, joint dim 4096, pooled 768, the full VAE) with 4 double + 8 single blocks (2 + 4 for the
+50-step run) at 256 x 256 pixels.
+
+Chained steps amplify rounding (SURVEY §7 "hard parts"), so the comparison is per step: after every Euler update the packed
+latents of the HIP path and of the reference-dtype (bf16) oracle are both measured against the float32 oracle.  Bars, written
+here: at EVERY step the HIP path's distance from float32 is at most 1.3 x the bf16 oracle's own distance (max-norm and rms,
+relative to the float32 latents' max / rms; a floor of 2e-3 covers the first steps, where both distances are a few bf16 ulps);
+the error may not grow faster than linearly in the step count; final pixels within max(1e-2, 1.3 x the bf16 oracle's distance) of
+full scale.  The per-step curves are printed and written to gpurun_out/ (the round's copy is committed under profiles/)."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RATIO = 1.3
+FLOOR = 2e-3
+
+
+def _dist(a, ref):
+    a, ref = a.double(), ref.double()
+    d = (a - ref).abs()
+    return (d.max() / ref.abs().max()).item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+def _curves(hip_lat, taps32, tapsbf, steps):
+    rows = []
+    for i in steps:
+        emax, erms = _dist(hip_lat[i], taps32[f"lat.{i}"])
+        omax, orms = _dist(tapsbf[f"lat.{i}"], taps32[f"lat.{i}"])
+        rows.append({"step": i, "hip_max": emax, "bf16_oracle_max": omax, "hip_rms": erms, "bf16_oracle_rms": orms,
+                     "ratio_max": emax / max(omax, 1e-30), "ratio_rms": erms / max(orms, 1e-30)})
+    return rows
+
+
+def _check(rows, what):
+    for r in rows:
+        msg = (f"{what} step {r['step']}: HIP vs f32 max {r['hip_max']:.3e} rms {r['hip_rms']:.3e}; bf16 oracle vs f32 max "
+               f"{r['bf16_oracle_max']:.3e} rms {r['bf16_oracle_rms']:.3e}; ratio max {r['ratio_max']:.2f} rms {r['ratio_rms']:.2f}")
+        assert r["hip_max"] <= max(FLOOR, RATIO * r["bf16_oracle_max"]), msg
+        assert r["hip_rms"] <= max(FLOOR / 4, RATIO * r["bf16_oracle_rms"]), msg
+    # growth: from the first quarter on, the rms error grows at most linearly with the number of steps taken (a compounding
+    # error would grow geometrically); 1.5 x slack for the step-to-step scatter
+    n = len(rows)
+    k = max(n // 4, 1)
+    bound = 1.5 * (n / k) * max(rows[k - 1]["hip_rms"], FLOOR / 4)
+    assert rows[-1]["hip_rms"] <= bound, f"{what}: rms error {rows[k - 1]['hip_rms']:.3e} after {k} steps -> {rows[-1]['hip_rms']:.3e} after {n}: super-linear"
+
+
+def _report(name, rows, extra):
+    print(f"[chained] {name}: step | HIP-f32 max  rms | bf16oracle-f32 max  rms | ratio max rms", flush=True)
+    for r in rows:
+        print(f"[chained] {name}: {r['step']:3d} | {r['hip_max']:.3e} {r['hip_rms']:.3e} | {r['bf16_oracle_max']:.3e} {r['bf16_oracle_rms']:.3e} | "
+              f"{r['ratio_max']:.2f} {r['ratio_rms']:.2f}", flush=True)
+    print(f"[chained] {name}: {json.dumps(extra)}", flush=True)
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"chained_steps_{name}.json"), "w") as f:
+            json.dump({"rows": rows, **extra}, f, indent=1)
+
+
+def _setup(in_channels, layers, single_layers, seed, gpu, guidance_embeds=True):
+    from domain_rag_amd import vae
+    from domain_rag_amd.flux_params import FluxConfig, init_params
+    from oracle import flux as oflux
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    cfg = FluxConfig(in_channels=in_channels, num_layers=layers, num_single_layers=single_layers, guidance_embeds=guidance_embeds)
+    assert (cfg.dim, cfg.num_attention_heads, cfg.joint_attention_dim, cfg.pooled_projection_dim) == (3072, 24, 4096, 768)
+    tp_dev = init_params(cfg, seed=seed, device=gpu)
+    tp = {k: v.cpu() for k, v in tp_dev.items()}
+    vcfg = vae.VaeConfig()
+    vp = vae.init_params(vcfg, seed=seed + 1)
+    ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    return cfg, ocfg, tp_dev, tp, vcfg, vp
+
+
+def test_fill_30_chained_steps_vs_oracle_per_step(gpu):
+    from domain_rag_amd import fill_pipeline as fp, vae
+    from domain_rag_amd.flux import FluxTransformerHIP
+    from oracle import fill as ofill
+    t_start = time.time()
+    res, steps, strength, St = 256, 30, 1.0, 48
+    cfg, ocfg, tp_dev, tp, vcfg, vp = _setup(384, 4, 8, 20, gpu)
+    g = torch.Generator().manual_seed(21)
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    base = torch.stack([128 + 90 * torch.sin(xx / 23.0 + c) * torch.cos(yy / 17.0 - c) for c in range(3)], -1)
+    image = (base + 8 * torch.randn(res, res, 3, generator=g)).clamp(0, 255).to(torch.uint8)[None]
+    mask = torch.full((1, res, res), 255, dtype=torch.uint8); mask[:, 90:166, 80:170] = 0
+    pe = torch.randn(1, St, 4096, generator=g).bfloat16(); pp = torch.randn(1, 768, generator=g).bfloat16()
+    en = torch.randn(1, 16, res // 8, res // 8, generator=g).bfloat16()
+    mn = torch.randn(1, 16, res // 8, res // 8, generator=g).bfloat16()
+    nt = torch.randn(1, (res // 16) ** 2, 64, generator=g).bfloat16()
+
+    fill = fp.FluxFillHIP(FluxTransformerHIP(cfg, tp_dev, gpu), vae.FluxVaeHIP(vcfg, vp, gpu))
+    hip_lat = {}
+    out = fill(image.to(gpu), mask.to(gpu), pe.to(gpu), pp.to(gpu), guidance_scale=30.0, num_inference_steps=steps, strength=strength,
+               enc_noise=en.to(gpu), masked_enc_noise=mn.to(gpu), noise_tokens=nt.to(gpu),
+               on_step=lambda i, lat: hip_lat.__setitem__(i, lat.float().cpu())).cpu()
+    del fill, tp_dev
+    torch.cuda.empty_cache()
+    assert sorted(hip_lat) == list(range(steps))
+    taps, imgs = {}, {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
+        taps[name] = {}
+        with torch.no_grad():
+            _, img = ofill.fill_pipeline(cast(tp), ocfg, cast(vp), dict(block_out=vcfg.block_out_channels, layers=vcfg.layers_per_block),
+                                         image, mask, pe, pp, 30.0, steps, strength, en, mn, nt, dtype=dt, taps=taps[name])
+        imgs[name] = img.float()
+    rows = _curves(hip_lat, taps["f32"], taps["bf16"], range(steps))
+    hip = out.float() / 255.0
+    e = (hip - imgs["f32"].permute(0, 2, 3, 1)).abs().max().item()
+    e_or = (imgs["bf16"] - imgs["f32"]).abs().max().item()
+    _report("fill30", rows, {"pipeline": "Fill, 30 steps, strength 1.0, 256x256, 4 double + 8 single blocks at D=3072", "pixels_hip_vs_f32": e,
+                             "pixels_bf16_oracle_vs_f32": e_or, "pixel_ratio": e / max(e_or, 1e-30), "seconds": time.time() - t_start})
+    _check(rows, "Fill x30")
+    assert e <= max(1e-2 + 0.5 / 255, RATIO * e_or), f"pixels: HIP vs f32 {e:.4f}, bf16 oracle vs f32 {e_or:.4f}, ratio {e / max(e_or, 1e-30):.2f}"
+
+
+def test_txt2img_50_chained_steps_vs_oracle_per_step(gpu):
+    from domain_rag_amd import vae
+    from domain_rag_amd.engine import FluxTxt2ImgHIP, generator_noise, pack_noise
+    from domain_rag_amd.flux import FluxTransformerHIP
+    from oracle import fill as ofill
+    t_start = time.time()
+    res, steps, St = 256, 50, 48
+    cfg, ocfg, tp_dev, tp, vcfg, vp = _setup(64, 2, 4, 30, gpu)
+    g = torch.Generator().manual_seed(31)
+    pe = torch.randn(1, St, 4096, generator=g).bfloat16(); pp = torch.randn(1, 768, generator=g).bfloat16()
+    noise = pack_noise(generator_noise(0, 1, res, res, 1)[0])          # stage 2's CPU generator, seed 0 (batch_...:52-61)
+    pipe = FluxTxt2ImgHIP(FluxTransformerHIP(cfg, tp_dev, gpu), vae.FluxVaeHIP(vcfg, vp, gpu))
+    hip_lat = {}
+    out = pipe(pe.to(gpu), pp.to(gpu), height=res, width=res, guidance_scale=2.5, num_inference_steps=steps, noise_tokens=noise.to(gpu),
+               on_step=lambda i, lat: hip_lat.__setitem__(i, lat.float().cpu())).cpu()
+    del pipe, tp_dev
+    torch.cuda.empty_cache()
+    taps, imgs = {}, {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
+        taps[name] = {}
+        with torch.no_grad():
+            _, img = ofill.txt2img_pipeline(cast(tp), ocfg, cast(vp), dict(block_out=vcfg.block_out_channels, layers=vcfg.layers_per_block),
+                                            pe, pp, 2.5, steps, res, res, noise, dtype=dt, taps=taps[name])
+        imgs[name] = img.float()
+    rows = _curves(hip_lat, taps["f32"], taps["bf16"], range(steps))
+    hip = out.float() / 255.0
+    e = (hip - imgs["f32"].permute(0, 2, 3, 1)).abs().max().item()
+    e_or = (imgs["bf16"] - imgs["f32"]).abs().max().item()
+    _report("txt2img50", rows, {"pipeline": "txt2img, 50 steps, guidance 2.5, 256x256, 2 double + 4 single blocks at D=3072", "pixels_hip_vs_f32": e,
+                                "pixels_bf16_oracle_vs_f32": e_or, "pixel_ratio": e / max(e_or, 1e-30), "seconds": time.time() - t_start})
+    _check(rows, "txt2img x50")
+    assert e <= max(1e-2 + 0.5 / 255, RATIO * e_or), f"pixels: HIP vs f32 {e:.4f}, bf16 oracle vs f32 {e_or:.4f}, ratio {e / max(e_or, 1e-30):.2f}"

@@ -3,6 +3,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+SLACK = 1.3      # HIP may sit at most this factor further from float32 than the reference-dtype (bf16) oracle does
 
 
 def _setup(cfg_kw, B, St, h, w, seed=0):
@@ -51,7 +52,7 @@ def test_flux_forward_vs_oracle(gpu, B, St, h, w, nl, ns, inch):
     e_bf16, e_f32 = rel(out, ref), rel(out, ref32)
     e_oracle = rel(ref, ref32)  # how far the bf16 oracle itself sits from fp32
     assert e_bf16 < 2e-2, (e_bf16, e_f32, e_oracle)
-    assert e_f32 < max(1e-2, 2.5 * e_oracle), (e_bf16, e_f32, e_oracle)
+    assert e_f32 < max(1e-2, SLACK * e_oracle), f"HIP vs f32 {e_f32:.4e}, bf16 oracle vs f32 {e_oracle:.4e}, ratio {e_f32 / max(e_oracle, 1e-30):.2f} (bar {SLACK}); HIP vs bf16 oracle {e_bf16:.4e}"
 
 
 def test_flux_depth_error_growth(gpu):

@@ -29,13 +29,20 @@ def test_full_size_flux_blocks_vs_oracle(gpu):
     t, gd = torch.tensor([0.6172]), torch.tensor([30.0])
     img_ids, txt_ids = latent_image_ids(h, w), torch.zeros(St, 3)
     ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
-    taps_ref, taps = {}, {}
+    taps_ref, taps32, taps = {}, {}, {}
+    p32 = {k: v.float() for k, v in params.items()}
     with torch.no_grad():
         ref = oflux.flux_forward(params, ocfg, hidden, enc, pooled, t, img_ids, txt_ids, gd, taps=taps_ref)
+        ref32 = oflux.flux_forward(p32, ocfg, hidden.float(), enc.float(), pooled.float(), t, img_ids, txt_ids, gd, taps=taps32,
+                                   time_dtype=torch.bfloat16)
     out = FluxTransformerHIP(cfg, params, gpu)(hidden.to(gpu), enc.to(gpu), pooled.to(gpu), t, img_ids, txt_ids, gd, taps=taps)
-    assert _rel(taps["double.0"], taps_ref["double.0"]) < 2e-2
-    assert _rel(taps["single.0"], taps_ref["single.0"]) < 2e-2
-    assert _rel(out, ref) < 2e-2
+    # bar (round 3): the HIP path sits at most 1.3 x as far from float32 as the reference-dtype (bf16) oracle does (floor 1e-2, north_star's
+    # figure); the fixed 2e-2 against the bf16 oracle stays as a second, absolute check
+    for name, got, rbf, r32 in (("double.0", taps["double.0"], taps_ref["double.0"], taps32["double.0"]),
+                                ("single.0", taps["single.0"], taps_ref["single.0"], taps32["single.0"]), ("out", out, ref, ref32)):
+        e, e_or = _rel(got, r32), _rel(rbf, r32)
+        assert e < max(1e-2, 1.3 * e_or), f"{name}: HIP vs f32 {e:.4e}, bf16 oracle vs f32 {e_or:.4e}, ratio {e / max(e_or, 1e-30):.2f} (bar 1.3)"
+        assert _rel(got, rbf) < 2e-2, name
 
 
 def test_full_size_attention_properties(gpu):

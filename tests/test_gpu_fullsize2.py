@@ -30,11 +30,19 @@ def _rand(shape, seed, scale=1.0):
 ORACLE_THREADS = 64      # the oracle's convolutions / GEMMs scale badly past this on a 256-core host (measured: 4x slower at 256)
 
 
+SLACK = 1.3
+
+
+def _msg(what, e, e_or):
+    return f"{what}: HIP vs f32 {e:.4e}, bf16 oracle vs f32 {e_or:.4e}, ratio {e / max(e_or, 1e-30):.2f} (bar {SLACK})"
+
+
 def _tol(e_bf16_oracle, floor):
     """The reference computes in torch.bfloat16 (batch_generate_flux_kshot.py:49, outpainting_updown_sampling_redux.py:28), so
     its own arithmetic sits e_bf16_oracle away from the float32 truth (2e-2 for the VAE with random weights — measured,
-    tests/tools/explore_fullsize_errors.py).  Stated bar: HIP within max(floor, 2.5 x that distance) of float32."""
-    return max(floor, 2.5 * e_bf16_oracle)
+    tests/tools/explore_fullsize_errors.py).  Stated bar: HIP within max(floor, 1.3 x that distance) of float32 (round 3: was 2.5 x; the measured ratio is 0.9-1.1,
+    so a kernel regression that doubled the error used to pass)."""
+    return max(floor, SLACK * e_bf16_oracle)
 
 
 def test_vae_full_size_decode_and_encodes_vs_oracle(gpu):
@@ -56,9 +64,9 @@ def test_vae_full_size_decode_and_encodes_vs_oracle(gpu):
         _, ref32 = ov.decode_tokens_to_u8(p32, tok[:1].float(), h, w)
         _, refbf = ov.decode_tokens_to_u8(p, tok[:1], h, w)
     e, e_or = _rel(got[:1], ref32), _rel(refbf, ref32)
-    assert e < _tol(e_or, 1e-2), ("decode", e, e_or)
+    assert e < _tol(e_or, 1e-2), _msg("decode", e, e_or)
     d = (img_u8[0].int() - (ref32[0].permute(1, 2, 0) * 255).round().int()).abs()
-    assert d.max().item() <= max(3.0, 255 * 2.5 * e_or), ("pixels", d.max().item(), e_or)
+    assert d.max().item() <= max(3.0, 255 * SLACK * e_or), _msg("pixel levels / 255", d.max().item() / 255, e_or)
     assert d.float().mean().item() < 1.0, d.float().mean().item()          # on average well under one level
     del ref32, refbf
     alone = model.decode_tokens(tok[1:2].to(gpu), 1, h, w).cpu()
@@ -83,7 +91,7 @@ def test_vae_full_size_decode_and_encodes_vs_oracle(gpu):
             ref = ov.pack_latents(ov.sample_latents(ov.encode_moments(p32, x), None if nz is None else nz[:1].float()))
             refb = ov.pack_latents(ov.sample_latents(ov.encode_moments(p, x.bfloat16()), None if nz is None else nz[:1]))
         e, e_or = _rel(toks[:1], ref), _rel(refb, ref)
-        assert e < _tol(e_or, 1.5e-2), ("encode", use_mask, e, e_or)
+        assert e < _tol(e_or, 1.5e-2), _msg(f"encode mask={use_mask}", e, e_or)
 
 
 def test_siglip_so400m_full_config_vs_transformers(gpu):
@@ -101,7 +109,7 @@ def test_siglip_so400m_full_config_vs_transformers(gpu):
     refbf = ov.siglip_last_hidden_state(g, 384, 14, 1152, 16, 27, 4304, px[:1], torch.bfloat16)
     # the reference runs SigLIP in torch.bfloat16 (batch_generate_flux_kshot.py:49,139): bar = 2.5 x its own distance from fp32
     e, e_or = _rel(out[:1], ref32), _rel(refbf, ref32)
-    assert e < _tol(e_or, 1.5e-2), (e, e_or)
+    assert e < _tol(e_or, 1.5e-2), _msg("siglip", e, e_or)
     m = ((out[:1].float().cpu() - ref32).abs().mean() / ref32.abs().mean()).item()
     m_or = ((refbf.float() - ref32).abs().mean() / ref32.abs().mean()).item()
     assert m < max(1e-2, 1.5 * m_or), (m, m_or)
@@ -135,6 +143,11 @@ def test_full_size_dit_blocks_batch8_rows_are_images(gpu):
         for i in (0, 7):
             ref = oflux.flux_forward(params, ocfg, hidden[i:i + 1], enc[i:i + 1], pooled[i:i + 1], t[:1], img_ids, txt_ids, gd[:1])
             assert _rel(out8[i:i + 1], ref) < 2e-2, i
+            if i == 7:          # the ratio bar against float32 on one image (the float32 oracle doubles the host time)
+                ref32 = oflux.flux_forward({k: v.float() for k, v in params.items()}, ocfg, hidden[i:i + 1].float(), enc[i:i + 1].float(),
+                                           pooled[i:i + 1].float(), t[:1], img_ids, txt_ids, gd[:1], time_dtype=torch.bfloat16)
+                e, e_or = _rel(out8[i:i + 1], ref32), _rel(ref, ref32)
+                assert e < _tol(e_or, 1e-2), _msg(f"B=8 row {i}", e, e_or)
 
 
 def test_sharded_gather_order_equals_single_order(gpu):

@@ -1,9 +1,13 @@
 """BASELINE configs[2] at FULL size, end to end, against the CPU oracle: the complete FLUX.1-Fill-dev architecture (19 double + 38
 single blocks, D = 3072, S = 1241 + 4096), the full VAE, SigLIP-so400m + Redux, one 1024x1024 image + mask, 2 denoise steps at
-strength 1.0, identical seeds -> composited uint8 pixels.  The oracle runs the whole thing twice on the host (float32 yardstick and
-the reference's bfloat16), about ten minutes of CPU work, so the test only runs with DRAG_FULLSIZE_E2E=1; the log of the round's run
-is committed as profiles/r02_fullsize_e2e.log.  Bar (the pipeline tests' own): within max(1e-2, 2.5 x the bf16 oracle's distance
-from float32) of full scale."""
+strength 1.0, identical seeds -> composited uint8 pixels.
+
+Default (round 3: part of every `-m gpu` run, about two minutes of host time): the oracle runs ONCE, in the reference's dtype (bfloat16);
+bar: the HIP path's uint8 pixels differ from the bf16 oracle's by at most 1.3 levels on average and 12 levels anywhere (two bf16
+evaluations of the same graph with different summation orders; measured 0.87 / 7 — a kernel regression that doubled the HIP path's
+error would put the mean near 1.7).  With DRAG_FULLSIZE_E2E=1 the float32 yardstick runs as well (+4 min) and the ratio bar of the
+other pipeline tests applies: HIP within max(1e-2, 1.3 x the bf16 oracle's own distance from float32) of full scale, max and mean.
+The round's log is committed under profiles/."""
 import os
 import time
 
@@ -13,7 +17,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(os.environ.get("DRAG_FULLSIZE_E2E") != "1", reason="~10 min of host time (57-block DiT on the CPU, twice): set DRAG_FULLSIZE_E2E=1")
 def test_fullsize_fill_pipeline_vs_oracle(gpu):
     from domain_rag_amd import fill_pipeline as fp, redux, vae, vit
     from domain_rag_amd.flux import FluxTransformerHIP
@@ -57,7 +60,8 @@ def test_fullsize_fill_pipeline_vs_oracle(gpu):
 
     res_or = {}
     ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
-    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+    with_f32 = os.environ.get("DRAG_FULLSIZE_E2E") == "1"
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32))[: 2 if with_f32 else 1]:
         cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
         with torch.no_grad():
             lat = ovit.siglip_last_hidden_state(vitp, 384, 14, 1152, 16, 27, 4304, ovit.normalize_u8(bg, vitcfg.mean, vitcfg.std), dt)
@@ -66,17 +70,21 @@ def test_fullsize_fill_pipeline_vs_oracle(gpu):
                                           image, mask, pes, pps, 30.0, steps, strength, en, mn, nt, dtype=dt)
         res_or[name] = (u8, img.float())
         print(f"[e2e] oracle {name} done {time.time() - t0:.0f} s", flush=True)
-    ref_img = res_or["f32"][1]
-    e_or = (res_or["bf16"][1] - ref_img).abs().max().item()
-    hip = out.float() / 255.0
-    e = (hip - ref_img.permute(0, 2, 3, 1)).abs().max().item()
-    e_vs_bf = (hip - res_or["bf16"][1].permute(0, 2, 3, 1)).abs().max().item()
-    m = (hip - ref_img.permute(0, 2, 3, 1)).abs().mean().item()
-    m_or = (res_or["bf16"][1] - ref_img).abs().mean().item()
-    lv = (out.int() - res_or["bf16"][0].int()).abs()
-    print(f"[e2e] full-size Fill pipeline, {steps} steps @ {res}^2: max |HIP - f32 oracle| {e:.4f} of full scale (mean {m:.5f}); "
-          f"bf16 oracle vs f32 oracle max {e_or:.4f} (mean {m_or:.5f}); HIP vs bf16 oracle max {e_vs_bf:.4f}; "
-          f"uint8 levels vs bf16 oracle: max {lv.max().item()}, mean {lv.float().mean().item():.3f}, identical {100 * (lv == 0).float().mean().item():.1f} %", flush=True)
     assert out.shape == (1, res, res, 3) and out.dtype == torch.uint8
-    assert e < max(1e-2 + 0.5 / 255, 2.5 * e_or), (e, e_or)
-    assert m < max(2e-3, 2.5 * m_or), (m, m_or)
+    hip = out.float() / 255.0
+    lv = (out.int() - res_or["bf16"][0].int()).abs()
+    lv_max, lv_mean, same = lv.max().item(), lv.float().mean().item(), 100 * (lv == 0).float().mean().item()
+    e_vs_bf = (hip - res_or["bf16"][1].permute(0, 2, 3, 1)).abs().max().item()
+    print(f"[e2e] full-size Fill pipeline, {steps} steps @ {res}^2: HIP vs bf16 oracle max {e_vs_bf:.4f} of full scale; uint8 levels vs bf16 "
+          f"oracle: max {lv_max}, mean {lv_mean:.3f}, identical {same:.1f} %", flush=True)
+    assert lv_mean <= 1.3 and lv_max <= 12, f"uint8 levels vs the bf16 oracle: mean {lv_mean:.3f} (bar 1.3), max {lv_max} (bar 12), identical {same:.1f} %"
+    if with_f32:
+        ref_img = res_or["f32"][1]
+        e_or = (res_or["bf16"][1] - ref_img).abs().max().item()
+        e = (hip - ref_img.permute(0, 2, 3, 1)).abs().max().item()
+        m = (hip - ref_img.permute(0, 2, 3, 1)).abs().mean().item()
+        m_or = (res_or["bf16"][1] - ref_img).abs().mean().item()
+        print(f"[e2e] max |HIP - f32 oracle| {e:.4f} of full scale (mean {m:.5f}); bf16 oracle vs f32 oracle max {e_or:.4f} (mean {m_or:.5f}); "
+              f"ratios {e / max(e_or, 1e-30):.2f} / {m / max(m_or, 1e-30):.2f}", flush=True)
+        assert e < max(1e-2 + 0.5 / 255, 1.3 * e_or), f"max: HIP vs f32 {e:.4e}, bf16 oracle vs f32 {e_or:.4e}, ratio {e / max(e_or, 1e-30):.2f} (bar 1.3)"
+        assert m < max(2e-3, 1.3 * m_or), f"mean: HIP vs f32 {m:.4e}, bf16 oracle vs f32 {m_or:.4e}, ratio {m / max(m_or, 1e-30):.2f} (bar 1.3)"

@@ -150,3 +150,24 @@ def test_damaged_files_never_fault_the_gpu(gpu):
     # the device is still healthy and a clean file still decodes to PIL's bytes afterwards
     good = jpeg.decode_files([seeds[0]], gpu)
     assert np.array_equal(good.image(0).cpu().numpy(), pil_rgb(seeds[0]))
+
+
+def test_cut_short_file_between_same_size_files_does_not_shift_its_neighbours(gpu):
+    """a file cut in the middle of its scan keeps an output slot inside its size class (status 10 is known only after the
+    decode); groups() must still hand every good image its own pixels, and the corpus embedding route must give the files
+    behind it the embedding they get alone (jpeg.py groups())"""
+    from domain_rag_amd import jpeg
+    rng = np.random.default_rng(5)
+    files = [encode(natural_image(rng, 96, 128), quality=85, subsampling=2) for _ in range(7)]
+    files += [encode(natural_image(rng, 64, 64), quality=85) for _ in range(3)]
+    good = list(files)
+    for i in (2, 3, 8):
+        files[i] = files[i][: len(files[i]) * 3 // 5]
+    batch = jpeg.decode_files(files, gpu)
+    assert [int(s) for s in batch.status] == [10 if i in (2, 3, 8) else 0 for i in range(10)]
+    seen = []
+    for (h, w), idx, imgs in batch.groups():
+        for r, i in enumerate(idx.tolist()):
+            assert np.array_equal(imgs[r].cpu().numpy(), pil_rgb(good[i])), i
+        seen += idx.tolist()
+    assert sorted(seen) == [0, 1, 4, 5, 6, 7, 9]

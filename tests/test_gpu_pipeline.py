@@ -50,7 +50,7 @@ def test_fill_pipeline_vs_oracle(gpu):
         e_or = (res_or["bf16"][1] - ref_img).abs().max().item()      # bf16 oracle vs fp32 oracle, full scale = 1
         e = (out.float() / 255.0 - ref_img.permute(0, 2, 3, 1)).abs().max().item()
         assert out.shape == (B, res, res, 3) and out.dtype == torch.uint8
-        assert e < max(1e-2 + 0.5 / 255, 2.5 * e_or), (strength, e, e_or)
+        assert e < max(1e-2 + 0.5 / 255, 1.3 * e_or), f"strength {strength}: HIP vs f32 {e:.4e}, bf16 oracle vs f32 {e_or:.4e}, ratio {e / max(e_or, 1e-30):.2f} (bar 1.3)"
 
 
 @pytest.mark.parametrize("guidance_embeds,steps", [(True, 3), (False, 4)])
@@ -91,7 +91,7 @@ def test_txt2img_pipeline_vs_oracle(gpu, guidance_embeds, steps):
     e_or = (outs["bf16"] - outs["f32"]).abs().max().item()
     e = (out.float() / 255.0 - outs["f32"].permute(0, 2, 3, 1)).abs().max().item()
     assert out.shape == (1, res, res, 3)
-    assert e < max(1e-2 + 0.5 / 255, 2.5 * e_or), (e, e_or)
+    assert e < max(1e-2 + 0.5 / 255, 1.3 * e_or), f"HIP vs f32 {e:.4e}, bf16 oracle vs f32 {e_or:.4e}, ratio {e / max(e_or, 1e-30):.2f} (bar 1.3)"
 
 
 def test_prior_outputs_do_not_alias(gpu):

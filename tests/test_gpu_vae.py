@@ -97,10 +97,10 @@ def test_vae_decode_encode_vs_oracle(gpu, blocks, layers, B, h, w):
     H, W = img_u8.shape[1:3]
     got = (rows.view(B, H, W, -1)[..., :3].float().cpu() / 2 + 0.5).clamp(0, 1).permute(0, 3, 1, 2)
     e, e_or = _rel(got, ref32), _rel(ref_img, ref32)
-    assert e < max(1e-2, 2.5 * e_or), (e, e_or)
+    assert e < max(1e-2, 1.3 * e_or), f"decode: HIP vs f32 {e:.4e}, bf16 oracle vs f32 {e_or:.4e}, ratio {e / max(e_or, 1e-30):.2f} (bar 1.3)"
     # pixels: within 1e-2 relative of full scale (= 2.55 LSB) of the fp32 oracle's pixels
     d = (img_u8.cpu().int() - (ref32.permute(0, 2, 3, 1) * 255).round().int()).abs()
-    assert d.float().max().item() <= max(3.0, 255 * 2.5 * e_or), d.max()
+    assert d.float().max().item() <= max(3.0, 255 * 1.3 * e_or), f"pixel levels {d.max().item()}, bf16 oracle vs f32 {e_or:.4e} of full scale (bar 1.3 x)"
 
     # encode (mode and sampled) -> packed tokens
     S = cfg.downscale
@@ -118,7 +118,7 @@ def test_vae_decode_encode_vs_oracle(gpu, blocks, layers, B, h, w):
         ref = ov.pack_latents(ov.sample_latents(ov.encode_moments(p32, x, block_out=blocks, layers=layers), None if nz is None else nz.float()))
         refb = ov.pack_latents(ov.sample_latents(ov.encode_moments(p, x.bfloat16(), block_out=blocks, layers=layers), nz))
         e, e_or = _rel(toks, ref), _rel(refb, ref)
-        assert e < max(1.5e-2, 2.5 * e_or), (use_mask, e, e_or)
+        assert e < max(1.5e-2, 1.3 * e_or), f"encode mask={use_mask}: HIP vs f32 {e:.4e}, bf16 oracle vs f32 {e_or:.4e}, ratio {e / max(e_or, 1e-30):.2f} (bar 1.3)"
 
 
 def test_mid_attention_query_blocks_are_exact(gpu):

@@ -22,7 +22,7 @@ def test_siglip_shape_encoder(gpu):
     refbf = ov.siglip_last_hidden_state(g, 56, 14, 192, 2, 3, 304, px, torch.bfloat16)
     out = vit.VitHIP(cfg, g, gpu)(img.to(gpu))
     e, eo = _rel(out, ref32), _rel(refbf, ref32)
-    assert e < max(1.5e-2, 2.5 * eo), (e, eo)
+    assert e < max(1.5e-2, 1.3 * eo), f"HIP vs f32 {e:.4e}, bf16 upstream vs f32 {eo:.4e}, ratio {e / max(eo, 1e-30):.2f} (bar 1.3)"
 
 
 def test_clip_shape_encoder(gpu):
@@ -39,7 +39,7 @@ def test_clip_shape_encoder(gpu):
     out = vit.VitHIP(cfg, g, gpu)(img.to(gpu))
     assert out.dtype == torch.float32 and out.shape == (5, 64)
     e, eo = _rel(out, ref32), _rel(refbf, ref32)
-    assert e < max(1.5e-2, 2.5 * eo), (e, eo)
+    assert e < max(1.5e-2, 1.3 * eo), f"HIP vs f32 {e:.4e}, bf16 upstream vs f32 {eo:.4e}, ratio {e / max(eo, 1e-30):.2f} (bar 1.3)"
 
 
 @pytest.mark.parametrize("N,es,ps", [(1, [0.9], [1.0]), (2, [0.8, 1.0], [1.0, 1.0])])

@@ -74,3 +74,20 @@ def test_stage2_ranks_share_one_timestamp(monkeypatch):
     assert a == b and len(a) == 15 and a[8] == "_"
     monkeypatch.setenv("DRAG_TIMESTAMP", "20240101_000000")
     assert S2.run_timestamp(4) == S2.run_timestamp(1) == "20240101_000000"
+
+
+def test_clip_fingerprint_sees_every_tensor():
+    """a tower that differs from another only in one transformer-block weight (or one element of a big matrix the strided
+    sample misses) has a different fingerprint: a feature cache computed with other weights is stale"""
+    import torch
+    from domain_rag_amd.retrieval import weights_fingerprint
+    from domain_rag_amd.vit import VitConfig, init_generic_params
+    cfg = VitConfig.clip_vit_b32()
+    g = init_generic_params(cfg, seed=0)
+    base = weights_fingerprint(g)
+    assert base == weights_fingerprint({k: v.clone() for k, v in g.items()})
+    for name, pos in (("l7.fc1.weight", 5), ("l0.q.bias", 3), ("l11.fc2.weight", 1234567), ("pos", 11)):
+        h = {k: v.clone() for k, v in g.items()}
+        flat = h[name].view(-1)
+        flat[pos] = flat[pos] + 0.5
+        assert weights_fingerprint(h) != base, name
