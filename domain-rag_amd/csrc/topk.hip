@@ -10,11 +10,29 @@
 //   ties -> lower corpus index first.
 //
 // Scan kernel (HBM-bound: N*d*4 bytes per pass): each wave streams groups of 16 corpus rows
-// HBM -> LDS with LDS-DMA (full 256-B row segments, XOR-swizzled), then feeds
+// HBM -> LDS with LDS-DMA (full 256-B row segments, XOR-swizzled; the next group's first chunk is
+// already in flight while the current group's last chunk is multiplied), then feeds
 // v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain) with 16 rows x 16 queries; the
 // reduction over d happens inside the matrix core, no cross-lane shuffles.
-// Selection: (score, index) -> unique 64-bit composite key; per-slice radix select in LDS,
-// tree-merged, bitonic-sorted.
+//
+// Round 3 — ONE corpus pass for up to 64 queries, and selection that never sees the corpus:
+//   * query tiles: a launch carries ceil(Q/16) <= 4 tiles of 16 queries.  The workgroups b, b+8, b+16, b+24 land on the
+//     SAME XCD (the dispatcher deals workgroups round-robin over the 8 XCDs), walk the SAME corpus rows and differ only in
+//     their query tile: the first of them pulls a row chunk from HBM into that XCD's L2, the other three hit it there.
+//     HBM traffic stays N*d*4 per launch whatever Q <= 64 (the reference re-builds its index and re-reads the corpus per
+//     query, retrieval/...:419-430).  At Q = 64 the launch is bound by the exact-f32 matrix core, not by HBM:
+//     2*N*d*Q = 7.75 GFLOP at N = 118 287 is 49 us at the 157 TFLOP/s f32 MFMA peak, against 38 us for the bytes.
+//   * threshold pre-filter: a first, small launch scores a strided SAMPLE of 8192 rows (512 groups spread evenly over the
+//     corpus); the k-th largest (score, index) composite of the sample is a valid lower bound T_q of the final k-th largest
+//     (those k rows are in the corpus).  The main scan then keeps a score only if its composite is >= T_q — about k*N/8192
+//     rows per query (1 400 of 118 287 for k = 100) — and appends it to the query's candidate list; the score matrix
+//     [Q, N] is never written or re-read.  Every WAVE owns a region of each query's list sized for all the rows it visits
+//     and counts its appends in a register (ballot + popcount: no atomics — a first version with one global atomic per
+//     candidate ran the Q = 16 call in 235 us, the counters shared a cache line and 23 000 atomics queued on it); a wave
+//     stores its per-query counts once, at its end.  The final selection (prefix sum over the regions' counts, radix select +
+//     bitonic sort + decode, one workgroup per query) works on the candidates alone.  The regions have room for all N rows,
+//     so a sample that misrepresents the corpus costs time, never correctness, and the whole call is deterministic.
+// Selection: (score, index) -> unique 64-bit composite key; radix select in LDS over slices of the input, bitonic sort.
 #include "drag_common.h"
 #include <float.h>
 
@@ -22,93 +40,6 @@ namespace {
 
 typedef unsigned long long u64;
 
-// ------------------------------------------------------------------ scan
-struct ScanArgs {
-  const float* corpus;
-  const float* queries;  // [Q, d] (this pass: Q <= 16)
-  float* scores;         // [Q, npad]
-  long long N, npad;
-  int d, Q;
-};
-
-__global__ __launch_bounds__(256, 2) void ip_scan_kernel(ScanArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: query image [d/64][16][256 B] | per wave: 2 x 4 KiB staging
-  const int nch = p.d / 64;
-  char* sQ = smem;
-  const int w = wave_id(), l = lane_id();
-  char* sA = smem + nch * 4096 + w * 8192;
-
-  // ---- query image (rows >= Q are zero) ----
-  for (int i = threadIdx.x; i < 16 * (p.d / 4); i += 256) {
-    const int q = i / (p.d / 4), k4 = i - q * (p.d / 4);  // float4 index within the row
-    const int c = k4 >> 4, slot = k4 & 15;
-    f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (q < p.Q) v = *(const f32x4_t*)(p.queries + (long long)q * p.d + k4 * 4);
-    *(f32x4_t*)(sQ + c * 4096 + q * 256 + ((slot ^ q) & 15) * 16) = v;
-  }
-  __syncthreads();
-
-  const long long ngroups = (p.N + 15) / 16;
-  const long long gstride = (long long)gridDim.x * 4;
-  const int g = l >> 4, r16 = l & 15;
-  const int rd_base = r16 * 256;
-
-  // this lane's DMA role inside a group chunk: instruction i covers rows 4i + (l>>4)
-  // physical slot l&15 holds logical slot (l&15) ^ (row&15)
-  unsigned lane_off[4];
-  int lane_row[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lane_row[i] = 4 * i + (l >> 4);
-    lane_off[i] = (unsigned)((((l & 15) ^ (lane_row[i] & 15)) & 15) * 16);
-  }
-
-  for (long long grp = (long long)blockIdx.x * 4 + w; grp < ngroups; grp += gstride) {
-    const long long row0 = grp * 16;
-    const int nvalid = (int)min((long long)16, p.N - row0);
-    const float* gbase = p.corpus + row0 * p.d;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, (unsigned)(nvalid * p.d * 4), 0x00020000);
-    unsigned voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) voff[i] = (unsigned)(min(lane_row[i], nvalid - 1) * p.d * 4) + lane_off[i];
-
-    auto dma = [&](int buf, int c) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (DRAG_LDS void*)((DRAG_LDS char*)sA + buf * 4096 + i * 1024), 16,
-                                                 voff[i], c * 256, 0, 0);
-    };
-
-    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    dma(0, 0);
-    for (int c = 0; c < nch; ++c) {
-      const int buf = c & 1;
-      if (c + 1 < nch) {
-        dma(buf ^ 1, c + 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      const char* a = sA + buf * 4096 + rd_base;
-      const char* q = sQ + c * 4096 + rd_base;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int so = (((4 * cc + g) ^ r16) & 15) * 16;
-        const f32x4_t av = *(const f32x4_t*)(a + so);
-        const f32x4_t qv = *(const f32x4_t*)(q + so);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], qv[s], acc, 0, 0, 0);
-      }
-      // the next iteration's DMA overwrites `buf^1`... whose reads were consumed by the MFMAs above
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    // acc[r] = score[row0 + 4g + r][query r16]
-    if (r16 < p.Q) *(f32x4_t*)(p.scores + (long long)r16 * p.npad + row0 + 4 * g) = acc;
-  }
-}
-
-// ------------------------------------------------------------------ selection
 __device__ __forceinline__ unsigned okey(float f) {
   unsigned u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return 1u;  // NaN ranks below every real score
@@ -119,127 +50,405 @@ __device__ __forceinline__ float okey_inv(unsigned k) {
   const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
   return __uint_as_float(u);
 }
+// composite: score order in the high word, lower index wins ties in the low word; never 0 for a real row (0 = empty slot)
+__device__ __forceinline__ u64 composite(float score, unsigned row) { return ((u64)okey(score) << 32) | (u64)(~row); }
 
-constexpr int LMAX = 8192;   // elements a selection block holds in LDS
-constexpr int KMAX = 2048;
-
-struct SelArgs {
-  const float* scores;   // level 1 input  [Q, npad]
-  const u64* in;         // level >= 2 input [Q, G_in, k]
-  u64* out;              // [Q, G_out, k]
-  long long N, npad;
-  int slice;             // level 1: rows per block
-  int G_in, F;           // level >= 2: groups in, groups merged per block
-  int k, kpad;
-  int from_scores;
+// ------------------------------------------------------------------ scan
+enum { SCAN_SCORES = 0, SCAN_KEYS_DENSE = 1, SCAN_KEYS_FILTER = 2 };
+struct ScanArgs {
+  const float* corpus;
+  const float* queries;  // [Q, d], Q <= 64 in one launch
+  long long N;
+  int d, Q, ntile;       // ntile = ceil(Q / 16)
+  int mode;
+  // which groups of 16 rows this launch visits: group(i) = i * gstride, i < niter  (gstride 1 = the whole corpus)
+  long long gstride, niter;
+  // SCAN_SCORES
+  float* scores;         // [Q, npad]
+  long long npad;
+  // SCAN_KEYS_DENSE: keys[q * kstride + 16 * i + r] = composite(score, row), 0 for rows >= N
+  // SCAN_KEYS_FILTER: wave v = worker * 4 + w appends the composites >= thresh[q] it finds to its own region
+  //   keys[q * kstride + v * region_cap + n], n = 0, 1, ...; counts[q * nregions + v] = how many
+  u64* keys;
+  long long kstride;
+  const u64* thresh;
+  unsigned* counts;
+  long long region_cap;
+  int nregions;
 };
 
+template <int NBUF>
+__global__ __launch_bounds__(256, 2) void ip_scan_kernel(ScanArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: query image of this workgroup's tile [d/64][16][256 B] | per wave: NBUF x 4 KiB staging ring
+  const int nch = p.d / 64;
+  char* sQ = smem;
+  const int w = wave_id(), l = lane_id();
+  char* sA = smem + nch * 4096 + w * (NBUF * 4096);
+
+  // workgroups b, b+8, ..., b+8*(ntile-1) sit on one XCD: same rows, different query tile (L2 serves the re-reads)
+  const int grp8 = (int)blockIdx.x >> 3;
+  const int tile = grp8 % p.ntile;
+  const long long worker = (long long)(grp8 / p.ntile) * 8 + ((int)blockIdx.x & 7);
+  const long long nworkers = (long long)(gridDim.x / (8 * p.ntile)) * 8;
+  const int q0 = tile * 16;
+  const int qn = min(16, p.Q - q0);
+
+  // ---- query image (rows >= qn are zero) ----
+  for (int i = threadIdx.x; i < 16 * (p.d / 4); i += 256) {
+    const int q = i / (p.d / 4), k4 = i - q * (p.d / 4);  // float4 index within the row
+    const int c = k4 >> 4, slot = k4 & 15;
+    f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (q < qn) v = *(const f32x4_t*)(p.queries + (long long)(q0 + q) * p.d + k4 * 4);
+    *(f32x4_t*)(sQ + c * 4096 + q * 256 + ((slot ^ q) & 15) * 16) = v;
+  }
+  __syncthreads();
+
+  const int g = l >> 4, r16 = l & 15;
+  const int rd_base = r16 * 256;
+  // this lane's DMA role inside a group chunk: instruction i covers rows 4i + (l>>4)
+  // physical slot l&15 holds logical slot (l&15) ^ (row&15)
+  unsigned lane_off[4];
+  int lane_row[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lane_row[i] = 4 * i + (l >> 4);
+    lane_off[i] = (unsigned)((((l & 15) ^ (lane_row[i] & 15)) & 15) * 16);
+  }
+  u64 T = ~0ull;
+  if (p.mode == SCAN_KEYS_FILTER && r16 < qn) T = p.thresh[q0 + r16];
+
+  const long long step = nworkers * 4;
+  const long long first = worker * 4 + w;
+  unsigned ncand = 0;                    // filter mode: candidates of query q0 + r16 appended by this wave so far (same in its 4 lanes)
+  u64* region = nullptr;
+  if (p.mode == SCAN_KEYS_FILTER) {
+    if (first >= p.niter) {              // a wave without rows still owns a region: say that it is empty
+      if (l < qn) p.counts[(long long)(q0 + l) * p.nregions + worker * 4 + w] = 0u;
+      return;
+    }
+    region = p.keys + (long long)(q0 + min(r16, qn - 1)) * p.kstride + (worker * 4 + w) * p.region_cap;
+  }
+  if (first >= p.niter) return;
+
+  // ---- the wave's work is ONE stream of (group, 256-byte chunk) steps; the LDS-DMA runs NBUF - 1 steps ahead of the MFMAs,
+  // across group boundaries too (the next group's first chunks fly under this group's last ones) ----
+  const long long nmine = (p.niter - first + step - 1) / step;
+  const long long total = nmine * nch;
+  // issue side
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff[4];
+  long long is_it = first;               // group iteration of the next chunk to issue
+  int is_c = 0, is_buf = 0;
+  auto issue = [&]() {
+    if (is_c == 0) {                     // the DMA descriptor of a group: base of its 16 rows, clamped row offsets for a ragged last group
+      const long long row0 = is_it * p.gstride * 16;
+      const int nvalid = (int)min((long long)16, p.N - row0);
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.corpus + row0 * p.d), 0, (unsigned)(nvalid * p.d * 4), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) voff[i] = (unsigned)(min(lane_row[i], nvalid - 1) * p.d * 4) + lane_off[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (DRAG_LDS void*)((DRAG_LDS char*)sA + is_buf * 4096 + i * 1024), 16, voff[i],
+                                               is_c * 256, 0, 0);
+    is_buf = is_buf + 1 == NBUF ? 0 : is_buf + 1;
+    if (++is_c == nch) { is_c = 0; is_it += step; }
+  };
+  constexpr int D = NBUF - 1;
+  for (int i = 0; i < D && i < total; ++i) issue();
+
+  long long it = first;
+  int c = 0, buf = 0;
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (long long sidx = 0; sidx < total; ++sidx) {
+    if (sidx + D < total) {
+      issue();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * D) : "memory");
+    } else {                             // the tail: fewer chunks ahead of this one than the ring holds
+      const int ahead = (int)(total - 1 - sidx);
+      if (D >= 7 && ahead == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (D >= 6 && ahead == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if (D >= 5 && ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (D >= 4 && ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (D >= 3 && ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (D >= 2 && ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char* a = sA + buf * 4096 + rd_base;
+    const char* q = sQ + c * 4096 + rd_base;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int so = (((4 * cc + g) ^ r16) & 15) * 16;
+      const f32x4_t av = *(const f32x4_t*)(a + so);
+      const f32x4_t qv = *(const f32x4_t*)(q + so);
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ss], qv[ss], acc, 0, 0, 0);
+    }
+    // the next step's DMA overwrites this buffer's predecessor in the ring, whose reads were consumed by the MFMAs above
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
+    if (++c < nch) continue;
+    c = 0;
+
+    // ---- a group is complete: acc[r] = score[row0 + 4g + r][query q0 + r16]
+    const long long row0 = it * p.gstride * 16;
+    if (p.mode == SCAN_KEYS_FILTER) {
+      // the query r16 lives in lanes r16, r16 + 16, r16 + 32, r16 + 48: slots are handed out with ballots, no atomics
+      u64 key[4];
+      bool pass[4], any = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = row0 + 4 * g + r;
+        key[r] = composite(acc[r], (unsigned)row);
+        pass[r] = row < p.N && key[r] >= T;        // T = ~0 in lanes without a query
+        any = any || pass[r];
+      }
+      if (__ballot(any) != 0ull) {
+        const u64 mine = 0x0001000100010001ull << r16;
+        const u64 below = (1ull << l) - 1ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u64 m = __ballot(pass[r]) & mine;
+          if (pass[r]) region[ncand + __popcll(m & below)] = key[r];
+          ncand += (unsigned)__popcll(m);
+        }
+      }
+    } else if (r16 < qn) {
+      const int qq = q0 + r16;
+      if (p.mode == SCAN_SCORES) {
+        *(f32x4_t*)(p.scores + (long long)qq * p.npad + row0 + 4 * g) = acc;
+      } else {
+        u64* dst = p.keys + (long long)qq * p.kstride + it * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long row = row0 + 4 * g + r;
+          dst[r] = row < p.N ? composite(acc[r], (unsigned)row) : 0ull;
+        }
+      }
+    }
+    acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    it += step;
+  }
+  if (p.mode == SCAN_KEYS_FILTER && l < qn) p.counts[(long long)(q0 + l) * p.nregions + worker * 4 + w] = ncand;
+}
+
+// ------------------------------------------------------------------ selection
+constexpr int LMAX = 8192;   // elements a selection workgroup holds in LDS
+constexpr int KMAX = 2048;
+constexpr int SAMPLE_GROUPS = 512;   // 8192 sampled rows
+
+struct SelArgs {
+  const u64* keys;        // [Q, kstride]
+  long long kstride;
+  // input form 1 (counts == null): keys[q * kstride + 0 .. fixed_count)
+  // input form 2: nregions regions of region_cap slots, region v holds counts[q * nregions + v] keys
+  const unsigned* counts;
+  long long fixed_count;
+  long long region_cap;
+  int nregions;
+  int k, kpad;
+  // outputs: either the threshold ...
+  u64* thresh;
+  // ... or the decoded top-k
+  float* out_d;
+  long long* out_i;
+};
+
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+  return ((u64)(unsigned)__shfl((int)(v >> 32), src, 64) << 32) | (unsigned)__shfl((int)(unsigned)v, src, 64);
+}
+
+// One workgroup (1024 threads) per query.  Streams the query's keys through LDS in slices: the k best so far stay at the
+// head of the list, up to LMAX - k new keys join them, a radix select keeps the k best again.  With a single slice
+// (the normal case: ~1 500 candidates, or the 8192-row sample) this is one select.
+// What the first version paid for (11 us per 8192-key threshold, 19 us per final selection) and what replaced it:
+//   * candidates all share their sign / exponent / leading mantissa bits, so the first radix digits put EVERY key into one
+//     histogram bin — thousands of LDS atomics on one address.  The bits common to all keys (AND vs OR) are skipped and the
+//     first digit starts at the highest bit in which two keys differ;
+//   * the bitonic sort's 28 barriers for 128 keys -> a rank sort (keys are unique: rank = number of larger keys), one barrier;
+//   * the prefix sum over the candidate regions' counts by wave shuffles (2 barriers instead of 20).
 __global__ __launch_bounds__(1024) void select_kernel(SelArgs p) {
   __shared__ u64 lst[LMAX];
   __shared__ u64 srt[KMAX];
   __shared__ unsigned hist[256];
   __shared__ unsigned sh_need, sh_cnt, sh_done;
   __shared__ u64 sh_prefix;
-  const int tid = threadIdx.x;
-  const int gblk = blockIdx.x, q = blockIdx.y;
-  int L;
-  if (p.from_scores) {
-    const long long r0 = (long long)gblk * p.slice;
-    L = (int)min((long long)p.slice, p.N - r0);
-    const float* s = p.scores + (long long)q * p.npad + r0;
-    for (int i = tid; i < L; i += 1024)
-      lst[i] = ((u64)okey(s[i]) << 32) | (u64)(~(unsigned)(r0 + i));
-  } else {
-    const int g0 = gblk * p.F;
-    const int ng = min(p.F, p.G_in - g0);
-    L = ng * p.k;
-    const u64* s = p.in + ((long long)q * p.G_in + g0) * p.k;
-    for (int i = tid; i < L; i += 1024) lst[i] = s[i];
+  __shared__ u64 red_or[16], red_and[16];
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = blockIdx.x;
+  const u64* src = p.keys + (long long)q * p.kstride;
+  // ---- regions: this thread owns regions [r0, r1); base = number of keys in the regions before them
+  int r0 = 0, r1 = 0;
+  long long base = 0, total = p.fixed_count;
+  if (p.counts) {
+    const unsigned* cnt = p.counts + (long long)q * p.nregions;
+    const int rpt = (p.nregions + 1023) / 1024;
+    r0 = min(tid * rpt, p.nregions); r1 = min(r0 + rpt, p.nregions);
+    unsigned mine = 0;
+    for (int r = r0; r < r1; ++r) mine += cnt[r];
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const unsigned v = wsum[i];
+      before += i < wv ? v : 0u;
+      all += v;
+    }
+    base = (long long)before + incl - mine;
+    total = all;
   }
-  __syncthreads();
-  u64* dst = p.out + ((long long)q * gridDim.x + gblk) * p.k;
 
-  if (L <= p.k) {
-    for (int i = tid; i < p.kpad; i += 1024) srt[i] = i < L ? lst[i] : 0ull;
-  } else {
-    // ---- radix select of the k-th largest composite: up to 8 passes of 8 bits from the top.
-    // Early exit: once the bin that holds the k-th element contains EXACTLY the number of elements still needed,
-    // every element with that prefix is selected and the remaining low bits need not be resolved (with distinct
-    // scores this happens after 2-3 passes; only exact score ties ever reach the index bits).
-    if (tid == 0) { sh_need = (unsigned)p.k; sh_prefix = 0ull; sh_done = 0u; }
-    u64 mask = 0ull;
-    for (int pass = 7; pass >= 0; --pass) {
-      if (tid < 256) hist[tid] = 0u;
+  long long done = 0;
+  int have = 0;                          // keys at the head of lst carried over from the previous slice
+  u64 T = 0ull;
+  int nsel = 0;                          // valid entries in srt
+  bool first = true;
+  while (first || done < total) {
+    first = false;
+    const int take = (int)min((long long)(LMAX - have), total - done);
+    u64 vor = 0ull, vand = ~0ull;        // over the keys this thread brings in (and, below, the carried ones)
+    if (!p.counts) {
+      for (int i = tid; i < take; i += 1024) {
+        const u64 x = src[done + i];
+        lst[have + i] = x; vor |= x; vand &= x;
+      }
+    } else {                             // keys with ordinals [done, done + take) out of this thread's regions
+      const unsigned* cnt = p.counts + (long long)q * p.nregions;
+      long long o = base;
+      for (int r = r0; r < r1 && o < done + take; ++r) {
+        const unsigned n = cnt[r];
+        if (o + n > done) {
+          const u64* reg = src + (long long)r * p.region_cap;
+          for (unsigned e = (unsigned)max(0ll, done - o); e < n && o + e < done + take; ++e) {
+            const u64 x = reg[e];
+            lst[have + (int)(o + e - done)] = x; vor |= x; vand &= x;
+          }
+        }
+        o += n;
+      }
+    }
+    done += take;
+    const int L = have + take;
+    for (int i = tid; i < have; i += 1024) { const u64 x = lst[i]; vor |= x; vand &= x; }
+    if (L <= p.k) {
       __syncthreads();
-      if (sh_done) break;
-      const u64 prefix = sh_prefix;
-      const unsigned need = sh_need;
+      for (int i = tid; i < p.kpad; i += 1024) srt[i] = i < L ? lst[i] : 0ull;
+      nsel = L;
+      T = 0ull;
+    } else {
+      // ---- bits shared by all L keys: OR / AND over the workgroup
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) { vor |= shfl64(vor, lane ^ m); vand &= shfl64(vand, lane ^ m); }
+      if (lane == 0) { red_or[wv] = vor; red_and[wv] = vand; }
+      if (tid == 0) { sh_need = (unsigned)p.k; sh_done = 0u; }
+      __syncthreads();
+      u64 aor = 0ull, aand = ~0ull;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { aor |= red_or[i]; aand &= red_and[i]; }
+      const u64 diff = aor ^ aand;
+      // ---- radix select of the k-th largest composite, 8 bits per pass from the highest bit in which two keys differ.
+      // Early exit: once the bin that holds the k-th element contains EXACTLY the number of elements still needed,
+      // every element with that prefix is selected and the remaining low bits need not be resolved (with distinct
+      // scores this happens after 2-3 passes; only exact score ties ever reach the index bits).
+      if (diff == 0ull) {                // L copies of one key (only empty slots can repeat): that key is the k-th best
+        T = aand;
+      } else {
+        const int hb = 63 - __builtin_clzll(diff);
+        u64 mask = hb == 63 ? 0ull : ~((2ull << hb) - 1ull);
+        if (tid == 0) sh_prefix = aand & mask;
+        int sh = max(hb - 7, 0), width = hb - sh + 1;
+        while (true) {
+          if (tid < 256) hist[tid] = 0u;
+          __syncthreads();
+          if (sh_done) break;
+          const u64 prefix = sh_prefix;
+          const unsigned need = sh_need;
+          const unsigned dm = (1u << width) - 1u;
+          for (int i = tid; i < L; i += 1024) {
+            const u64 x = lst[i];
+            if ((x & mask) == prefix) atomicAdd(&hist[(unsigned)(x >> sh) & dm], 1u);
+          }
+          __syncthreads();
+          // wave 0 scans the 256 bins from the top: lane i owns bins 255-4i .. 252-4i
+          if (tid < 64) {
+            unsigned h[4], s4 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * tid - j]; s4 += h[j]; }
+            unsigned incl = s4;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+              const unsigned v = __shfl_up(incl, off, 64);
+              if (tid >= off) incl += v;
+            }
+            unsigned run = incl - s4;                       // elements in bins above this lane's first bin
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (run < need && need <= run + h[j]) {
+                sh_need = need - run;
+                sh_prefix = prefix | ((u64)(255 - 4 * tid - j) << sh);
+                if (h[j] == need - run) sh_done = 1u;       // the whole bin is selected
+              }
+              run += h[j];
+            }
+          }
+          mask |= ((u64)dm << sh);
+          __syncthreads();
+          if (sh == 0) break;
+          const int nsh = max(sh - 8, 0);
+          width = sh - nsh;
+          sh = nsh;
+        }
+        T = sh_prefix;                   // every selected key is >= T, exactly k keys are
+      }
+      if (tid == 0) sh_cnt = 0u;
+      __syncthreads();
       for (int i = tid; i < L; i += 1024) {
         const u64 x = lst[i];
-        if ((x & mask) == prefix) atomicAdd(&hist[(unsigned)(x >> (8 * pass)) & 255u], 1u);
+        if (x > T) srt[atomicAdd(&sh_cnt, 1u)] = x;
       }
       __syncthreads();
-      // wave 0 scans the 256 bins from the top: lane i owns bins 255-4i .. 252-4i
-      if (tid < 64) {
-        unsigned h[4], s4 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * tid - j]; s4 += h[j]; }
-        unsigned incl = s4;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const unsigned v = __shfl_up(incl, off, 64);
-          if (tid >= off) incl += v;
-        }
-        unsigned run = incl - s4;                       // elements in bins above this lane's first bin
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (run < need && need <= run + h[j]) {
-            sh_need = need - run;
-            sh_prefix = prefix | ((u64)(255 - 4 * tid - j) << (8 * pass));
-            if (h[j] == need - run) sh_done = 1u;       // the whole bin is selected
-          }
-          run += h[j];
-        }
-      }
-      mask |= (0xffull << (8 * pass));
-      __syncthreads();
-    }
-    const u64 T = sh_prefix;
-    if (tid == 0) sh_cnt = 0u;
-    __syncthreads();
-    for (int i = tid; i < L; i += 1024) {
-      const u64 x = lst[i];
-      if (x > T) srt[atomicAdd(&sh_cnt, 1u)] = x;
+      const int cgt = (int)sh_cnt;       // k, or fewer when keys equal T bit for bit (one real key, or repeated empty slots)
+      for (int i = cgt + tid; i < p.kpad; i += 1024) srt[i] = i < p.k ? T : 0ull;
+      nsel = p.k;
     }
     __syncthreads();
-    const int cgt = (int)sh_cnt;  // < k
-    for (int i = cgt + tid; i < p.kpad; i += 1024) srt[i] = i < p.k ? T : 0ull;
-  }
-  __syncthreads();
-  // ---- bitonic sort, descending ----
-  for (int sz = 2; sz <= p.kpad; sz <<= 1) {
-    for (int st = sz >> 1; st > 0; st >>= 1) {
-      for (int i = tid; i < p.kpad; i += 1024) {
-        const int j = i ^ st;
-        if (j > i) {
-          const bool desc = (i & sz) == 0;
-          const u64 a = srt[i], b = srt[j];
-          if (desc ? (a < b) : (a > b)) { srt[i] = b; srt[j] = a; }
-        }
-      }
+    if (done < total) {                  // carry the k best into the next slice
+      for (int i = tid; i < nsel; i += 1024) lst[i] = srt[i];
+      have = nsel;
       __syncthreads();
     }
   }
-  for (int i = tid; i < p.k; i += 1024) dst[i] = srt[i];
-}
 
-__global__ void decode_kernel(const u64* in, float* out_d, long long* out_i, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const u64 x = in[i];
-  if (x == 0ull) { out_d[i] = -FLT_MAX; out_i[i] = -1; return; }   // faiss' padding for k > ntotal
-  out_d[i] = okey_inv((unsigned)(x >> 32));
-  out_i[i] = (long long)(~(unsigned)(x & 0xffffffffull));
+  if (p.thresh) {                        // threshold mode: the sample's k-th best is a lower bound of the corpus' k-th best
+    if (tid == 0) p.thresh[q] = nsel < p.k ? 0ull : T;
+    return;
+  }
+  // ---- rank sort, descending: real keys are unique, so a key's rank is the number of larger keys; empty slots (0) go last
+  for (int i = tid; i < p.k; i += 1024) {
+    const long long o = (long long)q * p.k + i;
+    if (i >= nsel) { p.out_d[o] = -FLT_MAX; p.out_i[o] = -1; }     // faiss' padding for k > ntotal
+  }
+  for (int i = tid; i < nsel; i += 1024) {
+    const u64 x = srt[i];
+    int rank = 0;
+    if (x == 0ull) {                     // an empty slot inside the selection (dense input with rows >= N): after every real key,
+      for (int j = 0; j < nsel; ++j) rank += (srt[j] != 0ull) || (j < i);   // ordered among themselves by position
+    } else {
+      for (int j = 0; j < nsel; ++j) rank += srt[j] > x;
+    }
+    const long long o = (long long)q * p.k + rank;
+    if (x == 0ull) { p.out_d[o] = -FLT_MAX; p.out_i[o] = -1; }
+    else { p.out_d[o] = okey_inv((unsigned)(x >> 32)); p.out_i[o] = (long long)(~(unsigned)(x & 0xffffffffull)); }
+  }
 }
 
 struct L2Args { float* x; long long rows; int d; };
@@ -256,40 +465,65 @@ __global__ __launch_bounds__(256) void l2norm_kernel(L2Args p) {
   for (int c = l; c < p.d; c += 64) xr[c] = xr[c] / nrm;
 }
 
-inline int level1_slice() { return 4096; }
+// launch geometry of the scan: a multiple of 8 * ntile workgroups (the tiles of a row range share an XCD)
+inline int scan_grid(long long niter, int ntile) {
+  const long long unit = 8 * ntile;
+  long long want = (niter + 3) / 4 * ntile;                 // one wave per group
+  want = (want + unit - 1) / unit * unit;
+  // workgroups at most (speed only; 0 = the measured default: two resident workgroups per CU, each wave walks many groups with
+  // the next group's first chunk prefetched — scan at Q = 16, N = 118 287: 40.2 us with 512, 41.8 with 1024, 46.9 with 1856)
+  const int opt = drag_opt(DRAG_OPT_TOPK_GRID);
+  const long long cap = (long long)(min(opt > 0 ? opt : 512, 2048) / unit) * unit;
+  return (int)(want < unit ? unit : (want > cap ? cap : want));
+}
+template <int NBUF>
+int launch_scan_n(ScanArgs& sa, hipStream_t st) {
+  const int lds = (sa.d / 64) * 4096 + 4 * NBUF * 4096;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)ip_scan_kernel<NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DRAG_CHECK(e == hipSuccess, "cosine scan: cannot raise dynamic LDS limit");
+  }
+  hipLaunchKernelGGL(ip_scan_kernel<NBUF>, dim3(scan_grid(sa.niter, sa.ntile)), dim3(256), lds, st, sa);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+// Ring depth 2 (one chunk ahead) is the measured default: 8 waves per CU hide each other's latency, a third buffer per wave
+// (80 KiB per workgroup, still two per CU) measured -3...-7 % at Q <= 16 and +2 % at Q = 64; putting a whole group in flight
+// (8 buffers, 160 KiB, one workgroup per CU) for the launches that give a wave a single group (the 512-group sample) made
+// that launch slower (7.2-8.4 -> 9.6-11.2 us): it is bound by the workgroup's start-up (32 KiB query image), not by the stream.
+int launch_scan(ScanArgs& sa, hipStream_t st) {
+  if (drag_opt(DRAG_OPT_TOPK_DEPTH) == 3) return launch_scan_n<3>(sa, st);
+  return launch_scan_n<2>(sa, st);
+}
+
+// workspace layout: thresholds [64] u64 | region counters [64][MAXREG] u32 | sample keys [64][8192] u64 |
+//                   candidates [min(Q,64)][ceil16(N) + 16 * MAXREG] u64 (one region per scanning wave, MAXREG = 2048 workgroups x 4)
+inline long long ceil16(long long n) { return (n + 15) / 16 * 16; }
+constexpr long long MAXREG = 8192;
+inline long long cand_stride(long long N) { return ceil16(N) + 16 * MAXREG; }
 
 }  // namespace
 
 extern "C" int64_t drag_cosine_topk_workspace_bytes(int64_t N, int32_t Q) {
   if (N <= 0 || Q <= 0) return 0;
-  const long long npad = (N + 63) / 64 * 64;
-  const long long G1 = (N + level1_slice() - 1) / level1_slice();
-  // scores for one pass of <=16 queries + two candidate buffers sized for the worst k
-  return 16 * npad * 4 + 2 * 16 * G1 * (long long)KMAX * 8 + 256;
+  const long long qp = Q < 64 ? Q : 64;
+  return 64 * 8 + 64 * MAXREG * 4 + 64ll * SAMPLE_GROUPS * 16 * 8 + qp * cand_stride(N) * 8 + 256;
 }
 
-// scan only: scores[q, n] = <corpus[n], queries[q]> for Q <= 16 queries, row stride npad = ceil64(N) floats.
-// The same kernel, launch geometry and summation order as the first stage of drag_cosine_topk_f32 (bench.py times
-// the HBM-bound pass alone through this entry; tests compare it bit for bit with the oracle's score order).
+// scan only: scores[q, n] = <corpus[n], queries[q]> for Q <= 64 queries in ONE pass over the corpus, row stride
+// npad = ceil64(N) floats.  The same kernel, launch geometry and summation order as the scan inside drag_cosine_topk_f32
+// (bench.py times the HBM-bound pass alone through this entry; tests compare it bit for bit with the oracle's score order).
 extern "C" int drag_cosine_scores_f32(const float* corpus, const float* queries, int64_t N, int32_t d, int32_t Q,
                                       float* scores, void* stream) {
   DRAG_CHECK(corpus && queries && scores, "drag_cosine_scores_f32: null pointer");
-  DRAG_CHECK(N > 0 && Q > 0 && Q <= 16, "drag_cosine_scores_f32: N > 0 and 1 <= Q <= 16 (one scan pass)");
+  DRAG_CHECK(N > 0 && Q > 0 && Q <= 64, "drag_cosine_scores_f32: N > 0 and 1 <= Q <= 64 (one scan pass)");
   DRAG_CHECK(d > 0 && d % 64 == 0 && d <= 1024, "drag_cosine_scores_f32: d must be a multiple of 64, <= 1024");
   DRAG_CHECK(N < (1ll << 32) - 1, "drag_cosine_scores_f32: N must fit 32 bits");
-  const int lds = (d / 64) * 4096 + 4 * 8192;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)ip_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    DRAG_CHECK(e == hipSuccess, "drag_cosine_scores_f32: cannot raise dynamic LDS limit");
-  }
-  const long long ngroups = (N + 15) / 16;
-  const int grid = (int)min((long long)2048, (ngroups + 3) / 4);
-  ScanArgs sa;
-  sa.corpus = corpus; sa.queries = queries; sa.scores = scores;
-  sa.N = N; sa.npad = (N + 63) / 64 * 64; sa.d = d; sa.Q = Q;
-  hipLaunchKernelGGL(ip_scan_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, sa);
-  DRAG_LAUNCH_CHECK();
-  return 0;
+  ScanArgs sa{};
+  sa.corpus = corpus; sa.queries = queries; sa.N = N; sa.d = d; sa.Q = Q; sa.ntile = (Q + 15) / 16;
+  sa.mode = SCAN_SCORES; sa.gstride = 1; sa.niter = (N + 15) / 16;
+  sa.scores = scores; sa.npad = (N + 63) / 64 * 64;
+  return launch_scan(sa, (hipStream_t)stream);
 }
 
 extern "C" int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, int32_t d, int32_t Q,
@@ -300,49 +534,49 @@ extern "C" int drag_cosine_topk_f32(const float* corpus, const float* queries, i
   DRAG_CHECK(k > 0 && k <= KMAX, "drag_cosine_topk_f32: 1 <= k <= 2048");
   DRAG_CHECK(N < (1ll << 32) - 1, "drag_cosine_topk_f32: N must fit 32 bits");
   hipStream_t st = (hipStream_t)stream;
-  const long long npad = (N + 63) / 64 * 64;
-  const int slice = level1_slice();
-  const long long G1 = (N + slice - 1) / slice;
-  float* scores = (float*)workspace;
-  u64* bufA = (u64*)((char*)workspace + 16 * npad * 4);
-  u64* bufB = bufA + 16 * G1 * (long long)KMAX;
+  u64* thresh = (u64*)workspace;
+  unsigned* counts = (unsigned*)(thresh + 64);
+  u64* sample = (u64*)(counts + 64 * MAXREG);
+  u64* cand = sample + 64ll * SAMPLE_GROUPS * 16;
+  const long long ngroups = (N + 15) / 16;
+  const long long cstride = cand_stride(N);
   int kpad = 1;
   while (kpad < k) kpad <<= 1;
-  const int lds = (d / 64) * 4096 + 4 * 8192;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)ip_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    DRAG_CHECK(e == hipSuccess, "drag_cosine_topk_f32: cannot raise dynamic LDS limit");
-  }
-  const long long ngroups = (N + 15) / 16;
-  int grid = (int)min((long long)2048, (ngroups + 3) / 4);
 
-  for (int q0 = 0; q0 < Q; q0 += 16) {
-    const int qn = min(16, Q - q0);
-    ScanArgs sa;
-    sa.corpus = corpus; sa.queries = queries + (long long)q0 * d; sa.scores = scores;
-    sa.N = N; sa.npad = npad; sa.d = d; sa.Q = qn;
-    hipLaunchKernelGGL(ip_scan_kernel, dim3(grid), dim3(256), lds, st, sa);
-    DRAG_LAUNCH_CHECK();
-    // level 1
-    SelArgs se;
-    se.scores = scores; se.in = nullptr; se.out = bufA; se.N = N; se.npad = npad; se.slice = slice;
-    se.G_in = 0; se.F = 0; se.k = k; se.kpad = kpad; se.from_scores = 1;
-    hipLaunchKernelGGL(select_kernel, dim3((unsigned)G1, qn), dim3(1024), 0, st, se);
-    DRAG_LAUNCH_CHECK();
-    long long G = G1;
-    u64 *cur = bufA, *nxt = bufB;
-    const int F = LMAX / k;  // >= 4
-    while (G > 1) {
-      const long long Gn = (G + F - 1) / F;
-      se.scores = nullptr; se.in = cur; se.out = nxt; se.G_in = (int)G; se.F = F; se.from_scores = 0;
-      hipLaunchKernelGGL(select_kernel, dim3((unsigned)Gn, qn), dim3(1024), 0, st, se);
+  for (int q0 = 0; q0 < Q; q0 += 64) {
+    const int qn = min(64, Q - q0);
+    ScanArgs sa{};
+    sa.corpus = corpus; sa.queries = queries + (long long)q0 * d; sa.N = N; sa.d = d; sa.Q = qn; sa.ntile = (qn + 15) / 16;
+    SelArgs se{};
+    se.k = k; se.kpad = kpad;
+    if (ngroups <= SAMPLE_GROUPS) {
+      // small corpus: every composite goes to the candidate list at its own slot (no sample, no atomics)
+      sa.mode = SCAN_KEYS_DENSE; sa.gstride = 1; sa.niter = ngroups; sa.keys = cand; sa.kstride = cstride;
+      if (int rc = launch_scan(sa, st)) return rc;
+      se.keys = cand; se.kstride = cstride; se.counts = nullptr; se.fixed_count = ngroups * 16;
+    } else {
+      // 1) the strided sample -> 2) its k-th best composite per query = the filter threshold
+      sa.mode = SCAN_KEYS_DENSE; sa.gstride = ngroups / SAMPLE_GROUPS; sa.niter = SAMPLE_GROUPS; sa.keys = sample;
+      sa.kstride = SAMPLE_GROUPS * 16;
+      if (int rc = launch_scan(sa, st)) return rc;
+      SelArgs sth = se;
+      sth.keys = sample; sth.kstride = SAMPLE_GROUPS * 16; sth.counts = nullptr; sth.fixed_count = SAMPLE_GROUPS * 16;
+      sth.thresh = thresh;
+      hipLaunchKernelGGL(select_kernel, dim3(qn), dim3(1024), 0, st, sth);
       DRAG_LAUNCH_CHECK();
-      u64* t = cur; cur = nxt; nxt = t;
-      G = Gn;
+      // 3) the one pass over the corpus, keeping what can still make the top k: one candidate region per scanning wave,
+      //    sized for every row the wave visits
+      const int grid = scan_grid(ngroups, sa.ntile);
+      const long long nwaves = (long long)(grid / (8 * sa.ntile)) * 8 * 4;
+      sa.mode = SCAN_KEYS_FILTER; sa.gstride = 1; sa.niter = ngroups; sa.keys = cand; sa.kstride = cstride;
+      sa.thresh = thresh; sa.counts = counts; sa.nregions = (int)nwaves; sa.region_cap = 16 * ((ngroups + nwaves - 1) / nwaves);
+      if (int rc = launch_scan(sa, st)) return rc;
+      se.keys = cand; se.kstride = cstride; se.counts = counts; se.fixed_count = 0; se.nregions = sa.nregions; se.region_cap = sa.region_cap;
     }
-    const int total = qn * k;
-    hipLaunchKernelGGL(decode_kernel, dim3((total + 255) / 256), dim3(256), 0, st, cur, out_d + (long long)q0 * k,
-                       (long long*)out_i + (long long)q0 * k, total);
+    // 4) select + sort + decode on the candidates
+    se.thresh = nullptr;
+    se.out_d = out_d + (long long)q0 * k; se.out_i = (long long*)out_i + (long long)q0 * k;
+    hipLaunchKernelGGL(select_kernel, dim3(qn), dim3(1024), 0, st, se);
     DRAG_LAUNCH_CHECK();
   }
   return 0;

@@ -309,7 +309,7 @@ def cosine_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int):
 
 
 def cosine_scores(corpus: torch.Tensor, queries: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """scan pass alone: f32 [Q <= 16, ceil64(N)] inner products in the pinned summation order (entries >= N unspecified)"""
+    """scan pass alone (ONE pass over the corpus): f32 [Q <= 64, ceil64(N)] inner products in the pinned summation order (entries >= N unspecified)"""
     lib = _lib.load()
     _need(corpus, torch.float32, "corpus")
     _need(queries, torch.float32, "queries")

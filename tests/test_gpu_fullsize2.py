@@ -197,7 +197,7 @@ def test_scan_only_entry_matches_oracle_scores_bitwise(gpu):
     from domain_rag_amd import ops
     from oracle import retrieval as oret
     rng = np.random.default_rng(5)
-    for N, Q in ((1000, 16), (4099, 3), (17, 1)):
+    for N, Q in ((1000, 16), (4099, 3), (17, 1), (2100, 64), (777, 33)):
         corpus = rng.standard_normal((N, 512)).astype(np.float32)
         corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
         q = rng.standard_normal((Q, 512)).astype(np.float32)
@@ -207,4 +207,4 @@ def test_scan_only_entry_matches_oracle_scores_bitwise(gpu):
     with pytest.raises(ValueError):
         ops.cosine_scores(torch.zeros(10, 512, device=gpu)[:, :256], torch.zeros(1, 256, device=gpu))
     with pytest.raises(RuntimeError):
-        ops.cosine_scores(torch.zeros(10, 512, device=gpu), torch.zeros(17, 512, device=gpu))
+        ops.cosine_scores(torch.zeros(10, 512, device=gpu), torch.zeros(65, 512, device=gpu))

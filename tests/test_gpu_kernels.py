@@ -291,7 +291,8 @@ def test_attention_spike(gpu):
 
 
 # ------------------------------------------------------------------ top-k
-@pytest.mark.parametrize("N,Q,k", [(1000, 16, 100), (37, 3, 37), (5000, 1, 100), (20000, 20, 7), (4097, 2, 2048)])
+@pytest.mark.parametrize("N,Q,k", [(1000, 16, 100), (37, 3, 37), (5000, 1, 100), (20000, 20, 7), (4097, 2, 2048),
+                                   (8192, 5, 100), (8193, 64, 100), (8209, 17, 1), (30011, 70, 100), (50000, 33, 2048), (9000, 48, 300)])
 def test_topk_bit_exact(gpu, N, Q, k):
     from domain_rag_amd import ops
     from oracle import retrieval as oret
@@ -322,6 +323,56 @@ def test_topk_ties_and_padding(gpu):
     D2r, I2r = oret.cosine_topk(corpus[:10], qs, 16)
     assert np.array_equal(I2.cpu().numpy(), I2r) and np.array_equal(D2.cpu().numpy(), D2r)
     assert (I2.cpu().numpy()[:, 10:] == -1).all()
+
+
+def test_topk_when_the_sample_misrepresents_the_corpus(gpu):
+    """round 3: the scan keeps a score only if it beats the k-th best of a strided 8192-row SAMPLE.  Here the corpus is arranged
+    so that every sampled row scores at the bottom: nearly all N rows pass the filter (far more than one LDS slice), the
+    selection streams them slice by slice, and the answer is still the oracle's, bit for bit.  Also: a corpus of identical
+    rows (every score ties -> index order), and NaN / inf rows inside a filtered scan."""
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(17)
+    N, Q, k = 40000, 3, 100
+    qs = rng.standard_normal((Q, 512)).astype(np.float32)
+    corpus = rng.standard_normal((N, 512)).astype(np.float32)
+    ngroups = (N + 15) // 16
+    stride = ngroups // 512
+    sampled = np.zeros(N, dtype=bool)
+    for i in range(512):
+        sampled[i * stride * 16: i * stride * 16 + 16] = True
+    corpus[sampled] = -10.0 * qs.sum(0)                        # the sampled rows: strongly anti-aligned with every query
+    D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu), k)
+    Dr, Ir = oret.cosine_topk(corpus, qs, k)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+    same = np.tile(rng.standard_normal((1, 512)).astype(np.float32), (20000, 1))
+    D, I = ops.cosine_topk(torch.from_numpy(same).to(gpu), torch.from_numpy(qs).to(gpu), k)
+    assert (I.cpu().numpy() == np.arange(k)[None]).all() and (D.cpu().numpy() == D.cpu().numpy()[:, :1]).all()
+    Dr, Ir = oret.cosine_topk(same, qs[:1], k)
+    assert np.array_equal(D.cpu().numpy()[:1], Dr) and np.array_equal(I.cpu().numpy()[:1], Ir)
+    odd = rng.standard_normal((12000, 512)).astype(np.float32)
+    odd[5, 7] = np.nan; odd[11000, :] = np.inf; odd[640, :] = -np.inf; odd[3000:3100] = 0.0
+    q1 = np.abs(qs[:2])
+    D, I = ops.cosine_topk(torch.from_numpy(odd).to(gpu), torch.from_numpy(q1).to(gpu), 2048)
+    Dr, Ir = oret.cosine_topk(odd, q1, 2048)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+    assert I[0, 0].item() == 11000
+
+
+def test_topk_q64_is_one_call_and_equals_q16_calls(gpu):
+    """64 queries in one launch (4 query tiles sharing the corpus rows through L2) == four calls of 16, bit for bit; the scan-only
+    entry now takes up to 64 queries"""
+    from domain_rag_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(3)
+    corpus = torch.randn(23457, 512, generator=g, device=gpu)
+    q = torch.randn(64, 512, generator=g, device=gpu)
+    D, I = ops.cosine_topk(corpus, q, 100)
+    for a in range(0, 64, 16):
+        d, i = ops.cosine_topk(corpus, q[a:a + 16].contiguous(), 100)
+        assert torch.equal(D[a:a + 16], d) and torch.equal(I[a:a + 16], i)
+    sc = ops.cosine_scores(corpus, q)
+    for a in (0, 16, 37):
+        assert torch.equal(sc[a:a + 5, :23457], ops.cosine_scores(corpus, q[a:a + 5].contiguous())[:, :23457])
 
 
 def test_l2_normalize(gpu):
