@@ -400,6 +400,8 @@ def run_generate(args, d: Dist):
         del job
         torch.cuda.empty_cache()
         out["side_configs"] = {"configs1": side_config1(d.dev)}
+        torch.cuda.empty_cache()
+        out["side_configs"]["retrieval"] = side_retrieval(d.dev, cpu_budget_s=0.0 if args.no_cpu_baseline else 20.0)
     if not args.no_cpu_baseline and d.world == 1:
         out["cpu_baseline"] = cpu_baseline_generate(args.res, args.denoise_steps)
     return out
@@ -434,6 +436,76 @@ def side_config1(dev) -> dict:
     return {"workload": "BASELINE configs[1]: Flux-schnell shape 512x512, 4 steps, batch=1 (latency case: 1536 joint rows)",
             "value": 1.0 / dt, "unit": "images/s", "ms_per_image": dt * 1e3, "achieved_tflops": flops / dt / 1e12,
             "mfma_frac": flops / dt / (MFMA_BF16_PEAK_TF * 1e12)}
+
+
+def side_retrieval(dev, k: int = 100, cpu_budget_s: float = 20.0) -> dict:
+    """the retrieval side of the path as a side field of the DEFAULT line (N = 1 only, about 15 s; SURVEY 8(d)'s retrieval rows):
+    the HBM-bound scan and the whole exact top-k call at N = 118 287 (BASELINE configs[4]'s corpus: 242 MB, Infinity-Cache
+    resident across repeats) AND at N = 1 000 000 (2.05 GB: HBM, not cache), Q = 1 / 16 / 64 queries per call; the float32 CLIP
+    tower on 4096 resident crops; BASELINE configs[0] on the host cores.  `--workload retrieval` is the full second line."""
+    from domain_rag_amd import ops
+    from domain_rag_amd.retrieval import embed_images, load_clip
+    ev = lambda: torch.cuda.Event(enable_timing=True)            # noqa: E731
+
+    def timed(fn, reps=20, warm=3):
+        for _ in range(warm):
+            fn()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    out = {"k": k, "d": 512, "peak_GBs": HBM_PEAK_GBS, "measured_achievable_GBs": HBM_MEASURED_GBS, "shapes": {}}
+    g = torch.Generator(device=dev).manual_seed(11)
+    for N in (118287, 1000000):
+        corpus = torch.randn(N, 512, device=dev, generator=g)
+        corpus /= corpus.norm(dim=-1, keepdim=True)              # test-data preparation, outside every timed region
+        planted = torch.randint(0, N, (64,), generator=g, device=dev)
+        qs = (corpus[planted] + 0.02 * torch.randn(64, 512, generator=g, device=dev)).contiguous()
+        row = {}
+        for Q in (1, 16, 64):
+            q = qs[:Q].contiguous()
+            sc = ops.cosine_scores(corpus, q)
+            scan_ms = timed(lambda: ops.cosine_scores(corpus, q, out=sc))
+            call_ms = timed(lambda: ops.cosine_topk(corpus, q, k))
+            D, I = ops.cosine_topk(corpus, q, k)
+            scan_bytes = N * 512 * 4 + Q * 512 * 4 + Q * sc.shape[1] * 4
+            call_bytes = N * 512 * 4 + Q * 512 * 4 + Q * k * 12                # SURVEY 8(d)
+            mfma_ms = 2.0 * N * 512 * Q / (MFMA_F32_PEAK_TF * 1e12) * 1e3
+            row[f"Q{Q}"] = {"scan_us": scan_ms * 1e3, "scan_GBs": scan_bytes / scan_ms / 1e6, "scan_frac_hbm": scan_bytes / scan_ms / 1e6 / HBM_PEAK_GBS,
+                            "scan_tflops_f32": 2.0 * N * 512 * Q / scan_ms / 1e9,
+                            "topk_call_us": call_ms * 1e3, "topk_GBs": call_bytes / call_ms / 1e6,
+                            "topk_scan_plus_select_frac": call_bytes / call_ms / 1e6 / HBM_PEAK_GBS,
+                            "f32_mfma_floor_us": mfma_ms * 1e3, "bound": "mfma_f32" if mfma_ms > call_bytes / (HBM_PEAK_GBS * 1e6) else "hbm",
+                            "planted_neighbour_first": f"{int((I[:, 0] == planted[:Q]).sum().item())}/{Q}"}
+        out["shapes"][f"N{N}"] = row
+        del corpus
+    torch.cuda.empty_cache()
+    out["formula"] = ("topk bytes = N*512*4 + Q*512*4 + Q*k*12 (SURVEY 8d), ONE corpus pass for Q <= 64; scan bytes add the Q*ceil64(N)*4 "
+                      "score rows the scan-only entry writes.  At Q = 64 the exact-f32 matrix core, not HBM, is the floor: 2*N*512*Q flop at "
+                      f"{MFMA_F32_PEAK_TF} TFLOP/s (f32_mfma_floor_us)")
+    # the tower: 4096 resident 224^2 crops through the float32 CLIP ViT-B/32
+    model, _ = load_clip("ViT-B/32", dev, weights=None, seed=0, precision="fp32")
+    crops = synthetic_crops(0, 4096, dev)
+    embed_images(model, crops, 1024)
+    rec = ops.GemmRecorder(f32=True)
+    ops.set_recorder(rec)
+    try:
+        embed_images(model, crops, 1024)
+    finally:
+        ops.set_recorder(None)
+    e_ms = timed(lambda: embed_images(model, crops, 1024), reps=3, warm=0)
+    flops, ms, launches = rec.totals()
+    out["embed"] = {"images_per_s": 4096 / e_ms * 1e3, "kernel": "conv2d_f32_kernel", "achieved_tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                    "peak_tflops": MFMA_F32_PEAK_TF, "launches_timed": launches, "batch": 1024}
+    del model, crops
+    torch.cuda.empty_cache()
+    if cpu_budget_s > 0:
+        out["cpu_config0"] = cpu_baseline_retrieval(k, budget_s=cpu_budget_s)
+    return out
 
 
 def synthetic_crops(lo: int, hi: int, device, chunk: int = 2048) -> torch.Tensor:
@@ -497,7 +569,7 @@ def run_retrieval(args, d: Dist):
     # checks (outside the timed region): planted neighbours come back first on this rank's queries
     hits = int((I[:, 0] == planted[qs:qe]).sum().item()) if qe > qs else 0
     # the HBM-bound scan kernel alone, events on the launch stream
-    q16 = queries[: min(16, queries.shape[0])]
+    q16 = queries[: min(16, queries.shape[0])]                 # the roofline figure is quoted at 16 queries per pass, as in rounds 1-2
     sc = ops.cosine_scores(corpus, q16)
     reps = 20
     e0, e1 = ev(), ev()
@@ -537,7 +609,11 @@ def run_retrieval(args, d: Dist):
         "roofline": {"bound": "hbm", "kernel": "ip_scan_kernel", "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "frac_of_measured_achievable": scan_bytes / (scan_ms * 1e-3) / 1e9 / HBM_MEASURED_GBS,
-                     "traffic": _pmc_traffic("ip_scan_kernel")[0], "avg_launch_ms": scan_ms, "launches_timed": reps,
+                     "traffic": _pmc_traffic("ip_scan_kernel")[0],
+                     "traffic_note": "fabric-side bytes per launch of the scan at this N, FETCH_SIZE scaled by the factor measured on the same "
+                                     "kernel at N = 1 000 000 (past the Infinity Cache), + WRITE_SIZE; Infinity-Cache hits are counted: a 242 MB "
+                                     "corpus stays cache-resident across repeated launches",
+                     "avg_launch_ms": scan_ms, "launches_timed": reps,
                      "algorithmic_bytes_per_launch": scan_bytes, "queries_per_pass": qn,
                      "topk_scan_plus_select": {"avg_call_ms": topk_ms, "achieved": topk_bytes / (topk_ms * 1e-3) / 1e9,
                                                "frac": topk_bytes / (topk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

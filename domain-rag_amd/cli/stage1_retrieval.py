@@ -71,7 +71,7 @@ def style_cache_meta(stem) -> dict:
         backend = "cv2"
     except ImportError:
         backend = "cv2-restated"
-    if getattr(stem, "gpu_files", False):
+    if getattr(stem, "gpu_files", False) or getattr(stem, "force_restated", False):
         backend = "cv2-restated"            # the device route and its host detour both use the restated tables
     return {"stem": tensor_fingerprint([stem.state[k] for k in sorted(stem.state)]), "resize": backend}
 
@@ -131,6 +131,12 @@ def build_parser():
     p.add_argument("--decode", choices=["gpu", "host"], default="gpu",
                    help="corpus JPEG decode: on the GPU (default; byte-identical to PIL, the host only reads the files) or on the "
                         "host (PIL in --decode-procs worker processes / threads)")
+    p.add_argument("--style-resize", choices=["auto", "cv2", "restated"], default="auto",
+                   help="256x256 resize of the ResNet-stem style re-rank (retrieval/clip100_resnet_style_all_shots.py:186-192 calls "
+                        "cv2.imread + cv2.resize): 'cv2' = the real OpenCV calls on the host, exactly the reference's pixels; 'restated' = "
+                        "OpenCV's INTER_LINEAR restated (parity with cv2 UNPINNED: OpenCV is absent from the build box), which is what "
+                        "lets the candidates of a query be decoded + resized on the GPU in one batch; 'auto' (default) = cv2 whenever "
+                        "OpenCV is importable, restated otherwise")
     p.add_argument("--host-preprocess", action="store_true",
                    help="resize on the host with PIL like the reference (default: PIL-exact resize on the GPU; same bits)")
     p.add_argument("--style-cache", type=str, default=None,
@@ -344,6 +350,21 @@ def retrieve_dataset(args, dataset, shot, model, preprocess, stem, feats, paths,
     return all_results
 
 
+def style_resize_mode(choice: str) -> str:
+    """'cv2' or 'restated' for the style re-rank's 256x256 resize.  With OpenCV installed the reference's own calls decide the final
+    ranks (near-tied candidates can order differently under the restated, unpinned resize), so 'auto' keeps them; the batched GPU
+    route is the default only where OpenCV does not exist, and opt-in (--style-resize restated) where it does."""
+    if choice == "restated":
+        return "restated"
+    try:
+        import cv2  # noqa: F401
+        return "cv2"
+    except ImportError:
+        if choice == "cv2":
+            raise SystemExit("--style-resize cv2: OpenCV (cv2) is not importable in this environment")
+        return "restated"
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     results_dir = args.output_dir or RESULTS_DIR
@@ -364,7 +385,8 @@ def main(argv=None):
     if not args.host_preprocess:
         preprocess = R.load_clip_device_preprocess(device)
     stem = R.StemStyle(torch.load(resnet_w, map_location="cpu") if resnet_w else None, device)
-    stem.gpu_files = args.decode == "gpu"
+    stem.force_restated = style_resize_mode(args.style_resize) == "restated"
+    stem.gpu_files = args.decode == "gpu" and stem.force_restated
     feats, paths = {}, {}
     if args.dataset_source in ("coco", "both"):
         f, p = load_or_compute_features(args, "coco", args.coco_dir, None, args.pretrained_coco_features, args.pretrained_coco_paths,

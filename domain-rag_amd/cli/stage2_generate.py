@@ -207,12 +207,27 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
 def run_timestamp(world: int) -> str:
     """the ``_<timestamp>`` suffix of a results directory (batch_generate_flux_kshot.py:798-802).  One process: now, like the
     reference.  Several ranks of one launch must agree on ONE directory per dataset (each rank calling now() splits a dataset run
-    over directories whenever the ranks cross a second boundary): $DRAG_TIMESTAMP if the launcher exports one, else the start
-    time of the common parent process (the torch.distributed.run agent), which every rank reads identically from /proc."""
+    over directories whenever the ranks cross a second boundary): $DRAG_TIMESTAMP if the launcher exports one; else rank 0's
+    clock, BROADCAST over a gloo process group (works across nodes and under any launcher that provides RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT — torchrun, srun + env, mpirun wrappers; the data path itself needs no collective, the group exists
+    for this one string); only if no rendezvous is possible, the start time of the common parent process read from /proc (same
+    node, same parent only — the warning says so)."""
     env = os.environ.get("DRAG_TIMESTAMP")
     if env:
         return env
     if world > 1:
+        try:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+                    raise RuntimeError("MASTER_ADDR / MASTER_PORT are not set")
+                from datetime import timedelta
+                dist.init_process_group("gloo", timeout=timedelta(seconds=300))
+            box = [datetime.now().strftime("%Y%m%d_%H%M%S")]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        except Exception as e:
+            print(f"警告：无法通过进程组广播时间戳 ({e})；退回到父进程启动时间（仅限同一节点、同一父进程）")
         try:
             with open(f"/proc/{os.getppid()}/stat") as f:
                 ticks = int(f.read().rsplit(")", 1)[1].split()[19])          # field 22: start time in clock ticks since boot

@@ -131,7 +131,8 @@ struct AttnArgs {
   int B, S, H, ld_qk, ld_o, s_pad;
   long long qk_bs, o_bs;
   float c;  // scale * log2(e)
-  unsigned k_bytes, vt_bytes;
+  unsigned k_bytes, vt_bytes;          // span of ONE (batch, head) in the K tensor / the V^T tensor (attention_q64_kernel's descriptors)
+  unsigned k_bytes_all, vt_bytes_all;  // span of the whole K tensor (all batches, all heads) / the whole V^T tensor (attention_d128_kernel)
   // optional Q preparation fused into the fragment load (all null / 0 = q is used as stored):
   const bf16_t *wq_txt, *wq_img;   // RMSNorm weights [128] of the text / image stream (rows < s_txt are text)
   const float *cosT, *sinT;        // RoPE tables [S, 64]
@@ -157,7 +158,14 @@ constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 //       quad that this half-wave's P registers 0-3 hold, the second the quad of registers 4-7, so the key permutation the V^T
 //       image needed is absorbed by the addresses.  16-byte units of a key row are XOR-swizzled with 4 * (key & 3): the 16 units
 //       (4 keys x 64 B) a 32-lane access touches fall into 16 different bank groups.  Same MFMA operands -> same bits as the V^T kernels.
-template <int NW, int SCHED, bool QPREP, bool PMAX, bool VROW = false>   // NW: waves per block (4 or 8), 32 queries each; QPREP: RMSNorm + RoPE of q on load
+// PERSIST (round 3): one workgroup per CU walks the items (batch-head, query block) loc = slot, slot + P/8, ... of its XCD's list and
+//       the K / V^T LDS-DMA stream runs CONTINUOUSLY across them: the last two KV iterations of an item — whose prefetches used to
+//       fetch tiles past the sequence end that nobody reads — fetch tiles 0, 0, 1 of the NEXT item instead, so the next item starts
+//       with its operands in LDS and pays neither a workgroup dispatch nor the first HBM round trip.  Measured per workgroup outside
+//       its KV loop before this (scripts/bench_attn_seams.py, B=8 S=5337): 6.6 us plain, 10.9 us with the q preparation = 4.3 % / 7.0 %
+//       of an 84-tile workgroup.  The descriptors span the whole K / V^T tensors and an item is a scalar byte offset, so switching
+//       items costs two SGPRs.  Same arithmetic per item: bit-identical outputs.
+template <int NW, int SCHED, bool QPREP, bool PMAX, bool VROW = false, bool PERSIST = false>   // NW: waves per block (4 or 8), 32 queries each; QPREP: RMSNorm + RoPE of q on load
 __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
   const int w = wave_id(), l = lane_id();
@@ -167,20 +175,29 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   constexpr int QB = NW * 32;          // queries per block
   constexpr int CPW = 16 / NW;         // 1-KiB DMA chunks per wave per tile (K and V^T tiles have 16 each)
   const int nqb = (p.S + QB - 1) / QB;
-  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int bh = (loc / nqb) * 8 + xcd;
-  if (bh >= p.B * p.H) return;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = (loc - (loc / nqb) * nqb) * QB + w * 32;
+  const int xcd = blockIdx.x & 7;
+  int loc = blockIdx.x >> 3;           // index into this XCD's item list: item -> (bh = (loc / nqb) * 8 + xcd, query block loc % nqb)
+  const int nloc = ((p.B * p.H + 7) / 8) * nqb;
+  const int lstep = PERSIST ? (int)(gridDim.x >> 3) : nloc;
+  if (((loc / nqb) * 8 + xcd) >= p.B * p.H) return;      // (PERSIST launches only when B * H is a multiple of 8: every item exists)
+  int b, h, q0;
+  unsigned soK, soV;                  // scalar byte offsets of this item's (batch, head) inside the K tensor / the V^T (or V) tensor
+  auto item_offsets = [&](int lc, int& bb, int& hd, unsigned& ok, unsigned& ov) {
+    const int bh = (lc / nqb) * 8 + xcd;
+    bb = bh / p.H; hd = bh - bb * p.H;
+    ok = (unsigned)(((long long)bb * p.qk_bs + hd * 128) * 2);
+    ov = VROW ? ok : (unsigned)((((long long)(bb * p.H + hd)) * 128) * p.s_pad * 2);
+  };
+  item_offsets(loc, b, h, soK, soV);
+  q0 = (loc - (loc / nqb) * nqb) * QB + w * 32;
 
   // ---- Q fragments stay in registers: B operand, lane -> query (l&31), k = 16ks + 8hh .. +8 (loaded below, after the
   // first K / V^T tiles have been requested: one workgroup per CU, so nothing else hides this prologue's latency) ----
   bf16x8_t qf[8];
-  // ---- staging descriptors ----
-  const bf16_t* kbase = p.k + (long long)b * p.qk_bs + h * 128;
-  const bf16_t* vbase = VROW ? p.v + (long long)b * p.qk_bs + h * 128 : p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
-  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, VROW ? p.k_bytes : p.vt_bytes, 0x00020000);
+  // ---- staging descriptors: the WHOLE K tensor / V^T tensor; the item is the scalar offset ----
+  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, p.k_bytes_all, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(VROW ? p.v : p.vt), 0, VROW ? p.k_bytes_all : p.vt_bytes_all, 0x00020000);
+  unsigned soKn = soK, soVn = soV;    // the NEXT item's offsets (PERSIST; = this item's when there is none: harmless re-reads)
   // K chunk c (1 KiB) = key rows 4c..4c+3; lane: row 4c + (l>>4), physical slot l&15
   // V chunk c (1 KiB) = d rows 8c..8c+7;   lane: row 8c + (l>>3), physical slot l&7
   int krow[4];                        // (fixed-size: a template-dependent array bound here makes hipcc drop the host stub)
@@ -197,31 +214,33 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     const int vslot = (l & 7) ^ ((vrow >> 1) & 7);
     voff[i] = (unsigned)(((long long)vrow * p.s_pad + vslot * 8) * 2);
   }
+  // tile index kv0 >= s_pad names tile kv0 - s_pad of the NEXT item (PERSIST): wave-uniform selects, no branches
+  auto stage_k1 = [&](int buf, int kv0, int i) {
+    const int c = w * CPW + i;
+    const bool nx = PERSIST && kv0 >= p.s_pad;
+    const int kvr = nx ? kv0 - p.s_pad : kv0;
+    const int kr = min(kvr + krow[i], p.S - 1);
+    const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024), 16, ko, nx ? soKn : soK, 0, 0);
+  };
   auto stage_k = [&](int buf, int kv0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i >= CPW) break;
-      const int c = w * CPW + i;
-      const int kr = min(kv0 + krow[i], p.S - 1);
-      const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
-      DRAG_LDS char* dK = (DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)dK, 16, ko, 0, 0, 0);
+      stage_k1(buf, kv0, i);
     }
-  };
-  auto stage_k1 = [&](int buf, int kv0, int i) {
-    const int c = w * CPW + i;
-    const int kr = min(kv0 + krow[i], p.S - 1);
-    const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024), 16, ko, 0, 0, 0);
   };
   auto stage_v1 = [&](int buf, int kv0, int i) {
     const int c = w * CPW + i;
+    const bool nx = PERSIST && kv0 >= p.s_pad;
+    const int kvr = nx ? kv0 - p.s_pad : kv0;
+    const unsigned so = nx ? soVn : soV;
     DRAG_LDS char* dV = (DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024;
     if constexpr (VROW) {
-      const int vr = min(kv0 + krow[i], p.S - 1);          // rows past S are real rows: finite values under a zero probability
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, (unsigned)((long long)vr * p.ld_qk * 2) + vrslot, 0, 0, 0);
+      const int vr = min(kvr + krow[i], p.S - 1);          // rows past S are real rows: finite values under a zero probability
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, (unsigned)((long long)vr * p.ld_qk * 2) + vrslot, so, 0, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, voff[i], kv0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)dV, 16, voff[i], so + (unsigned)(kvr * 2), 0, 0);
     }
   };
   auto stage_v = [&](int buf, int kv0) {
@@ -241,12 +260,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   const int vx = ((l & 31) >> 1) & 7;
 
   f32x16_t oacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
+  float m_run, l_run;
 
   const int nkv = p.s_pad / 64;
   f32x16_t scur[2], snext[2];
@@ -295,6 +309,18 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   stage_k(0, 0);
   stage_v(0, 0);
   if (nkv > 1) stage_k(1, 64);
+  for (;;) {                           // items of this workgroup (one, unless PERSIST)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  m_run = -INFINITY; l_run = 0.f;
+  const bool has_next = PERSIST && loc + lstep < nloc;
+  if (PERSIST) {                       // where the stream goes when this item's tiles run out
+    int bn, hn;
+    if (has_next) item_offsets(loc + lstep, bn, hn, soKn, soVn);
+    else { soKn = soK; soVn = soV; }
+  }
   // Q load (+ RMSNorm / RoPE when QPREP) while those tiles are in flight
   {
     const int qr = min(q0 + (l & 31), p.S - 1);
@@ -464,7 +490,6 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     body(it, std::integral_constant<int, 0>{}, scur, snext);
     if (it + 1 < nkv) body(it + 1, std::integral_constant<int, 1>{}, snext, scur);
   }
-  }
 
   // ---- epilogue: lane holds O[query l&31][d = 32dt + 8(r>>2) + 4hh + (r&3)] ----
   const float lt = l_run + __shfl_xor(l_run, 32, 64);
@@ -500,6 +525,13 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
         o[1] = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
         *(u32x2_t*)(op + 32 * dt + 8 * g) = o;
       }
+  }
+  if (!has_next) break;
+  // ---- next item: its K(0), V^T(0), K(1) tiles are already in LDS / in flight (issued by the last two KV iterations) ----
+  loc += lstep;
+  item_offsets(loc, b, h, soK, soV);
+  q0 = (loc - (loc / nqb) * nqb) * QB + w * 32;
+  }                                    // items
   }
 }
 
@@ -883,6 +915,19 @@ extern "C" int drag_attention_v_bf16(const void* q, const void* k, const void* v
                           rope_sin, s_txt, eps, stream, true);
 }
 
+// workgroups per XCD of the persistent attention kernel
+static int persist_slots() {
+  const int opt = drag_opt(DRAG_OPT_ATTN_PERSIST);
+  if (opt >= 3) return opt;
+  static int ncu8 = 0;
+  if (ncu8 == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu8 = n / 8 > 0 ? n / 8 : 1;
+  }
+  return ncu8;
+}
+
 static int attention_launch(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S, int32_t H,
                             int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
                             const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt,
@@ -901,6 +946,9 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   const long long vspan = (long long)128 * p.s_pad * 2;
   DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
+  const long long kall = ((long long)(B - 1) * qk_batch_stride + (H - 1) * 128) * 2 + kspan, vall = (long long)B * H * vspan;
+  DRAG_CHECK(kall < (1ll << 32) && vall < (1ll << 32), "drag_attention_bf16: the K / V^T tensors must span < 4 GiB (32-bit offsets)");
+  p.k_bytes_all = (unsigned)kall; p.vt_bytes_all = (unsigned)vall;
   const int groups = (B * H + 7) / 8;
   const bool w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
   const int QB = (w8 || (!vrow && drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024)) ? 256 : 128;
@@ -926,6 +974,14 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   } else if (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024) {
     if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attention_q64_kernel<false>), grid, dim3(256), 0, st, p);
+  } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 2 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&
+             nqb2 * groups > persist_slots()) {
+    // persistent form: one workgroup per CU, the K / V^T stream runs on across its items (the KV loop is unrolled by two: an even
+    // number of tiles keeps the buffer parity across items).  "attn_persist": 0 = on with one workgroup per CU, 2 = off, n >= 3 = on
+    // with n workgroups per XCD (tests: many items per workgroup).  Same bits either way.
+    const dim3 pgrid(8 * persist_slots());
+    if (qprep) hipLaunchKernelGGL((attention_d128_kernel<8, 1, true, true, false, true>), pgrid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((attention_d128_kernel<8, 1, false, true, false, true>), pgrid, dim3(512), 0, st, p);
   } else if (w8) DRAG_ATTN_PICK(8); else DRAG_ATTN_PICK(4);
 #undef DRAG_ATTN_PICK
 #undef DRAG_ATTN_LAUNCH

@@ -92,6 +92,39 @@ class StagedFiles:
     def file_bytes(self, i: int) -> bytes:
         return self.buf.numpy()[self.offsets[i]: self.offsets[i + 1]].tobytes()
 
+    def slice(self, a: int, b: int) -> "StagedFiles":
+        """files [a, b) as a batch of their own (a view of the same pinned buffer; the PAD bytes behind it are the next file's)"""
+        o = int(self.offsets[a])
+        return StagedFiles(self.buf[o:], self.offsets[a: b + 1] - o, {k - a: v for k, v in self.errors.items() if a <= k < b})
+
+
+def parse_pixels(staged: "StagedFiles", device="cuda") -> np.ndarray:
+    """width * height per file as the device parser reads the headers (0 for files it will not decode): what a caller needs to
+    cut a batch so that its decode buffers (about 7.5 bytes per pixel: RGB out, int16 coefficients, sample planes) fit a budget"""
+    lib = _lib.load()
+    n = len(staged)
+    device = torch.device(device)
+    data = staged.buf[: int(staged.offsets[-1]) + PAD].to(device, non_blocking=True)
+    d_off = torch.from_numpy(np.ascontiguousarray(staged.offsets)).to(device)
+    d_info = torch.empty((n, INFO_WORDS), dtype=torch.int32, device=device)
+    check(lib.drag_jpeg_parse(_p(data), _p(d_off), n, _p(d_info), _stream()), "drag_jpeg_parse")
+    info = d_info.cpu().numpy()
+    return np.where(info[:, 0] == 0, info[:, 1].astype(np.int64) * info[:, 2].astype(np.int64), 0)
+
+
+def budget_bounds(pixels: np.ndarray, max_pixels: int) -> list:
+    """[(a, b)] consecutive index ranges whose pixel sums stay within ``max_pixels`` (a single file above the budget gets a range
+    of its own: the parser already refuses anything above 2^24 pixels)"""
+    bounds, a, acc = [], 0, 0
+    for i, px in enumerate(pixels.tolist()):
+        if i > a and acc + px > max_pixels:
+            bounds.append((a, i))
+            a, acc = i, 0
+        acc += px
+    if a < len(pixels):
+        bounds.append((a, len(pixels)))
+    return bounds
+
 
 def stage_paths(paths, device="cuda", slot: int = 0, threads: int = 32) -> StagedFiles:
     """read files straight into the pinned staging buffer (no bytes objects, no concatenation pass) with the library's native
@@ -152,7 +185,7 @@ def decode_files(blobs, device="cuda", check_scan: bool = True) -> DecodedBatch:
         data = blobs.buf[: int(offsets[-1]) + PAD].to(device, non_blocking=True)
     else:
         data, offsets = _upload(blobs, device)
-    d_off = torch.from_numpy(offsets).to(device)
+    d_off = torch.from_numpy(np.ascontiguousarray(offsets)).to(device)
     d_info = torch.empty((n, INFO_WORDS), dtype=torch.int32, device=device)
     check(lib.drag_jpeg_parse(_p(data), _p(d_off), n, _p(d_info), _stream()), "drag_jpeg_parse")
     info = d_info.cpu().numpy()                       # the one synchronisation: sizes are needed to plan the outputs

@@ -242,6 +242,7 @@ class StemStyle:
         self.scale, self.shift = scale.contiguous().to(dev), shift.contiguous().to(dev)
         self.device = dev
         self.gpu_files = False      # set by stage 1 (--decode gpu): candidate files are decoded / resized on the device in batches
+        self.force_restated = False  # set by stage 1 (--style-resize restated): never call cv2, also on the host route
 
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
         """fp32 [B,3,H,W] in [0,1] -> fp32 [B,128] = cat(mean, std)   (ref :197-200)"""
@@ -299,7 +300,7 @@ class StemStyle:
         image_path = clean_image_path(image_path)
         try:
             try:
-                if restated_resize:
+                if restated_resize or self.force_restated:
                     raise ImportError("restated resize requested")
                 import cv2
                 img = cv2.imread(image_path)
@@ -443,12 +444,16 @@ def allgather_rows(local: torch.Tensor, n_total: int, group=None, force: bool = 
 
 
 def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch.Tensor, ok: torch.Tensor, batch: int,
-                            files_per_batch: int = 16384, readers: int = 32) -> dict:
+                            files_per_batch: int = 16384, readers: int = 32, max_pixels: int | None = None) -> dict:
     """corpus rows of this rank with the JPEG decode on the GPU.  Reader threads put the FILES of a chunk straight into a pinned
     buffer (``jpeg.stage_paths``), the chunk is uploaded as one blob, decoded (``jpeg.decode_files``: byte-identical to
     ``Image.open(f).convert("RGB")``), resized + centre-cropped per size class by the PIL-exact resample kernel and embedded.
     The entropy decoder runs one image per LANE (~0.15 s for a 125-KiB file whatever the batch), so its throughput is its batch:
     16384 files are 256 waves = every CU once; the reads of chunk c + 1 overlap the GPU work of chunk c.
+    A chunk's decode buffers take about 7.5 bytes per pixel, so a chunk whose headers add up to more than ``max_pixels`` (default
+    2^33 = 64 GB of buffers; 16384 files of 640x480 are 5e9 pixels = 38 GB and stay one piece; $DRAG_JPEG_MAX_PIXELS overrides)
+    is decoded in consecutive pieces that each stay within it — a corpus of multi-megapixel files (mini-ImageNet has some) costs more launches, never an
+    out-of-memory abort (the reference decodes one file at a time and takes any size).
     Files outside the device decoder's coverage (progressive, CMYK, PNG, damaged, ...) go through PIL on the host, one by one, like
     the reference does for every file; what PIL cannot open is skipped with the reference's message (:290-292).  Returns counters."""
     import concurrent.futures as cf
@@ -456,8 +461,10 @@ def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch
     from PIL import Image
     from . import jpeg, resample
     dev = model.device
-    stats = {"gpu_decoded": 0, "host_decoded": 0, "failed": 0}
+    stats = {"gpu_decoded": 0, "host_decoded": 0, "failed": 0, "decode_pieces": 0}
     chunks = [list(range(i, min(i + files_per_batch, len(mine)))) for i in range(0, len(mine), files_per_batch)]
+    if max_pixels is None:
+        max_pixels = int(os.environ.get("DRAG_JPEG_MAX_PIXELS", str(1 << 33)))
 
     main = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev)       # decode + resize of chunk c + 1 run here, under the tower of chunk c on `main`
@@ -469,12 +476,19 @@ def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch
             stats["failed"] += 1
         n = len(rows)
         with torch.cuda.stream(side):
-            dec = jpeg.decode_files(staged, dev)
             crops = torch.empty((n, 224, 224, 3), dtype=torch.uint8, device=dev)
             have = np.zeros(n, dtype=bool)
-            for (_h, _w), idx, imgs in dec.groups():
-                crops[torch.from_numpy(idx).to(dev)] = resample.clip_preprocess_u8(imgs)
-                have[idx] = True
+            pieces = [(0, n)]
+            px = jpeg.parse_pixels(staged, dev)
+            if int(px.sum()) > max_pixels:
+                pieces = jpeg.budget_bounds(px, max_pixels)
+            stats["decode_pieces"] += len(pieces)
+            for a, b in pieces:
+                dec = jpeg.decode_files(staged if (a, b) == (0, n) else staged.slice(a, b), dev)
+                for (_h, _w), idx, imgs in dec.groups():
+                    crops[torch.from_numpy(idx + a).to(dev)] = resample.clip_preprocess_u8(imgs)
+                    have[idx + a] = True
+                del dec
             stats["gpu_decoded"] += int(have.sum())
             for g in np.nonzero(~have)[0].tolist():         # the device decoder declined: PIL decides (same bytes by definition)
                 if g in staged.errors:

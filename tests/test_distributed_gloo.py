@@ -63,3 +63,37 @@ def test_single_process_is_identity():
     from domain_rag_amd.retrieval import allgather_rows
     x = torch.randn(5, 4)
     assert allgather_rows(x, 5) is x
+
+
+def _ts_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.pop("DRAG_TIMESTAMP", None)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from domain_rag_amd.cli import stage2_generate as S2
+    time.sleep(1.2 * rank)                      # the ranks reach the call in different seconds
+    a = S2.run_timestamp(world)
+    time.sleep(1.1)
+    b = S2.run_timestamp(world)                 # the next dataset: a NEW stamp (like the reference's now() per dataset), again shared
+    q.put((rank, a, b))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_stage2_ranks_agree_on_rank0s_timestamp_over_gloo():
+    """ranks of one launch write ONE results directory per dataset whatever started them (the parent-process
+    start time only works for same-node children of one parent): rank 0's clock is broadcast over a gloo group"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ts_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    firsts, seconds = {r[1] for r in res}, {r[2] for r in res}
+    assert len(firsts) == 1 and len(seconds) == 1 and firsts != seconds, res

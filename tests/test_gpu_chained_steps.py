@@ -6,10 +6,14 @@ width (D = 3072, 24 heads x 128, joint dim 4096, pooled 768, the full VAE) with 
 
 Chained steps amplify rounding (SURVEY §7 "hard parts"), so the comparison is per step: after every Euler update the packed
 latents of the HIP path and of the reference-dtype (bf16) oracle are both measured against the float32 oracle.  Bars, written
-here: at EVERY step the HIP path's distance from float32 is at most 1.3 x the bf16 oracle's own distance (max-norm and rms,
-relative to the float32 latents' max / rms; a floor of 2e-3 covers the first steps, where both distances are a few bf16 ulps);
-the error may not grow faster than linearly in the step count; final pixels within max(1e-2, 1.3 x the bf16 oracle's distance) of
-full scale.  The per-step curves are printed and written to gpurun_out/ (the round's copy is committed under profiles/)."""
+here: at EVERY step the HIP path's rms distance from float32 is at most 1.1 x the bf16 oracle's own rms distance (measured
+1.00-1.011 at every one of the 30 + 50 steps: profiles/r03_chained_steps_*.json) and its max-norm distance at most 1.3 x the
+oracle's (measured 1.00-1.27: the maximum over 16 384 latent elements of ONE realisation is a noisy statistic — two bf16
+evaluations of one graph with different summation orders disagree on which element is the worst — so it gets the looser of
+the two bars; the rms averages over all elements and is the stable measure).  Distances are relative to the float32 latents'
+rms / max; a floor of 2e-3 covers the first steps, where both distances are a few bf16 ulps.  The error may not grow faster
+than linearly in the step count; final pixels within max(1e-2, 1.3 x the bf16 oracle's distance) of full scale.  The per-step
+curves are printed and written to gpurun_out/ (the round's copy is committed under profiles/)."""
 import json
 import os
 import time
@@ -19,7 +23,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-RATIO = 1.3
+RATIO = 1.3          # max-norm
+RATIO_RMS = 1.1
 FLOOR = 2e-3
 
 
@@ -44,7 +49,7 @@ def _check(rows, what):
         msg = (f"{what} step {r['step']}: HIP vs f32 max {r['hip_max']:.3e} rms {r['hip_rms']:.3e}; bf16 oracle vs f32 max "
                f"{r['bf16_oracle_max']:.3e} rms {r['bf16_oracle_rms']:.3e}; ratio max {r['ratio_max']:.2f} rms {r['ratio_rms']:.2f}")
         assert r["hip_max"] <= max(FLOOR, RATIO * r["bf16_oracle_max"]), msg
-        assert r["hip_rms"] <= max(FLOOR / 4, RATIO * r["bf16_oracle_rms"]), msg
+        assert r["hip_rms"] <= max(FLOOR / 4, RATIO_RMS * r["bf16_oracle_rms"]), msg
     # growth: from the first quarter on, the rms error grows at most linearly with the number of steps taken (a compounding
     # error would grow geometrically); 1.5 x slack for the step-to-step scatter
     n = len(rows)

@@ -244,6 +244,45 @@ def test_attention_schedules_are_bit_identical(gpu):
         ops.set_option("no_such_switch", 1)
 
 
+@pytest.mark.parametrize("B,S,H,s_txt", [(1, 4300, 8, 1241), (2, 4224, 8, 0), (3, 4161, 8, 512), (1, 5337, 24, 1241)])
+def test_persistent_attention_equals_the_one_item_kernel(gpu, B, S, H, s_txt):
+    """round 3: the persistent attention kernel (one workgroup walks many (batch-head, query block) items; the last KV iterations of an
+    item prefetch the next item's first tiles) against the one-item-per-workgroup kernel: same bits, with and without the fused q
+    preparation, with few workgroups per XCD (every workgroup crosses many item seams, ragged last query blocks and key tiles
+    included) and with the product's one per CU"""
+    from domain_rag_amd import ops
+    from oracle import flux as oflux
+    D = H * 128
+    qkv = _randn((B, S, 3 * D), 77 + S).to(gpu)
+    g = torch.Generator().manual_seed(S)
+    wq_t, wq_i = [(1 + 0.1 * torch.randn(128, generator=g)).bfloat16().to(gpu) for _ in range(2)]
+    ids = torch.zeros(S, 3); ids[:, 1] = torch.arange(S) // 41; ids[:, 2] = torch.arange(S) % 41
+    cos, sin = (t.to(gpu) for t in oflux.rope_tables(ids))
+    s_pad = (S + 63) // 64 * 64
+    assert (s_pad // 64) % 2 == 0 and (B * H) % 8 == 0
+    vt = torch.empty((B, H, 128, s_pad), dtype=torch.bfloat16, device=gpu)
+    ops.k_norm_rope_vt(qkv, vt, wq_t, wq_i, cos, sin, B, S, H, 3 * D, s_txt)
+    scale = 1 / math.sqrt(128)
+
+    def run(qprep):
+        o = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
+        if qprep:
+            ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, scale, wq_t, wq_i, cos, sin, s_txt)
+        else:
+            ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
+        return o.cpu()
+    try:
+        ops.set_option("attn_persist", 2)
+        ref = {qp: run(qp) for qp in (False, True)}
+        assert all(torch.isfinite(r.float()).all() for r in ref.values())
+        for slots in (3, 5, 0):
+            ops.set_option("attn_persist", slots)
+            for qp in (False, True):
+                assert torch.equal(run(qp), ref[qp]), (slots, qp)
+    finally:
+        ops.set_option("attn_persist", 0)
+
+
 @pytest.mark.parametrize("B,S,H,s_txt", [(2, 4300, 2, 1241), (1, 5337, 1, 512), (3, 300, 2, 10), (2, 64, 1, 0), (1, 1753, 3, 77), (2, 129, 1, 129)])
 def test_attention_row_major_v_equals_vt_path(gpu, B, S, H, s_txt):
     """drag_attention_v_bf16 reads v straight from the projection buffer (LDS transpose reads) — same MFMA operands as the V^T

@@ -120,6 +120,15 @@ def test_corpus_features_same_bits_through_decode_processes(gpu, tmp_path):
     e, ve = R.compute_corpus_features(model, host_pre, more, batch=5, decode_workers=2)
     assert vd == ve == [p for p in more if "bad" not in p] and d.shape == (26, 512)
     assert np.array_equal(d, e) and np.array_equal(d[:24], a)
+    # a pixel budget far below the chunk (a corpus of multi-megapixel files must cost launches, not an OOM abort):
+    # the chunk is decoded in many consecutive pieces, every file still lands in its own row with the same bits
+    import torch
+    n = len(more)
+    feats = torch.zeros((n, 512), dtype=torch.float32, device=gpu); okf = torch.zeros((n, 1), dtype=torch.float32, device=gpu)
+    st = R._embed_files_gpu_decode(model, more, feats, okf, 16, max_pixels=700 * 500)
+    assert st["decode_pieces"] >= 8 and st["failed"] == 1 and st["gpu_decoded"] + st["host_decoded"] == 26
+    keep = okf[:, 0].bool().cpu().numpy()
+    assert [p for p, k in zip(more, keep) if k] == vd and np.array_equal(feats.cpu().numpy()[keep], d)
 
 
 def test_style_vectors_of_files_on_the_gpu_equal_the_host_route(gpu, tmp_path):

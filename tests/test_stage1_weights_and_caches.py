@@ -91,3 +91,26 @@ def test_clip_fingerprint_sees_every_tensor():
         flat = h[name].view(-1)
         flat[pos] = flat[pos] + 0.5
         assert weights_fingerprint(h) != base, name
+
+
+def test_style_resize_prefers_real_opencv_when_it_exists(monkeypatch):
+    """with OpenCV installed the style re-rank must keep calling cv2 (the reference's pixels) unless the restated,
+    parity-unpinned resize — the only one the GPU batch route can use — is asked for; without OpenCV the restated one is the default"""
+    import builtins
+    import sys
+    import types
+    import pytest
+    real_import = builtins.__import__
+
+    def no_cv2(name, *a, **k):
+        if name == "cv2":
+            raise ImportError("No module named 'cv2'")
+        return real_import(name, *a, **k)
+    monkeypatch.delitem(sys.modules, "cv2", raising=False)
+    monkeypatch.setattr(builtins, "__import__", no_cv2)
+    assert S1.style_resize_mode("auto") == "restated" and S1.style_resize_mode("restated") == "restated"
+    with pytest.raises(SystemExit):
+        S1.style_resize_mode("cv2")
+    monkeypatch.setattr(builtins, "__import__", real_import)
+    monkeypatch.setitem(sys.modules, "cv2", types.ModuleType("cv2"))
+    assert S1.style_resize_mode("auto") == "cv2" and S1.style_resize_mode("cv2") == "cv2" and S1.style_resize_mode("restated") == "restated"
