@@ -158,7 +158,7 @@ constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 //       quad that this half-wave's P registers 0-3 hold, the second the quad of registers 4-7, so the key permutation the V^T
 //       image needed is absorbed by the addresses.  16-byte units of a key row are XOR-swizzled with 4 * (key & 3): the 16 units
 //       (4 keys x 64 B) a 32-lane access touches fall into 16 different bank groups.  Same MFMA operands -> same bits as the V^T kernels.
-// PERSIST (round 3): one workgroup per CU walks the items (batch-head, query block) loc = slot, slot + P/8, ... of its XCD's list and
+// PERSIST (round 3; measured 1 % slower than one item per workgroup, kept off the product path — see attention_launch): one workgroup per CU walks the items (batch-head, query block) loc = slot, slot + P/8, ... of its XCD's list and
 //       the K / V^T LDS-DMA stream runs CONTINUOUSLY across them: the last two KV iterations of an item — whose prefetches used to
 //       fetch tiles past the sequence end that nobody reads — fetch tiles 0, 0, 1 of the NEXT item instead, so the next item starts
 //       with its operands in LDS and pays neither a workgroup dispatch nor the first HBM round trip.  Measured per workgroup outside
@@ -918,7 +918,7 @@ extern "C" int drag_attention_v_bf16(const void* q, const void* k, const void* v
 // workgroups per XCD of the persistent attention kernel
 static int persist_slots() {
   const int opt = drag_opt(DRAG_OPT_ATTN_PERSIST);
-  if (opt >= 3) return opt;
+  if (opt >= 3) return opt;           // (1 = one per CU)
   static int ncu8 = 0;
   if (ncu8 == 0) {
     int dev = 0, n = 0;
@@ -974,11 +974,16 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   } else if (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024) {
     if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attention_q64_kernel<false>), grid, dim3(256), 0, st, p);
-  } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 2 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&
+  } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 0 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&
              nqb2 * groups > persist_slots()) {
-    // persistent form: one workgroup per CU, the K / V^T stream runs on across its items (the KV loop is unrolled by two: an even
-    // number of tiles keeps the buffer parity across items).  "attn_persist": 0 = on with one workgroup per CU, 2 = off, n >= 3 = on
-    // with n workgroups per XCD (tests: many items per workgroup).  Same bits either way.
+    // EXPERIMENT, off by default ("attn_persist": 0 = off, 1 = one workgroup per CU, n >= 3 = n workgroups per XCD — tests: many items
+    // per workgroup): the persistent form, whose K / V^T stream runs on across a workgroup's items (the KV loop is unrolled by two: an
+    // even number of tiles keeps the buffer parity across items).  Same bits either way.  Measured same-box, interleaved
+    // (scripts/ab_attn_persist.py, B=8 S=5337): 2592 vs 2571 us with the q preparation, 2523 vs 2499 us without — 1 % SLOWER: what a
+    // workgroup pays outside its KV loop (6 us plain, 11-12 us with the q preparation) is the round trip + ingest of its Q rows and
+    // RoPE table rows (256 KiB per workgroup through one CU's ~100 GB/s global-load path), not the first K / V^T tiles nor the
+    // dispatch; and the hardware already overlaps the seams of one-item workgroups (a CU holds two of them by LDS and registers, so
+    // the next workgroup's waves start on SIMDs as the old one's retire), which a single persistent workgroup cannot do.
     const dim3 pgrid(8 * persist_slots());
     if (qprep) hipLaunchKernelGGL((attention_d128_kernel<8, 1, true, true, false, true>), pgrid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((attention_d128_kernel<8, 1, false, true, false, true>), pgrid, dim3(512), 0, st, p);

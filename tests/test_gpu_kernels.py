@@ -246,10 +246,10 @@ def test_attention_schedules_are_bit_identical(gpu):
 
 @pytest.mark.parametrize("B,S,H,s_txt", [(1, 4300, 8, 1241), (2, 4224, 8, 0), (3, 4161, 8, 512), (1, 5337, 24, 1241)])
 def test_persistent_attention_equals_the_one_item_kernel(gpu, B, S, H, s_txt):
-    """round 3: the persistent attention kernel (one workgroup walks many (batch-head, query block) items; the last KV iterations of an
-    item prefetch the next item's first tiles) against the one-item-per-workgroup kernel: same bits, with and without the fused q
-    preparation, with few workgroups per XCD (every workgroup crosses many item seams, ragged last query blocks and key tiles
-    included) and with the product's one per CU"""
+    """round 3 experiment (off the product path: measured 1 % slower): the persistent attention kernel (one workgroup walks many
+    (batch-head, query block) items; the last KV iterations of an item prefetch the next item's first tiles) against the product's
+    one-item-per-workgroup kernel: same bits, with and without the fused q preparation, with few workgroups per XCD (every workgroup
+    crosses many item seams, ragged last query blocks and key tiles included) and with one per CU"""
     from domain_rag_amd import ops
     from oracle import flux as oflux
     D = H * 128
@@ -272,10 +272,10 @@ def test_persistent_attention_equals_the_one_item_kernel(gpu, B, S, H, s_txt):
             ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
         return o.cpu()
     try:
-        ops.set_option("attn_persist", 2)
+        ops.set_option("attn_persist", 0)
         ref = {qp: run(qp) for qp in (False, True)}
         assert all(torch.isfinite(r.float()).all() for r in ref.values())
-        for slots in (3, 5, 0):
+        for slots in (3, 5, 1):
             ops.set_option("attn_persist", slots)
             for qp in (False, True):
                 assert torch.equal(run(qp), ref[qp]), (slots, qp)
