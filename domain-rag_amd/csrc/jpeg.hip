@@ -52,9 +52,12 @@ struct JpegArgs {
 };
 
 __global__ __launch_bounds__(64) void jpeg_parse_kernel(const uint8_t* data, const int64_t* off, int n, JpegInfo* info) {
+  // the descriptor is indexed dynamically while it is built (component / table numbers come from the file), so a per-lane local
+  // copy lives in scratch memory (196 B / lane in rounds 1-2); one LDS slot per lane instead: 12 KiB per wave, no scratch
+  __shared__ JpegInfo slot[64];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
-  JpegInfo o;
+  JpegInfo& o = slot[threadIdx.x];
   jpeg_parse(data + off[i], off[i + 1] - off[i], &o);
   if (o.status == 0) {                               // the Huffman kernel keeps four code tables per lane: DC 0/1, AC 0/1,
     const uint8_t* d = data + off[i];                // and 16 symbol slots per DC table (8-bit JPEG has at most 12 categories)
