@@ -175,28 +175,28 @@ __device__ __forceinline__ void epi_row(const GemmKArgs& p, long long coff, int 
   }
 }
 
-// whole-wave epilogue: MI row groups x 4 column groups; rows m = mrow0 + 16*mi, columns nbase + 16*ni
-template <int MI, int TM, int TN = TM>
-__device__ __forceinline__ void wave_epilogue(const GemmKArgs& p, int m0, int mrow0, int n0, int nbase, f32x4_t (*acc)[4]) {
+// whole-wave epilogue: MI row groups x NI column groups; rows m = mrow0 + 16*mi, columns nbase + 16*ni
+template <int MI, int TM, int TN = TM, int NI = 4>
+__device__ __forceinline__ void wave_epilogue(const GemmKArgs& p, int m0, int mrow0, int n0, int nbase, f32x4_t (*acc)[NI]) {
   const int b_first = m0 / p.cm.rpb;
   const bool gate_uniform = b_first == (min(m0 + TM, p.M) - 1) / p.cm.rpb;     // whole tile inside one batch
   const ActCoef ac = act_coef(p.act);
-  ColOps co[4];
+  ColOps co[NI];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) load_colops(p, nbase + ni * 16, b_first, gate_uniform, co[ni]);
+  for (int ni = 0; ni < NI; ++ni) load_colops(p, nbase + ni * 16, b_first, gate_uniform, co[ni]);
   const bool interior = m0 + TM <= p.M && n0 + TN <= p.N;
   if (interior) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = mrow0 + mi * 16;
-      epi_row<4, false>(p, p.cm.off(m), m / p.cm.rpb, nbase, acc[mi], co, gate_uniform, ac);
+      epi_row<NI, false>(p, p.cm.off(m), m / p.cm.rpb, nbase, acc[mi], co, gate_uniform, ac);
     }
   } else {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = mrow0 + mi * 16;
       if (m >= p.M) continue;
-      epi_row<4, true>(p, p.cm.off(m), m / p.cm.rpb, nbase, acc[mi], co, gate_uniform, ac);
+      epi_row<NI, true>(p, p.cm.off(m), m / p.cm.rpb, nbase, acc[mi], co, gate_uniform, ac);
     }
   }
 }
@@ -215,8 +215,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmKArgs& p, int m0, int mr
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
-template <int MI, int TM, bool CHECK>
-__device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[4],
+// A wave with more than 4 column blocks (the 192-column tiles of gemm_bf16_deep: NI = 6) runs the slab pass per GROUP of <= 4
+// blocks: group (NI0, NIG) covers the wave's columns 16 * NI0 .. 16 * (NI0 + NIG); nw0 is the group's first column.  A group of
+// 2 blocks uses the same slab layout with the upper half of its columns (and of the row-side lanes) idle.
+template <int MI, int TM, bool CHECK, int NI = 4, int NI0 = 0, int NIG = 4>
+__device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[NI],
                                             char* scr) {
   const int q = l >> 4, r16 = l & 15;
   const int c = l & 7, rl = l >> 3;
@@ -227,7 +230,7 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
   float bias[4][4];
   bool actv[4];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < NIG; ++ni) {
     const int n = nw0 + ni * 16 + q * 4;
     bias[ni][0] = bias[ni][1] = bias[ni][2] = bias[ni][3] = 0.f;
     if (p.bias && (!CHECK || n < p.N)) {
@@ -243,7 +246,7 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
   const int roff = rl * 128 + ((c ^ rl) << 4);                // + j * 1024; halves swapped for j = 1
   // row side: this lane's 8 columns
   const int n = nw0 + c * 8;
-  const bool col_ok = !CHECK || n + 8 <= p.N;                 // N % 8 == 0 on this path
+  const bool col_ok = (!CHECK || n + 8 <= p.N) && (NIG == 4 || c * 8 < NIG * 16);   // N % 8 == 0 on this path; a short group's upper lanes idle
   float g[8];
   if (p.gate && one_batch && col_ok) {
     const u32x4_t gg = *(const u32x4_t*)(p.gate + (long long)b_first * p.ldg + n);
@@ -261,7 +264,7 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
     for (int j = 0; j < 2; ++j) {
       const int m = mw0 + mi2 * 16 + j * 8 + rl;
       rres[mi2 % RD][j] = (u32x4_t){0u, 0u, 0u, 0u};
-      if (CHECK && (m >= p.M || !col_ok)) continue;
+      if ((CHECK || NIG < 4) && ((CHECK && m >= p.M) || !col_ok)) continue;
       const long long coff = (one_batch ? off0 + (long long)(m - mw0) * p.cm.ld : p.cm.off(m)) + n;
       rres[mi2 % RD][j] = *(const u32x4_t*)(p.resid + coff);
     }
@@ -273,9 +276,9 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      float v[4] = {acc[mi][ni][0] + bias[ni][0], acc[mi][ni][1] + bias[ni][1], acc[mi][ni][2] + bias[ni][2],
-                    acc[mi][ni][3] + bias[ni][3]};
+    for (int ni = 0; ni < NIG; ++ni) {
+      float v[4] = {acc[mi][NI0 + ni][0] + bias[ni][0], acc[mi][NI0 + ni][1] + bias[ni][1], acc[mi][NI0 + ni][2] + bias[ni][2],
+                    acc[mi][NI0 + ni][3] + bias[ni][3]};
       if (actv[ni]) {
         // torch: y = linear(x) is a bf16 tensor before the activation reads it
 #pragma unroll
@@ -294,7 +297,7 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
       const int m = mw0 + mi * 16 + j * 8 + rl;
       u32x4_t y = *(const u32x4_t*)(scr + roff + j * 1024);
       if (j == 1) y = (u32x4_t){y[2], y[3], y[0], y[1]};
-      if (CHECK && (m >= p.M || !col_ok)) continue;
+      if ((CHECK || NIG < 4) && ((CHECK && m >= p.M) || !col_ok)) continue;
       const long long coff = (one_batch ? off0 + (long long)(m - mw0) * p.cm.ld : p.cm.off(m)) + n;
       if (p.resid) {
         const u32x4_t x = rres[mi % RD][j];
@@ -319,11 +322,17 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
   }
 }
 
-template <int MI, int TM, int TN = TM>
-__device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[4],
+template <int MI, int TM, int TN = TM, int NI = 4>
+__device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[NI],
                                                 char* scr) {
-  if (m0 + TM <= p.M && n0 + TN <= p.N) staged_rows<MI, TM, false>(p, m0, mw0, n0, nw0, l, acc, scr);
-  else staged_rows<MI, TM, true>(p, m0, mw0, n0, nw0, l, acc, scr);
+  constexpr int G0 = NI < 4 ? NI : 4;
+  if (m0 + TM <= p.M && n0 + TN <= p.N) {
+    staged_rows<MI, TM, false, NI, 0, G0>(p, m0, mw0, n0, nw0, l, acc, scr);
+    if constexpr (NI > 4) staged_rows<MI, TM, false, NI, 4, NI - 4>(p, m0, mw0, n0, nw0 + 64, l, acc, scr);
+  } else {
+    staged_rows<MI, TM, true, NI, 0, G0>(p, m0, mw0, n0, nw0, l, acc, scr);
+    if constexpr (NI > 4) staged_rows<MI, TM, true, NI, 4, NI - 4>(p, m0, mw0, n0, nw0 + 64, l, acc, scr);
+  }
 }
 
 // tile selection shared by both kernels: XCD-contiguous, grouped along M for L2 reuse of the W panel
@@ -452,27 +461,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
 // Stage = A tile (32*MI rows) then W tile (128 rows), 128 B per row, same XOR swizzle as t128.  Per stage a wave issues
 // MI A chunks... (32*MI / 8 / 4) + 4 W chunks of 8 rows.  The epilogue slabs alias stage memory after the loop's last barrier.
 // --------------------------------------------------------------------------------------------
-template <int MI, int ST>
+// Round 3: the N extent of the tile is a template parameter too (NI column blocks of 16 per wave: 128- or 192-column tiles).
+// A launch of this family is bound by what ONE CU can ingest from L2 (measured ~70 GB/s per CU through LDS-DMA, whatever the
+// ring depth): its time is (K-steps) x (tile rows + tile columns) x 128 B x (tiles on the busiest CU) / that rate.  BASELINE
+// configs[1]'s two heaviest shapes sit badly on 128-column tiles: (1536, 3072, 15360) is 288 128x128 tiles on 256 CUs (32 CUs
+// carry two: 660 TFLOP/s) and (1536, 12288, 3072) is 1152 of them; 96x192 tiles make the first exactly 256 workgroups (one per
+// CU, 44 % fewer bytes on the busiest CU) and 128x192 tiles make the second exactly 3 rounds of 256.  Same MFMA, same k order per
+// output element: the bits cannot tell (test_gemm_kernels_are_bit_identical), so the choice stays a function of the launch shape.
+template <int MI, int ST, int NI = 4>
 __global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
-  constexpr int TBM = 32 * MI;
-  constexpr int A_BYTES = TBM * 128, W_BYTES = 128 * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int TBM = 32 * MI, TBN = 32 * NI;
+  constexpr int A_BYTES = TBM * 128, W_BYTES = TBN * 128, STAGE = A_BYTES + W_BYTES;
   constexpr int CA = TBM / 32;                 // A chunks (8 rows, 1 KiB) per wave per stage
-  constexpr int CH = CA + 4;                   // DMA instructions per wave per stage
-  static_assert(ST >= 2 && ST <= 4 && ST * STAGE >= 4 * 2048, "ring depth");
+  constexpr int CW = TBN / 32;                 // W chunks per wave per stage
+  constexpr int CH = CA + CW;                  // DMA instructions per wave per stage
+  static_assert(ST >= 2 && ST <= 4 && ST * STAGE >= 4 * 2048 && ST * STAGE <= 160 * 1024 && (NI == 4 || NI == 6), "ring depth / tile");
   __shared__ __attribute__((aligned(16))) char smem[ST * STAGE];
   const int w = wave_id();
   const int l = lane_id();
   const int wr = w >> 1, wc = w & 1;
   int tm, tn;
   pick_tile(p, (int)blockIdx.x, tm, tn);
-  const int m0 = tm * TBM, n0 = tn * 128;
+  const int m0 = tm * TBM, n0 = tn * TBN;
 
   const long long a0 = p.am.off(m0);
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a0), 0, 0x7ffffff0u, 0x00020000);
-  const int wrows = min(128, p.N - n0);
+  const int wrows = min(TBN, p.N - n0);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0,
                                                                  (unsigned)((long long)wrows * p.K * 2), 0x00020000);
-  unsigned voffA[4], voffW[4];      // (voffA[CA]: an array of dependent bound captured by the lambda below loses the host stub in hipcc 7.2)
+  unsigned voffA[4], voffW[6];      // (an array of template-dependent bound captured by the lambda below loses the host stub in hipcc 7.2)
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
     const int row = (w * CA + i) * 8 + (l >> 3);
@@ -481,8 +498,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
     voffA[i] = (unsigned)((p.am.off(ra) - a0 + slot * 8) * 2);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (w * 4 + i) * 8 + (l >> 3);
+  for (int i = 0; i < CW; ++i) {
+    const int row = (w * CW + i) * 8 + (l >> 3);
     const int slot = (l & 7) ^ ((row >> 1) & 7);
     const int rw = min(row, wrows - 1);
     voffW[i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
@@ -494,19 +511,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
     for (int i = 0; i < CA; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)(d + (w * CA + i) * 1024), 16, voffA[i], soff, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + A_BYTES + (w * 4 + i) * 1024), 16, voffW[i], soff, 0, 0);
+    for (int i = 0; i < CW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + A_BYTES + (w * CW + i) * 1024), 16, voffW[i], soff, 0, 0);
   };
 
   const int p0 = (l >> 4) ^ ((l & 15) >> 1);
   const int fa = (wr * (TBM / 2) + (l & 15)) * 128;            // + mi*2048
-  const int fb = A_BYTES + (wc * 64 + (l & 15)) * 128;         // + ni*2048
+  const int fb = A_BYTES + (wc * (TBN / 2) + (l & 15)) * 128;  // + ni*2048
 
-  f32x4_t acc[MI][4];
+  f32x4_t acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
 #pragma unroll
@@ -529,15 +546,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int so = ((p0 ^ (ks * 4)) << 4);
-      bf16x8_t xa[MI], wb[4];
+      bf16x8_t xa[MI], wb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) xa[i] = *(const bf16x8_t*)(sb + fa + i * 2048 + so);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wb[i] = *(const bf16x8_t*)(sb + fb + i * 2048 + so);
+      for (int i = 0; i < NI; ++i) wb[i] = *(const bf16x8_t*)(sb + fb + i * 2048 + so);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ni], xa[mi], acc[mi][ni], 0, 0, 0);
     }
     buf = buf + 1 == ST ? 0 : buf + 1;
@@ -546,9 +563,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
   const GemmKArgs pd = dest_of(p, n0);
   if (p.wide) {
     __syncthreads();                              // the slabs alias the ring
-    staged_epilogue<MI, TBM, 128>(pd, m0, m0 + wr * (TBM / 2), n0, n0 + wc * 64, l, acc, smem + w * 2048);
+    staged_epilogue<MI, TBM, TBN, NI>(pd, m0, m0 + wr * (TBM / 2), n0, n0 + wc * (TBN / 2), l, acc, smem + w * 2048);
   } else {
-    wave_epilogue<MI, TBM, 128>(pd, m0, m0 + wr * (TBM / 2) + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
+    wave_epilogue<MI, TBM, TBN, NI>(pd, m0, m0 + wr * (TBM / 2) + (l & 15), n0, n0 + wc * (TBN / 2) + (l >> 4) * 4, acc);
   }
 }
 
@@ -789,18 +806,39 @@ static bool use_t256(long long M, int N, int K) {
   return tiles * 10 >= rounds * 256 * 7;              // last-round efficiency >= 0.7
 }
 
-// which gemm_bf16_deep<MI, ST> (10*MI + ST) a launch the 256x256 kernel does not take should use; 0 = the t128 kernel
+// which gemm_bf16_deep<MI, ST, NI> (100 * (NI == 6) + 10 * MI + ST) a launch the 256x256 kernel does not take should use; 0 = the t128 kernel
 // Measured (scripts/bench_gemm_small_m.py, TFLOP/s, t128 -> pick): (512, 3072, 3072) 267 -> 416, (512, 3072, 12288) 310 -> 504,
 // (1024, 3072, 3072) 525 -> 625, (1024, 3072, 12288) 608 -> 715; with more than 256 128x128 tiles t128's two workgroups per CU win.
 // (8, 18432, 3072) — the AdaLN modulation Linears at batch 8, an HBM stream of the weight — 27 -> 46 (5.7 TB/s), (64, 3072, 3072) 38 -> 68.
+// Round 3, 192-column tiles (gemm_bf16_deep<MI, 3, 6>): such a launch is bound by the L2 -> LDS ingest of its busiest CU, i.e. by
+//   cost = (tile rounds on the busiest CU) x (tile rows + tile columns);
+// a (32 * MI) x 192 tiling replaces the 128-column choice when it is ONE full round (>= 94 % of the CUs, one workgroup each), cuts
+// that cost by >= 10 % and either the K loop is long (K >= 8192: the exposed ring fill + epilogue of a lone workgroup per CU are
+// then < 5 % of it) or the 128-column choice is a one-workgroup-per-CU ring kernel already.  Measured (scripts/bench_gemm_small_m.py,
+// TFLOP/s, isolated): (1536, 3072, 15360) — 288 128x128 tiles, 32 CUs carry two — t128 794 -> 96x192 903; (1024, 3072, 12288)
+// 64x128 703 -> 64x192 757; (1024, 3072, 3072) 622 -> 633.  NOT taken where the model alone would: (1536, 12288, 3072) 3 full rounds
+// of 128x192 847 vs t128 953 and (512, 12288, 3072) one round of 128x192 825 vs t128 879 — at K = 3072 t128's two workgroups per CU
+// overlap each other's fill and epilogue, which one workgroup per CU cannot.
 static int deep_policy(long long M, int N, int K) {
-  (void)K;
   const long long tn = (N + 127) / 128;
-  if (M <= 32 || ((M + 63) / 64) * tn < 64) return 14;     // 32-row tiles: no MFMA work on rows that do not exist, more workgroups
+  int pick;
+  long long cost;                                   // of the 128-column choice, in the units above
   const long long tiles128 = ((M + 127) / 128) * tn;
-  if (tiles128 <= 128) return 24;        // <= 256 workgroups of 64 x 128: one per CU, 4-stage ring (96 KiB)
-  if (tiles128 <= 256) return 23;        // <= 512 workgroups: two per CU, 3-stage ring (72 KiB each)
-  return 0;
+  if (M <= 32 || ((M + 63) / 64) * tn < 64) return 14;     // 32-row tiles: no MFMA work on rows that do not exist, more workgroups
+  if (tiles128 <= 128) { pick = 24; cost = ((((M + 63) / 64) * tn + 255) / 256) * (64 + 128); }        // <= 256 workgroups of 64 x 128: one per CU, 4-stage ring (96 KiB)
+  else if (tiles128 <= 256) { pick = 23; cost = ((((M + 63) / 64) * tn + 255) / 256) * (64 + 128); }   // <= 512 workgroups: two per CU, 3-stage ring (72 KiB each)
+  else { pick = 0; cost = ((tiles128 + 255) / 256) * (128 + 128); }
+  static const bool no192 = env_flag("DRAG_GEMM_NO_192");
+  if (N % 192 == 0 && M >= 256 && !no192) {
+    for (int mi = 4; mi >= 1; --mi) {
+      const long long tiles = ((M + 32 * mi - 1) / (32 * mi)) * (N / 192);
+      if (tiles > 256 || tiles * 100 < 256 * 94) continue;
+      const long long c192 = 32 * mi + 192;
+      if (c192 * 10 <= cost * 9 && (K >= 8192 || pick != 0)) return 100 + 10 * mi + 3;
+      break;
+    }
+  }
+  return pick;
 }
 
 // persistent grid of the 256x256 kernel: one workgroup per CU (128 KiB of LDS each), fewer when there are fewer tiles
@@ -879,19 +917,22 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
     k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
     hipLaunchKernelGGL(gemm_bf16_t256<0>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
   } else if (deep) {
-    const int mi = deep / 10, st = deep % 10;
-    DRAG_CHECK((mi == 1 || mi == 2 || mi == 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2 or 10*{1,2,4} + {2,3,4}");
-    k.tiles_m = (a->M + 32 * mi - 1) / (32 * mi); k.tiles_n = (a->N + 127) / 128;
+    const int ni = deep >= 100 ? 6 : 4, mi = (deep % 100) / 10, st = deep % 10;
+    DRAG_CHECK((mi >= 1 && mi <= 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2, 10*{1,2,4} + {2,3,4} or 100 + 10*{1..4} + 3");
+    k.tiles_m = (a->M + 32 * mi - 1) / (32 * mi); k.tiles_n = (a->N + 32 * ni - 1) / (32 * ni);
     const dim3 g(k.tiles_m * k.tiles_n);
     const hipStream_t st_ = (hipStream_t)stream;
 #define DRAG_DEEP(MI_, ST_) case 10 * MI_ + ST_: hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_>), g, dim3(256), 0, st_, k); break
+#define DRAG_DEEP6(MI_) case 100 + 10 * MI_ + 3: hipLaunchKernelGGL((gemm_bf16_deep<MI_, 3, 6>), g, dim3(256), 0, st_, k); break
     switch (deep) {
       DRAG_DEEP(4, 2); DRAG_DEEP(4, 3);
       DRAG_DEEP(2, 2); DRAG_DEEP(2, 3); DRAG_DEEP(2, 4);
       DRAG_DEEP(1, 3); DRAG_DEEP(1, 4);
-      default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel names a gemm_bf16_deep<MI, ST> that is not built (42 43 22 23 24 13 14)");
+      DRAG_DEEP6(1); DRAG_DEEP6(2); DRAG_DEEP6(3); DRAG_DEEP6(4);
+      default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel names a gemm_bf16_deep<MI, ST, NI> that is not built (42 43 22 23 24 13 14 113 123 133 143)");
     }
 #undef DRAG_DEEP
+#undef DRAG_DEEP6
   } else {
     hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
   }

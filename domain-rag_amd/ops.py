@@ -7,6 +7,7 @@ here, and nothing falls back to torch when the library is missing (``_lib.load()
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -54,9 +55,21 @@ class GemmRecorder:
                 return "gemm_bf16_deep<1, 4>"
             tiles128 = ((M + 127) // 128) * tn
             if tiles128 <= 128:
-                return "gemm_bf16_deep<2, 4>"
-            if tiles128 <= 256:
-                return "gemm_bf16_deep<2, 3>"
+                pick, cost = "gemm_bf16_deep<2, 4>", ((((M + 63) // 64) * tn + 255) // 256) * 192
+            elif tiles128 <= 256:
+                pick, cost = "gemm_bf16_deep<2, 3>", ((((M + 63) // 64) * tn + 255) // 256) * 192
+            else:
+                pick, cost = None, ((tiles128 + 255) // 256) * 256
+            if N % 192 == 0 and M >= 256 and not os.environ.get("DRAG_GEMM_NO_192"):
+                for mi in (4, 3, 2, 1):
+                    tiles = ((M + 32 * mi - 1) // (32 * mi)) * (N // 192)
+                    if tiles > 256 or tiles * 100 < 256 * 94:
+                        continue
+                    if (32 * mi + 192) * 10 <= cost * 9 and (K >= 8192 or pick):
+                        return f"gemm_bf16_deep<{mi}, 3, 6>"
+                    break
+            if pick:
+                return pick
         return "gemm_bf16_t128" + ("<1>" if conv else "<0>")
 
     def by_kernel(self):

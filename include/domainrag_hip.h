@@ -27,8 +27,11 @@ const char* drag_last_error(void);
 /* Measurement switches (A/B of kernel variants inside one process; every setting computes the same function):
  *   "attn_sched" 0 | 1 | 2 (schedule of the attention kernel's KV-tile loop), "attn_w4" 0 | 1 (128-query blocks at any
  *   length), "attn_tune" bit 0: static wave priority, bit 1: 16-byte epilogue stores, "attn_q64" 0 | 1 (the 4-wave x 64-query
- *   experiment kernel for S >= 1024).
- * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64.  Returns 0, or -1 for an unknown name. */
+ *   experiment kernel for S >= 1024), "attn_persist" 0 | 1 | n >= 3 (persistent attention experiment: off, one workgroup per
+ *   CU, n per XCD), "gemm_kernel", "gemm_group_m", "ln_generic", "topk_grid" (workgroups at most of the top-k scan, 0 = 512),
+ *   "topk_depth" 0 | 3 (LDS-DMA ring depth of the scan).
+ * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
+ * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 
 /* activation codes used by epilogues */
@@ -180,16 +183,21 @@ int drag_scale_sum_bf16(const void* x, const float* scales, void* out, int32_t G
 /* ---------------------------------------------------------------------------------------
  * drag_cosine_topk_f32 — exact inner-product top-k (faiss.IndexFlatIP.add/search,
  * retrieval/clip100_resnet_style_all_shots.py:425-434).
- *   corpus f32 [N, d] (d % 16 == 0, d <= 2048), queries f32 [Q, d]; out_d f32 [Q, k] descending,
+ *   corpus f32 [N, d] (d % 64 == 0, d <= 1024), queries f32 [Q, d]; out_d f32 [Q, k] descending,
  *   out_i int64 [Q, k].  Score = fp32 fma chain in the fixed order documented in oracle/topk.c;
- *   ties -> lower index first; k <= min(N, 2048); if k > N the tail is (-inf, -1) like faiss.
- *   workspace: drag_cosine_topk_workspace_bytes(N, Q) bytes of device memory.
+ *   ties -> lower index first; k <= 2048; if k > N the tail is (-FLT_MAX, -1) like faiss.
+ *   Up to 64 queries share ONE pass over the corpus (more: ceil(Q / 64) passes); the call is four launches: a strided
+ *   8192-row sample -> its k-th best per query (a valid lower bound of the answer's k-th best) -> the corpus pass keeping only
+ *   scores above it (per-wave candidate regions, no atomics, no [Q, N] score matrix) -> select + sort + decode on the candidates.
+ *   Deterministic; results do not depend on Q or on how queries are grouped into calls.
+ *   workspace: drag_cosine_topk_workspace_bytes(N, Q) bytes of device memory (candidate regions sized for all N rows per query
+ *   of a pass: about 8 * N * min(Q, 64) bytes + 5 MiB).
  */
 int64_t drag_cosine_topk_workspace_bytes(int64_t N, int32_t Q);
 int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, int32_t d,
                          int32_t Q, int32_t k, float* out_d, int64_t* out_i, void* workspace,
                          void* stream);
-/* Scan pass of the above alone (one pass, Q <= 16): scores f32 [Q, ceil64(N)] = corpus . queries in the same fixed
+/* Scan pass of the above alone (ONE pass over the corpus, Q <= 64): scores f32 [Q, ceil64(N)] = corpus . queries in the same fixed
  * summation order (what faiss computes before its heap; retrieval/clip100_resnet_style_all_shots.py:431).  Entries
  * N..ceil64(N) of a score row are unspecified. */
 int drag_cosine_scores_f32(const float* corpus, const float* queries, int64_t N, int32_t d, int32_t Q,

@@ -1,6 +1,6 @@
 """GEMM kernels at small M (BASELINE configs[1]: 512 text / 1024 image / 1536 joint rows): t128 (double-buffered 128x128), t256
 (persistent 256x256), gemm_bf16_deep<MI, ST> ((32 MI) x 128 tiles, ST-stage ring; option value 10 MI + ST), the policy's pick
-(option 0) and torch.matmul (hipBLASLt) as the yardstick.  Every variant must produce the same bits as t128."""
+(option 0; 1xx = the 192-column tiles of round 3: 100 + 10 MI + ST) and torch.matmul (hipBLASLt) as the yardstick.  Every variant must produce the same bits as t128."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ def bench(fn, iters=20):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-VARIANTS = [("t128", 1), ("t256", 2)] + [(f"d{c}", c) for c in (42, 43, 22, 23, 24, 13, 14)] + [("policy", 0)]
+VARIANTS = [("t128", 1), ("t256", 2)] + [(f"d{c}", c) for c in (42, 43, 22, 23, 24, 13, 14, 113, 123, 133, 143)] + [("policy", 0)]
 SHAPES = [(8, 18432, 3072), (8, 9216, 3072), (8, 3072, 256), (64, 3072, 3072), (729, 4096, 1152), (1458, 4304, 1152), (1458, 1152, 4352),
           (512, 3072, 3072), (512, 9216, 3072), (512, 12288, 3072), (512, 3072, 12288),
           (1024, 3072, 3072), (1024, 9216, 3072), (1024, 12288, 3072), (1024, 3072, 12288),

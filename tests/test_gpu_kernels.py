@@ -530,7 +530,7 @@ def test_gemm_staged_epilogue_equals_fragment_epilogue(gpu):
 
 @pytest.mark.parametrize("M,N,K", [(512, 3072, 1024), (1000, 1536, 512), (8, 4608, 256), (77, 136, 192), (1536, 768, 2048), (130, 128, 64)])
 def test_gemm_kernels_are_bit_identical(gpu, M, N, K):
-    """every GEMM kernel (t128, t256, gemm_bf16_deep<MI, ST>) runs the same MFMA in the same k order per output element, so
+    """every GEMM kernel (t128, t256, gemm_bf16_deep<MI, ST, NI>: 128- and 192-column tiles) runs the same MFMA in the same k order per output element, so
     the tile policy may depend on the launch's shape without changing a bit: plain, activation, gate + residual in batched
     rows, f32 output and the narrow (fragment) epilogue"""
     from domain_rag_amd import ops
@@ -550,7 +550,7 @@ def test_gemm_kernels_are_bit_identical(gpu, M, N, K):
         outs.append(y)
         return [o.cpu() for o in outs]
 
-    codes = [1, 42, 43, 22, 23, 24, 13, 14, 0] + ([2] if N >= 256 and K >= 256 else [])
+    codes = [1, 42, 43, 22, 23, 24, 13, 14, 113, 123, 133, 143, 0] + ([2] if N >= 256 and K >= 256 else [])      # 1xx: 192-column tiles
     try:
         res = {}
         for code in codes:
