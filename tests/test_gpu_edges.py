@@ -74,7 +74,8 @@ def test_attention_huge_logits_stay_finite(gpu):
     assert _rel(out, ops_ref.attention_ref_f64(q, k, v, 1 / math.sqrt(128))) < 2e-2
 
 
-@pytest.mark.parametrize("N,d,Q,k", [(1, 64, 1, 1), (5, 1024, 2, 5), (4096, 64, 1, 2048), (4097, 128, 3, 1), (100000, 64, 17, 10)])
+@pytest.mark.parametrize("N,d,Q,k", [(1, 64, 1, 1), (5, 1024, 2, 5), (4096, 64, 1, 2048), (4097, 128, 3, 1), (100000, 64, 17, 10),
+                                     (20000, 1024, 40, 50), (9000, 256, 64, 128), (8208, 192, 65, 3)])
 def test_topk_extremes(gpu, N, d, Q, k):
     from domain_rag_amd import ops
     from oracle import retrieval as oret
