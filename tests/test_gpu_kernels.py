@@ -414,6 +414,29 @@ def test_topk_q64_is_one_call_and_equals_q16_calls(gpu):
         assert torch.equal(sc[a:a + 5, :23457], ops.cosine_scores(corpus, q[a:a + 5].contiguous())[:, :23457])
 
 
+def test_topk_threshold_and_selection_variants_give_the_same_answer(gpu):
+    """the threshold may come from the sampled groups' maxima (k <= 128) or from every sampled row, the selection may run with 256 or
+    1024 threads, the scan with more workgroups or a deeper ring: speed only — (D, I) are the same arrays"""
+    from domain_rag_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(9)
+    corpus = torch.randn(50021, 512, generator=g, device=gpu)
+    q = torch.randn(21, 512, generator=g, device=gpu)
+    try:
+        ref = {k: ops.cosine_topk(corpus, q, k) for k in (1, 100, 128, 129)}
+        for opts in ({"topk_dense_sample": 1}, {"topk_select": 256}, {"topk_select": 1024}, {"topk_grid": 1024, "topk_depth": 3},
+                     {"topk_dense_sample": 1, "topk_select": 1024, "topk_grid": 2048}):
+            for name, v in opts.items():
+                ops.set_option(name, v)
+            for k, (D0, I0) in ref.items():
+                D, I = ops.cosine_topk(corpus, q, k)
+                assert torch.equal(D, D0) and torch.equal(I, I0), (opts, k)
+            for name in opts:
+                ops.set_option(name, 0)
+    finally:
+        for name in ("topk_dense_sample", "topk_select", "topk_grid", "topk_depth"):
+            ops.set_option(name, 0)
+
+
 def test_l2_normalize(gpu):
     from domain_rag_amd import ops
     x = torch.randn(33, 512)
