@@ -401,7 +401,7 @@ def run_generate(args, d: Dist):
         torch.cuda.empty_cache()
         out["side_configs"] = {"configs1": side_config1(d.dev)}
         torch.cuda.empty_cache()
-        out["side_configs"]["retrieval"] = side_retrieval(d.dev, cpu_budget_s=0.0 if args.no_cpu_baseline else 20.0)
+        out["side_configs"]["retrieval"] = side_retrieval(d.dev, cpu_budget_s=0.0 if args.no_cpu_baseline else 10.0)
     if not args.no_cpu_baseline and d.world == 1:
         out["cpu_baseline"] = cpu_baseline_generate(args.res, args.denoise_steps)
     return out
@@ -438,11 +438,11 @@ def side_config1(dev) -> dict:
             "mfma_frac": flops / dt / (MFMA_BF16_PEAK_TF * 1e12)}
 
 
-def side_retrieval(dev, k: int = 100, cpu_budget_s: float = 20.0) -> dict:
+def side_retrieval(dev, k: int = 100, cpu_budget_s: float = 10.0) -> dict:
     """the retrieval side of the path as a side field of the DEFAULT line (N = 1 only, about 15 s; SURVEY 8(d)'s retrieval rows):
     the HBM-bound scan and the whole exact top-k call at N = 118 287 (BASELINE configs[4]'s corpus: 242 MB, Infinity-Cache
     resident across repeats) AND at N = 1 000 000 (2.05 GB: HBM, not cache), Q = 1 / 16 / 64 queries per call; the float32 CLIP
-    tower on 4096 resident crops; BASELINE configs[0] on the host cores.  `--workload retrieval` is the full second line."""
+    tower on 4096 resident crops; BASELINE configs[0] on the host cores (a 10 s sample of it).  `--workload retrieval` is the full second line."""
     from domain_rag_amd import ops
     from domain_rag_amd.retrieval import embed_images, load_clip
     ev = lambda: torch.cuda.Event(enable_timing=True)            # noqa: E731
