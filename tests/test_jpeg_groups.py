@@ -58,3 +58,28 @@ def test_no_rejection_keeps_one_group_per_size():
     b = _batch(sizes, [])
     _check(b, sizes, [])
     assert len(list(b.groups())) == 2
+
+
+def test_budget_bounds_cut_a_chunk_by_pixels():
+    """consecutive ranges whose pixel sums stay within the budget; a file above the budget gets a range of its own; undecodable
+    files (0 pixels) ride along; every index is covered exactly once, in order"""
+    px = np.array([5, 5, 5, 20, 1, 1, 0, 0, 9], dtype=np.int64)
+    assert jpeg.budget_bounds(px, 10) == [(0, 2), (2, 3), (3, 4), (4, 8), (8, 9)]
+    assert jpeg.budget_bounds(px, 1000) == [(0, 9)]
+    assert jpeg.budget_bounds(np.zeros(4, dtype=np.int64), 1) == [(0, 4)]
+    assert jpeg.budget_bounds(np.array([], dtype=np.int64), 1) == []
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        p = rng.integers(0, 50, int(rng.integers(1, 40)))
+        b = jpeg.budget_bounds(p, 60)
+        assert b[0][0] == 0 and b[-1][1] == len(p) and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert all(p[a:e].sum() <= 60 or e - a == 1 for a, e in b)
+
+
+def test_staged_files_slice_is_a_batch_of_its_own():
+    buf = torch.arange(100, dtype=torch.uint8)
+    st = jpeg.StagedFiles(buf, np.array([0, 10, 10, 35, 60], dtype=np.int64), {1: OSError("unreadable")})
+    sub = st.slice(1, 3)
+    assert len(sub) == 2 and sub.offsets.tolist() == [0, 0, 25] and list(sub.errors) == [0]
+    assert sub.file_bytes(1) == bytes(range(10, 35))
+    assert st.slice(3, 4).file_bytes(0) == bytes(range(35, 60)) and st.slice(3, 4).errors == {}
