@@ -516,12 +516,18 @@ int launch_scan(ScanArgs& sa, hipStream_t st) {
 inline long long ceil16(long long n) { return (n + 15) / 16 * 16; }
 constexpr long long MAXREG = 8192;
 inline long long cand_stride(long long N) { return ceil16(N) + 16 * MAXREG; }
+// queries per corpus pass: 64, fewer when their candidate regions (room for ALL rows, 8 bytes each) would pass 1 GiB
+inline int pass_queries(long long N) {
+  int qp = 64;
+  while (qp > 16 && (long long)qp * cand_stride(N) * 8 > (1ll << 30)) qp >>= 1;
+  return qp;
+}
 
 }  // namespace
 
 extern "C" int64_t drag_cosine_topk_workspace_bytes(int64_t N, int32_t Q) {
   if (N <= 0 || Q <= 0) return 0;
-  const long long qp = Q < 64 ? Q : 64;
+  const long long qp = Q < pass_queries(N) ? Q : pass_queries(N);
   return 64 * 8 + 64 * MAXREG * 4 + 64ll * SAMPLE_GROUPS * 16 * 8 + qp * cand_stride(N) * 8 + 256;
 }
 
@@ -558,8 +564,9 @@ extern "C" int drag_cosine_topk_f32(const float* corpus, const float* queries, i
   int kpad = 1;
   while (kpad < k) kpad <<= 1;
 
-  for (int q0 = 0; q0 < Q; q0 += 64) {
-    const int qn = min(64, Q - q0);
+  const int qpass = pass_queries(N);
+  for (int q0 = 0; q0 < Q; q0 += qpass) {
+    const int qn = min(qpass, Q - q0);
     ScanArgs sa{};
     sa.corpus = corpus; sa.queries = queries + (long long)q0 * d; sa.N = N; sa.d = d; sa.Q = qn; sa.ntile = (qn + 15) / 16;
     SelArgs se{};

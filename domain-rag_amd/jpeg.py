@@ -85,6 +85,12 @@ class StagedFiles:
 
     def __init__(self, buf: torch.Tensor, offsets: np.ndarray, errors: dict):
         self.buf, self.offsets, self.errors = buf, offsets, errors
+        self._dev = None                    # the uploaded blob (made once: the header parse and the decode share it)
+
+    def device_blob(self, device) -> torch.Tensor:
+        if self._dev is None or self._dev.device != torch.device(device):
+            self._dev = self.buf[: int(self.offsets[-1]) + PAD].to(device, non_blocking=True)
+        return self._dev
 
     def __len__(self) -> int:
         return len(self.offsets) - 1
@@ -95,7 +101,10 @@ class StagedFiles:
     def slice(self, a: int, b: int) -> "StagedFiles":
         """files [a, b) as a batch of their own (a view of the same pinned buffer; the PAD bytes behind it are the next file's)"""
         o = int(self.offsets[a])
-        return StagedFiles(self.buf[o:], self.offsets[a: b + 1] - o, {k - a: v for k, v in self.errors.items() if a <= k < b})
+        sub = StagedFiles(self.buf[o:], self.offsets[a: b + 1] - o, {k - a: v for k, v in self.errors.items() if a <= k < b})
+        if self._dev is not None:           # already uploaded: the piece is a view of the parent's device blob
+            sub._dev = self._dev[o: int(self.offsets[b]) + PAD]
+        return sub
 
 
 def parse_pixels(staged: "StagedFiles", device="cuda") -> np.ndarray:
@@ -104,7 +113,7 @@ def parse_pixels(staged: "StagedFiles", device="cuda") -> np.ndarray:
     lib = _lib.load()
     n = len(staged)
     device = torch.device(device)
-    data = staged.buf[: int(staged.offsets[-1]) + PAD].to(device, non_blocking=True)
+    data = staged.device_blob(device)
     d_off = torch.from_numpy(np.ascontiguousarray(staged.offsets)).to(device)
     d_info = torch.empty((n, INFO_WORDS), dtype=torch.int32, device=device)
     check(lib.drag_jpeg_parse(_p(data), _p(d_off), n, _p(d_info), _stream()), "drag_jpeg_parse")
@@ -182,7 +191,7 @@ def decode_files(blobs, device="cuda", check_scan: bool = True) -> DecodedBatch:
         raise RuntimeError("decode_files: the JPEG decoder is a GPU path (domain-rag_amd has no CPU fallback)")
     if isinstance(blobs, StagedFiles):
         offsets = blobs.offsets
-        data = blobs.buf[: int(offsets[-1]) + PAD].to(device, non_blocking=True)
+        data = blobs.device_blob(device)
     else:
         data, offsets = _upload(blobs, device)
     d_off = torch.from_numpy(np.ascontiguousarray(offsets)).to(device)

@@ -186,12 +186,13 @@ int drag_scale_sum_bf16(const void* x, const float* scales, void* out, int32_t G
  *   corpus f32 [N, d] (d % 64 == 0, d <= 1024), queries f32 [Q, d]; out_d f32 [Q, k] descending,
  *   out_i int64 [Q, k].  Score = fp32 fma chain in the fixed order documented in oracle/topk.c;
  *   ties -> lower index first; k <= 2048; if k > N the tail is (-FLT_MAX, -1) like faiss.
- *   Up to 64 queries share ONE pass over the corpus (more: ceil(Q / 64) passes); the call is four launches: a strided
+ *   Up to 64 queries share ONE pass over the corpus (more: ceil(Q / 64) passes; 32 or 16 per pass when N is so large that 64
+ *   candidate regions would pass 1 GiB); the call is four launches: a strided
  *   8192-row sample -> its k-th best per query (a valid lower bound of the answer's k-th best) -> the corpus pass keeping only
  *   scores above it (per-wave candidate regions, no atomics, no [Q, N] score matrix) -> select + sort + decode on the candidates.
  *   Deterministic; results do not depend on Q or on how queries are grouped into calls.
  *   workspace: drag_cosine_topk_workspace_bytes(N, Q) bytes of device memory (candidate regions sized for all N rows per query
- *   of a pass: about 8 * N * min(Q, 64) bytes + 5 MiB).
+ *   of a pass: about 8 * N * min(Q, 64) bytes + 5 MiB, at most ~1 GiB + 128 * N).
  */
 int64_t drag_cosine_topk_workspace_bytes(int64_t N, int32_t Q);
 int drag_cosine_topk_f32(const float* corpus, const float* queries, int64_t N, int32_t d,

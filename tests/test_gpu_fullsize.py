@@ -98,3 +98,20 @@ def test_corpus_scale_topk_properties(gpu):
     assert np.array_equal(Ic[:2], Ir) and np.array_equal(Dc[:2], Dr)
     D2, I2 = ops.cosine_topk(corpus, q, 100)                     # idempotent / deterministic
     assert torch.equal(I2, I) and torch.equal(D2, D)
+
+
+def test_topk_past_the_candidate_workspace_bound(gpu):
+    """N = 2.1 M rows (4.3 GB): 64 candidate regions with room for every row would pass 1 GiB, so a pass carries 32 queries and
+    Q = 40 takes two passes; results equal one-query calls (which take the plain path) and, on two queries, the oracle"""
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    N, Q = 2_100_000, 40
+    g = torch.Generator(device=gpu).manual_seed(5)
+    corpus = torch.randn(N, 512, generator=g, device=gpu)
+    q = torch.randn(Q, 512, generator=g, device=gpu)
+    D, I = ops.cosine_topk(corpus, q, 100)
+    for j in (0, 31, 32, 39):
+        d1, i1 = ops.cosine_topk(corpus, q[j:j + 1].contiguous(), 100)
+        assert torch.equal(D[j:j + 1], d1) and torch.equal(I[j:j + 1], i1), j
+    Dr, Ir = oret.cosine_topk(corpus.cpu().numpy(), q[[3, 37]].cpu().numpy(), 100)
+    assert np.array_equal(I[[3, 37]].cpu().numpy(), Ir) and np.array_equal(D[[3, 37]].cpu().numpy(), Dr)
