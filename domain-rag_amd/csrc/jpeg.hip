@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
   if (i >= a.n) return;
   const JpegInfo& o = a.info[i];
   if (o.status != 0) { a.scan_status[i] = 0; return; }
+  if (o.progressive) return;                         // jpeg_progressive_kernel's file
   const uint8_t* d = a.data + a.off[i];
   const int64_t len = a.off[i + 1] - a.off[i];
   DRAG_LDS uint16_t* const L = (DRAG_LDS uint16_t*)lds + lane;
@@ -162,6 +163,51 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegArgs a) {
   // that lost sync on damaged data) is reported: libjpeg / PIL decide what such a file means (warning, OSError), not this kernel.
   jpeg_bits_fill(&b);
   a.scan_status[i] = (b.marker == 0xD9 && b.pos + 2 <= len) ? 0 : 1;
+}
+
+// SOF2 files (round 3): one file per lane like the sequential kernel, same LDS table geometry; the scans are walked by
+// jpeg_decode_progressive (jpeg_core.h), which rebuilds the lane's tables whenever a scan needs them.  Launched over the whole
+// batch: lanes whose file is not progressive leave at once (a batch without progressive files pays one empty launch).
+struct LaneTables {
+  DRAG_LDS uint16_t* L;
+  DRAG_LDS uint32_t* K;
+  DRAG_LDS uint8_t* V;
+  __device__ __forceinline__ DcTable dc(int id) const { return DcTable{L + id * (64 * 64), K + id * (17 * 64), V + id * (16 * 64)}; }
+  __device__ __forceinline__ AcTable ac(int id) const { return AcTable{L + (128 + id * 64) * 64, K + (34 + id * 17) * 64, V + (32 + id * 256) * 64}; }
+};
+
+__global__ __launch_bounds__(64) void jpeg_progressive_kernel(JpegArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * 64 + lane;
+  const LdsNat nat{(DRAG_LDS uint8_t*)lds + JPEG_LUT_BYTES + JPEG_LIMK_BYTES + JPEG_VAL_BYTES};
+  for (int k = lane; k < 80; k += 64) nat[k] = (uint8_t)jpeg_natural_order(k);
+  __syncthreads();
+  if (i >= a.n) return;
+  const JpegInfo& o = a.info[i];
+  if (o.status != 0 || !o.progressive) return;
+  const uint8_t* d = a.data + a.off[i];
+  const int64_t len = a.off[i + 1] - a.off[i];
+  const LaneTables tab{(DRAG_LDS uint16_t*)lds + lane, (DRAG_LDS uint32_t*)(lds + JPEG_LUT_BYTES) + lane,
+                       (DRAG_LDS uint8_t*)(lds + JPEG_LUT_BYTES + JPEG_LIMK_BYTES) + lane};
+  int16_t* cbase[3];
+  {
+    long long p = a.plan[(long long)i * 3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const bool on = c < o.ncomp;
+      cbase[c] = a.coef + p;
+      if (on) {
+        p += (long long)(o.mcus_x * o.hs[c]) * (o.mcus_y * o.vs[c]) * 64;
+        const uint8_t* qt = d + o.dqt_off[o.tq[c]];
+        const bool q16 = o.dqt_16[o.tq[c]] != 0;
+        uint16_t* q = a.qtab + ((long long)i * 3 + c) * 64;
+        for (int k = 0; k < 64; ++k) q[nat[k]] = q16 ? (uint16_t)jpeg_u16(qt + 2 * k) : (uint16_t)qt[k];
+      }
+    }
+  }
+  const int rc = jpeg_decode_progressive(d, len, &o, tab, nat, cbase[0], cbase[1], cbase[2]);
+  a.scan_status[i] = rc;                              // 0 clean; 1 not followed / damaged; 2 scans stop early (libjpeg would smooth)
 }
 
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegArgs a) {
@@ -241,6 +287,14 @@ extern "C" int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, co
     lds_ok = true;
   }
   hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((n + 63) / 64), dim3(64), lds, st, a);
+  DRAG_LAUNCH_CHECK();
+  static bool lds_ok2 = false;
+  if (!lds_ok2) {
+    e = hipFuncSetAttribute((const void*)jpeg_progressive_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DRAG_CHECK(e == hipSuccess, "drag_jpeg_decode_rgb: cannot raise the dynamic LDS limit (progressive kernel)");
+    lds_ok2 = true;
+  }
+  hipLaunchKernelGGL(jpeg_progressive_kernel, dim3((n + 63) / 64), dim3(64), lds, st, a);     // SOF2 files; other lanes leave at once
   DRAG_LAUNCH_CHECK();
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 255) / 256), n), dim3(256), 0, st, a);
   DRAG_LAUNCH_CHECK();

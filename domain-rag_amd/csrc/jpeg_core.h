@@ -9,10 +9,13 @@
 // very same functions with g++ so that the arithmetic is checked against PIL on the build host, where there is no GPU.
 // Nothing on the product path uses the host build.
 //
-// Supported: SOF0 / SOF1 (sequential Huffman, 8-bit), one interleaved scan, 1 component (-> grey replicated to RGB) or 3
-// components YCbCr with the luma at full resolution and the chroma at 1x1, 2x1 or 2x2 subsampling, restart intervals.
-// Everything else (progressive, arithmetic, 12-bit, CMYK / RGB-coded, multi-scan, other sampling ratios) is reported in
-// JpegInfo::status and left to the caller.
+// Supported: SOF0 / SOF1 (sequential Huffman, 8-bit), one interleaved scan, and (round 3) SOF2 PROGRESSIVE Huffman files (any
+// number of scans: DC / AC, first / refinement, interleaved DC scans, table redefinitions between scans; jdphuff.c restated in
+// jpeg_decode_progressive below); 1 component (-> grey replicated to RGB) or 3 components YCbCr with the luma at full
+// resolution and the chroma at 1x1, 2x1 or 2x2 subsampling, restart intervals.
+// Everything else (arithmetic, lossless, 12-bit, CMYK / RGB-coded, multi-scan sequential, other sampling ratios) is reported in
+// JpegInfo::status and left to the caller; a progressive file whose scans stop before coefficients 0-9 of every component are
+// fully refined is reported after decoding (libjpeg would run its inter-block smoothing on such a file).
 #pragma once
 #include <stdint.h>
 
@@ -26,7 +29,7 @@ enum {
   JPEG_OK = 0,
   JPEG_ERR_NOT_JPEG = 1,
   JPEG_ERR_TRUNCATED = 2,
-  JPEG_ERR_PROGRESSIVE = 3,      // SOF2 and the other non-sequential / arithmetic / lossless frame types
+  JPEG_ERR_PROGRESSIVE = 3,      // the non-Huffman / lossless / hierarchical frame types (SOF3, SOF5-7, SOF9-15); SOF2 itself is decoded
   JPEG_ERR_PRECISION = 4,        // not 8 bits per sample
   JPEG_ERR_COMPONENTS = 5,       // not 1 or 3 components, or a colour space other than grey / YCbCr
   JPEG_ERR_SAMPLING = 6,         // not 4:4:4 / 4:2:2 / 4:2:0 (full-resolution luma, chroma 1x1 / 2x1 / 2x2 subsampled)
@@ -48,7 +51,9 @@ struct JpegInfo {               // == drag_jpeg_info (include/domainrag_hip.h): 
   int32_t dqt_off[4];           // offset of a table's first element (zigzag order), -1 = absent
   int32_t dqt_16[4];            // 1 = 16-bit elements
   int32_t dht_off[8];           // [class * 4 + id]: offset of the 16 code-length counts, -1 = absent
-  int32_t reserved[7];
+  int32_t progressive;          // 1 = SOF2: scan_off is the offset of the first SOS MARKER (its 0xFF), td / ta are per scan
+  int32_t cid[3];               // component identifiers (scan headers name their components by these)
+  int32_t reserved[3];
 };
 
 JHD int jpeg_natural_order(int k) {   // zigzag position -> natural (row-major) position; positions past 63 alias 63 like libjpeg
@@ -112,22 +117,24 @@ JHD void jpeg_parse(const uint8_t* d, int64_t len, JpegInfo* o) {
       }
     } else if (m == 0xDD) {
       if (n >= 2) o->restart_interval = jpeg_u16(s);
-    } else if (m == 0xC0 || m == 0xC1) {
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      o->progressive = m == 0xC2 ? 1 : 0;
       if (n < 6) { o->status = JPEG_ERR_TRUNCATED; return; }
       if (s[0] != 8) { o->status = JPEG_ERR_PRECISION; return; }
       o->height = jpeg_u16(s + 1); o->width = jpeg_u16(s + 3); o->ncomp = s[5];
       if (o->ncomp != 1 && o->ncomp != 3) { o->status = JPEG_ERR_COMPONENTS; return; }
       if (n < 6 + 3 * o->ncomp || o->width <= 0 || o->height <= 0) { o->status = JPEG_ERR_TRUNCATED; return; }
       for (int c = 0; c < o->ncomp; ++c) {
-        cid[c] = s[6 + 3 * c];
+        cid[c] = s[6 + 3 * c]; o->cid[c] = cid[c];
         o->hs[c] = s[7 + 3 * c] >> 4; o->vs[c] = s[7 + 3 * c] & 15; o->tq[c] = s[8 + 3 * c];
         if (o->tq[c] > 3) { o->status = JPEG_ERR_TABLES; return; }
       }
       have_sof = true;
-    } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+    } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       o->status = JPEG_ERR_PROGRESSIVE; return;
     } else if (m == 0xDA) {
       if (!have_sof) { o->status = JPEG_ERR_NOT_JPEG; return; }
+      if (o->progressive) { o->scan_off = (int32_t)(p - 2); break; }     // the scans are walked by jpeg_decode_progressive
       if (n < 1 || s[0] != o->ncomp || n < 1 + 2 * o->ncomp + 3) { o->status = JPEG_ERR_MULTISCAN; return; }
       for (int c = 0; c < o->ncomp; ++c) {
         if (s[1 + 2 * c] != cid[c]) { o->status = JPEG_ERR_MULTISCAN; return; }
@@ -165,7 +172,8 @@ JHD void jpeg_parse(const uint8_t* d, int64_t len, JpegInfo* o) {
   o->mcus_x = (o->width + 8 * o->hmax - 1) / (8 * o->hmax);
   o->mcus_y = (o->height + 8 * o->vmax - 1) / (8 * o->vmax);
   for (int c = 0; c < o->ncomp; ++c) {
-    if (o->dqt_off[o->tq[c]] < 0 || o->dht_off[o->td[c]] < 0 || o->dht_off[4 + o->ta[c]] < 0) { o->status = JPEG_ERR_TABLES; return; }
+    if (o->dqt_off[o->tq[c]] < 0) { o->status = JPEG_ERR_TABLES; return; }
+    if (!o->progressive && (o->dht_off[o->td[c]] < 0 || o->dht_off[4 + o->ta[c]] < 0)) { o->status = JPEG_ERR_TABLES; return; }
   }
   // jdsample.c picks the triangle filters only when downsampled_width > 2 (box replication otherwise): images under 5 pixels wide
   if (o->ncomp == 3 && o->hmax == 2 && (o->width + 1) / 2 <= 2) { o->status = JPEG_ERR_TOO_SMALL; return; }
@@ -391,6 +399,243 @@ JHD void jpeg_decode_block(JpegBits* b, TDC dc, TAC ac, NAT nat, int* dc_pred, i
       k += 15;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------- progressive (jdphuff.c)
+#ifndef JPEG_PROG_FAIL
+#define JPEG_PROG_FAIL(code) return (code)       // (the host debug build redefines this to say where a file was given up)
+#endif
+// One bit / n bits of the entropy-coded segment.
+JHD int jpeg_get_bits(JpegBits* b, int n) {            // n in 1..16
+  jpeg_bits_fill(b);
+  const int r = jpeg_bits_peek(b, n);
+  jpeg_bits_skip(b, n);
+  return r;
+}
+JHD int16_t jpeg_shl(int v, int al) { return (int16_t)(int32_t)((uint32_t)v << al); }
+
+// refinement correction of an already-nonzero coefficient (decode_mcu_AC_refine): one bit; if set and the bit position is
+// still clear, move the magnitude away from zero by 1 << Al
+JHD void jpeg_refine_nonzero(JpegBits* b, int16_t* c, int p1, int m1) {
+  if (jpeg_get_bits(b, 1)) {
+    const int v = *c;
+    if ((v & p1) == 0) *c = (int16_t)(v >= 0 ? v + p1 : v + m1);
+  }
+}
+
+// Walks the marker segments from the first SOS on and decodes every scan into the (zeroed) coefficient planes c0 / c1 / c2
+// (natural order, row stride = mcus_x * hs[c] blocks, like the sequential decoder's).  `tab.dc(id)` / `tab.ac(id)`, id 0 | 1, are
+// the table views (rebuilt per scan from the latest DHT definitions: progressive files redefine tables between scans).
+// Returns 0 when the file ended at EOI with coefficients 0-9 of every component fully refined; 1 for anything this decoder
+// does not follow (table ids > 1, tables missing, quantisation tables redefined between scans, malformed scan headers, data
+// that does not end at a marker); 2 when the scans stop early (libjpeg smooths such files: the caller lets it).
+template <typename TAB, typename NAT>
+JHD int jpeg_decode_progressive(const uint8_t* d, int64_t len, const JpegInfo* o, TAB tab, NAT nat, int16_t* c0, int16_t* c1,
+                                int16_t* c2) {
+  int64_t p = o->scan_off;
+  int rst = o->restart_interval;
+  int32_t dh_dc0 = o->dht_off[0], dh_dc1 = o->dht_off[1], dh_ac0 = o->dht_off[4], dh_ac1 = o->dht_off[5];
+  uint64_t done0 = 0, done1 = 0, done2 = 0;            // bit k: coefficient k (zigzag) of the component has reached Al = 0
+  const int ncomp = o->ncomp, W = o->width, H = o->height, hmax = o->hmax, vmax = o->vmax, mcus_x = o->mcus_x, mcus_y = o->mcus_y;
+  for (int guard = 0; guard < 4096; ++guard) {
+    if (p + 2 > len || d[p] != 0xFF) JPEG_PROG_FAIL(1);
+    while (p < len && d[p] == 0xFF) ++p;
+    if (p >= len) JPEG_PROG_FAIL(1);
+    const int m = d[p++];
+    if (m == 0xD9) {                                    // EOI
+      const uint64_t need = 0x3FFull;
+      if ((done0 & need) != need) JPEG_PROG_FAIL(2);
+      if (ncomp == 3 && ((done1 & need) != need || (done2 & need) != need)) JPEG_PROG_FAIL(2);
+      return 0;
+    }
+    if ((m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+    if (p + 2 > len) JPEG_PROG_FAIL(1);
+    const int L = jpeg_u16(d + p);
+    if (L < 2 || p + L > len) JPEG_PROG_FAIL(1);
+    const uint8_t* s = d + p + 2;
+    const int n = L - 2;
+    if (m == 0xC4) {
+      int q = 0;
+      while (q < n) {
+        if (q + 17 > n) JPEG_PROG_FAIL(1);
+        const int tc = s[q] >> 4, id = s[q] & 15;
+        int cnt = 0;
+        for (int i = 0; i < 16; ++i) cnt += s[q + 1 + i];
+        if (tc > 1 || id > 1 || cnt > 256 || (tc == 0 && cnt > 16) || q + 17 + cnt > n) JPEG_PROG_FAIL(1);
+        const int32_t off = (int32_t)(p + 2 + q + 1);
+        if (tc == 0) { if (id == 0) dh_dc0 = off; else dh_dc1 = off; }
+        else { if (id == 0) dh_ac0 = off; else dh_ac1 = off; }
+        q += 17 + cnt;
+      }
+    } else if (m == 0xDD) {
+      if (n >= 2) rst = jpeg_u16(s);
+    } else if (m == 0xDB || (m >= 0xC0 && m <= 0xCF && m != 0xC4)) {
+      JPEG_PROG_FAIL(1);                                // new quantisation tables / a second frame header between scans
+    } else if (m == 0xDA) {
+      const int ns = n >= 1 ? s[0] : 0;
+      if (ns < 1 || ns > ncomp || n < 1 + 2 * ns + 3) JPEG_PROG_FAIL(1);
+      // scan components as indices into the frame's component list (in frame order, as the standard requires)
+      int sc0 = -1, sc1 = -1, sc2 = -1, td0 = 0, td1 = 0, td2 = 0, ta0 = 0;
+      for (int j = 0; j < ns; ++j) {
+        const int id = s[1 + 2 * j], tt = s[2 + 2 * j];
+        int ci = -1;
+        if (id == o->cid[0]) ci = 0; else if (ncomp == 3 && id == o->cid[1]) ci = 1; else if (ncomp == 3 && id == o->cid[2]) ci = 2;
+        if (ci < 0 || (tt >> 4) > 1 || (tt & 15) > 1) JPEG_PROG_FAIL(1);
+        if (j == 0) { sc0 = ci; td0 = tt >> 4; ta0 = tt & 15; }
+        else if (j == 1) { if (ci <= sc0) JPEG_PROG_FAIL(1); sc1 = ci; td1 = tt >> 4; }
+        else { if (ci <= sc1) JPEG_PROG_FAIL(1); sc2 = ci; td2 = tt >> 4; }
+      }
+      const uint8_t* t = s + 1 + 2 * ns;
+      const int Ss = t[0], Se = t[1], Ah = t[2] >> 4, Al = t[2] & 15;
+      if (Ss > Se || Se > 63 || Al > 13 || Ah > 13 || (Ss == 0 && Se != 0) || (Ss != 0 && ns != 1)) JPEG_PROG_FAIL(1);
+      // tables this scan decodes with
+      if (Ss == 0) {
+        if (Ah == 0) {
+          const bool use0 = td0 == 0 || (ns > 1 && td1 == 0) || (ns > 2 && td2 == 0);
+          const bool use1 = td0 == 1 || (ns > 1 && td1 == 1) || (ns > 2 && td2 == 1);
+          if ((use0 && dh_dc0 < 0) || (use1 && dh_dc1 < 0)) JPEG_PROG_FAIL(1);
+          if (use0) jpeg_build_huff(d + dh_dc0, tab.dc(0));
+          if (use1) jpeg_build_huff(d + dh_dc1, tab.dc(1));
+        }
+      } else {
+        const int32_t off = ta0 == 0 ? dh_ac0 : dh_ac1;
+        if (off < 0) JPEG_PROG_FAIL(1);
+        jpeg_build_huff(d + off, tab.ac(ta0));
+      }
+      // refinement bookkeeping: which coefficients are now final
+      {
+        const uint64_t band = (Se == 63 ? ~0ull : ((1ull << (Se + 1)) - 1ull)) & ~((1ull << Ss) - 1ull);
+        for (int j = 0; j < ns; ++j) {
+          const int ci = j == 0 ? sc0 : (j == 1 ? sc1 : sc2);
+          uint64_t& dn = ci == 0 ? done0 : (ci == 1 ? done1 : done2);
+          dn = Al == 0 ? (dn | band) : (dn & ~band);
+        }
+      }
+      JpegBits b;
+      jpeg_bits_init(&b, d, p + L, len);
+      int pred0 = 0, pred1 = 0, pred2 = 0, togo = rst;
+      unsigned eobrun = 0;
+      const int p1 = 1 << Al, m1 = -(1 << Al);
+      if (ns > 1) {
+        // ---- interleaved scan (DC only): whole MCUs, dummy blocks included
+        for (int my = 0; my < mcus_y; ++my)
+          for (int mx = 0; mx < mcus_x; ++mx) {
+            if (rst && togo == 0) { jpeg_bits_restart(&b); pred0 = pred1 = pred2 = 0; togo = rst; }
+            for (int j = 0; j < ns; ++j) {
+              const int ci = j == 0 ? sc0 : (j == 1 ? sc1 : sc2);
+              const int tdj = j == 0 ? td0 : (j == 1 ? td1 : td2);
+              const int hsj = ci == 0 ? o->hs[0] : (ci == 1 ? o->hs[1] : o->hs[2]);
+              const int vsj = ci == 0 ? o->vs[0] : (ci == 1 ? o->vs[1] : o->vs[2]);
+              int16_t* base = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
+              int& pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
+              const int bw = mcus_x * hsj;
+              for (int v = 0; v < vsj; ++v)
+                for (int h = 0; h < hsj; ++h) {
+                  int16_t* blk = base + ((long long)(my * vsj + v) * bw + mx * hsj + h) * 64;
+                  if (Ah == 0) {
+                    jpeg_bits_fill(&b);
+                    const int sz = jpeg_decode_symbol(&b, tab.dc(tdj)) & 15;
+                    if (sz) pred = (int)((uint32_t)pred + (uint32_t)jpeg_receive_extend(&b, sz));
+                    blk[0] = jpeg_shl(pred, Al);
+                  } else if (jpeg_get_bits(&b, 1)) {
+                    blk[0] = (int16_t)(blk[0] | p1);
+                  }
+                }
+            }
+            if (rst) --togo;
+          }
+      } else {
+        // ---- one component: its own block grid (no dummy blocks), one block per "MCU"
+        const int ci = sc0;
+        const int hsj = ci == 0 ? o->hs[0] : (ci == 1 ? o->hs[1] : o->hs[2]);
+        const int vsj = ci == 0 ? o->vs[0] : (ci == 1 ? o->vs[1] : o->vs[2]);
+        int16_t* base = ci == 0 ? c0 : (ci == 1 ? c1 : c2);
+        const int bw = mcus_x * hsj;
+        const int wb = (int)(((long long)W * hsj + (long long)hmax * 8 - 1) / ((long long)hmax * 8));
+        const int hb = (int)(((long long)H * vsj + (long long)vmax * 8 - 1) / ((long long)vmax * 8));
+        int pred = 0;
+        for (int by = 0; by < hb; ++by)
+          for (int bx = 0; bx < wb; ++bx) {
+            if (rst && togo == 0) { jpeg_bits_restart(&b); pred = 0; eobrun = 0; togo = rst; }
+            int16_t* blk = base + ((long long)by * bw + bx) * 64;
+            if (Ss == 0) {
+              if (Ah == 0) {
+                jpeg_bits_fill(&b);
+                const int sz = jpeg_decode_symbol(&b, tab.dc(td0)) & 15;
+                if (sz) pred = (int)((uint32_t)pred + (uint32_t)jpeg_receive_extend(&b, sz));
+                blk[0] = jpeg_shl(pred, Al);
+              } else if (jpeg_get_bits(&b, 1)) {
+                blk[0] = (int16_t)(blk[0] | p1);
+              }
+            } else if (Ah == 0) {
+              // decode_mcu_AC_first
+              if (eobrun > 0) {
+                --eobrun;
+              } else {
+                for (int k = Ss; k <= Se; ++k) {
+                  jpeg_bits_fill(&b);
+                  const int rs = jpeg_decode_symbol(&b, tab.ac(ta0));
+                  const int r = rs >> 4, sz = rs & 15;
+                  if (sz) {
+                    k += r;
+                    const int v = jpeg_receive_extend(&b, sz);
+                    blk[nat[k]] = jpeg_shl(v, Al);            // k <= 63 + 15: entries past 63 alias 63 like libjpeg's table
+                  } else if (r == 15) {
+                    k += 15;
+                  } else {
+                    eobrun = 1u << r;
+                    if (r) eobrun += (unsigned)jpeg_get_bits(&b, r);
+                    --eobrun;
+                    break;
+                  }
+                }
+              }
+            } else {
+              // decode_mcu_AC_refine
+              int k = Ss;
+              if (eobrun == 0) {
+                for (; k <= Se; ++k) {
+                  jpeg_bits_fill(&b);
+                  const int rs = jpeg_decode_symbol(&b, tab.ac(ta0));
+                  int r = rs >> 4, sv = rs & 15;
+                  if (sv) {
+                    sv = jpeg_get_bits(&b, 1) ? p1 : m1;        // (size must be 1: libjpeg warns and goes on alike)
+                  } else if (r != 15) {
+                    eobrun = 1u << r;
+                    if (r) eobrun += (unsigned)jpeg_get_bits(&b, r);
+                    break;                                    // force end-of-band
+                  }
+                  // advance over already-nonzero coefficients and r still-zero ones, appending correction bits to the nonzeroes
+                  do {
+                    int16_t* c = blk + nat[k];
+                    if (*c != 0) jpeg_refine_nonzero(&b, c, p1, m1);
+                    else if (--r < 0) break;                  // reached the target zero coefficient
+                    ++k;
+                  } while (k <= Se);
+                  if (sv) blk[nat[k]] = (int16_t)sv;
+                }
+              }
+              if (eobrun > 0) {
+                // correction bits for the already-nonzero coefficients after the end of band
+                for (; k <= Se; ++k) {
+                  int16_t* c = blk + nat[k];
+                  if (*c != 0) jpeg_refine_nonzero(&b, c, p1, m1);
+                }
+                --eobrun;
+              }
+            }
+            if (rst) --togo;
+          }
+      }
+      // the scan's data must stop at a marker (< 8 padding bits before it)
+      jpeg_bits_fill(&b);
+      if (!b.marker || b.pos + 2 > len) JPEG_PROG_FAIL(1);
+      p = b.pos;                                          // at the 0xFF of the next marker
+      continue;
+    }
+    p += L;
+  }
+  JPEG_PROG_FAIL(1);
 }
 
 // ---------------------------------------------------------------------------------------------- IDCT (jidctint.c, ISLOW)

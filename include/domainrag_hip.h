@@ -374,7 +374,9 @@ typedef struct drag_jpeg_info {
   int32_t scan_off;              /* first entropy-coded byte */
   int32_t dqt_off[4], dqt_16[4]; /* table offsets inside the file (-1 = absent), 16-bit flag */
   int32_t dht_off[8];            /* [class * 4 + id] */
-  int32_t reserved[7];
+  int32_t progressive;          /* 1 = SOF2 (scan_off then names the first SOS marker; td / ta are per scan) */
+  int32_t cid[3];               /* component identifiers */
+  int32_t reserved[3];
 } drag_jpeg_info;
 int drag_jpeg_parse(const void* data, const int64_t* offsets, int32_t n, drag_jpeg_info* info, void* stream);
 int drag_jpeg_decode_rgb(const void* data, const int64_t* offsets, const drag_jpeg_info* info, const int64_t* plan, int32_t n,

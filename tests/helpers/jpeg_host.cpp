@@ -33,6 +33,23 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* file, int64_t len, uint8_t* r
   std::vector<uint16_t> luts(6 * 256);
   std::vector<uint32_t> limk(6 * 17);
   std::vector<uint8_t> vals(6 * 256);
+  // coefficient storage
+  std::vector<std::vector<int16_t>> coef(3);
+  for (int c = 0; c < o.ncomp; ++c) coef[c].assign((size_t)jpeg_blocks_w(&o, c) * jpeg_blocks_h(&o, c) * 64, 0);
+  uint8_t nat[80];
+  jpeg_fill_natural_order(nat);
+  if (o.progressive) {
+    // SOF2: the scan walker shared with jpeg_progressive_kernel; table id 0 / 1 of each class, rebuilt per scan
+    struct HostTab {
+      uint16_t* l; uint32_t* k; uint8_t* v;
+      HostTableDC dc(int id) const { HostTableDC t; t.l = l + id * 256; t.k = k + id * 17; t.v = v + id * 256; return t; }
+      HostTable ac(int id) const { HostTable t; t.l = l + (2 + id) * 256; t.k = k + (2 + id) * 17; t.v = v + (2 + id) * 256; return t; }
+    };
+    const HostTab tab{luts.data(), limk.data(), vals.data()};
+    const int rc = jpeg_decode_progressive(d, len, &o, tab, (const uint8_t*)nat, coef[0].data(), o.ncomp == 3 ? coef[1].data() : nullptr,
+                                           o.ncomp == 3 ? coef[2].data() : nullptr);
+    if (rc) return 100 + rc;          // 101: not followed / damaged, 102: scans stop early (the caller lets libjpeg decide)
+  } else {
   HostTableDC tdc[3];
   HostTable tac[3];
   for (int c = 0; c < o.ncomp; ++c) {
@@ -41,11 +58,6 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* file, int64_t len, uint8_t* r
     jpeg_build_huff(d + o.dht_off[o.td[c]], tdc[c]);
     jpeg_build_huff(d + o.dht_off[4 + o.ta[c]], tac[c]);
   }
-  // coefficient storage
-  std::vector<std::vector<int16_t>> coef(o.ncomp);
-  for (int c = 0; c < o.ncomp; ++c) coef[c].assign((size_t)jpeg_blocks_w(&o, c) * jpeg_blocks_h(&o, c) * 64, 0);
-  uint8_t nat[80];
-  jpeg_fill_natural_order(nat);
   JpegBits b;
   jpeg_bits_init(&b, d, o.scan_off, len);
   int pred[3] = {0, 0, 0};
@@ -62,6 +74,7 @@ extern "C" int jpeg_host_decode_rgb(const uint8_t* file, int64_t len, uint8_t* r
           }
       if (o.restart_interval) --togo;
     }
+  }
   // planes
   std::vector<std::vector<uint8_t>> plane(o.ncomp);
   for (int c = 0; c < o.ncomp; ++c) {

@@ -91,7 +91,9 @@ def test_unsupported_variants_are_reported_not_guessed(host):
     rng = np.random.default_rng(3)
     im = natural_image(rng, 40, 56)
     info = (ctypes.c_int32 * 48)()
-    cases = {"progressive": (encode(im, quality=80, progressive=True), 3),
+    prog = bytearray(encode(im, quality=80, progressive=True))
+    i = prog.index(b"\xff\xc2"); prog[i + 1] = 0xCA                     # SOF10: progressive, ARITHMETIC coding
+    cases = {"arithmetic progressive": (bytes(prog), 3),
              "cmyk": (encode(im.convert("CMYK"), quality=80), 5),
              "not a jpeg": (b"\x89PNG\r\n\x1a\n" + b"\0" * 32, 1),
              "truncated header": (encode(im, quality=80)[:40], 2),
@@ -101,6 +103,47 @@ def test_unsupported_variants_are_reported_not_guessed(host):
     ok = encode(im, quality=80, subsampling=1)
     assert host.jpeg_host_info(ok, len(ok), info) == 0
     assert (info[1], info[2], info[3]) == (56, 40, 3) and (info[4], info[7]) == (2, 1)      # width, height, ncomp; luma 2x1
+
+
+@pytest.mark.parametrize("size", [(64, 48), (33, 17), (101, 77), (8, 8), (17, 40), (5, 3), (16, 1), (200, 150)])
+def test_progressive_decode_is_byte_identical_to_pil(host, size):
+    """round 3: SOF2 files — libjpeg's default progression (interleaved DC first, per-component AC first scans with spectral
+    selection, AC and DC refinement scans), every subsampling, grey, restart intervals, optimised tables — decode to PIL's bytes"""
+    rng = np.random.default_rng(size[0] * 131 + size[1])
+    w, h = size
+    im = natural_image(rng, h, w)
+    cases = [dict(quality=q, subsampling=sub) for q in (30, 75, 92, 100) for sub in (0, 1, 2)]
+    cases += [dict(quality=85, subsampling=2, optimize=True), dict(quality=60, subsampling=1, restart_marker_blocks=2),
+              dict(quality=90, subsampling=0, restart_marker_rows=1)]
+    info = (ctypes.c_int32 * 48)()
+    for kw in cases:
+        if w <= 4 and kw.get("subsampling", 0) != 0:
+            continue                                                        # (status 9: chroma too narrow for the triangle filters)
+        data = encode(im, progressive=True, **kw)
+        assert host.jpeg_host_info(data, len(data), info) == 0 and info[41] == 1, kw      # parsed as progressive
+        st, out, ref = decode_both(host, data)
+        assert st == 0, (kw, st)
+        assert np.array_equal(out, ref), (kw, int(np.abs(out.astype(int) - ref).max()))
+    grey = encode(im.convert("L"), quality=80, progressive=True)
+    st, out, ref = decode_both(host, grey)
+    assert st == 0 and np.array_equal(out, ref)
+    noise = encode(Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)), quality=97, progressive=True, subsampling=0)
+    st, out, ref = decode_both(host, noise)
+    assert st == 0 and np.array_equal(out, ref)
+
+
+def test_progressive_file_cut_after_some_scans_is_reported(host):
+    """a progressive file whose later scans are missing (EOI spliced in after the third scan): libjpeg would smooth the blocks, so the
+    decoder reports it (102) instead of producing different pixels; one cut inside a scan is reported as damaged (101)"""
+    rng = np.random.default_rng(8)
+    data = encode(natural_image(rng, 48, 64), quality=85, progressive=True, subsampling=2)
+    sos = [i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+    assert len(sos) >= 6
+    early = data[:sos[3]] + b"\xff\xd9"
+    out = np.zeros((48, 64, 3), np.uint8)
+    assert host.jpeg_host_decode_rgb(early, len(early), out.ctypes.data) == 102
+    cut = data[:sos[2] + 40]
+    assert host.jpeg_host_decode_rgb(cut, len(cut), out.ctypes.data) == 101
 
 
 def test_truncated_scan_does_not_crash_and_keeps_the_decoded_part(host):
