@@ -436,6 +436,7 @@ JHD int jpeg_decode_progressive(const uint8_t* d, int64_t len, const JpegInfo* o
   int rst = o->restart_interval;
   int32_t dh_dc0 = o->dht_off[0], dh_dc1 = o->dht_off[1], dh_ac0 = o->dht_off[4], dh_ac1 = o->dht_off[5];
   uint64_t done0 = 0, done1 = 0, done2 = 0;            // bit k: coefficient k (zigzag) of the component has reached Al = 0
+  int nscans = 0;
   const int ncomp = o->ncomp, W = o->width, H = o->height, hmax = o->hmax, vmax = o->vmax, mcus_x = o->mcus_x, mcus_y = o->mcus_y;
   for (int guard = 0; guard < 4096; ++guard) {
     if (p + 2 > len || d[p] != 0xFF) JPEG_PROG_FAIL(1);
@@ -472,6 +473,7 @@ JHD int jpeg_decode_progressive(const uint8_t* d, int64_t len, const JpegInfo* o
     } else if (m == 0xDB || (m >= 0xC0 && m <= 0xCF && m != 0xC4)) {
       JPEG_PROG_FAIL(1);                                // new quantisation tables / a second frame header between scans
     } else if (m == 0xDA) {
+      if (++nscans > 128) JPEG_PROG_FAIL(1);             // (an encoder writes ~10; a hostile file could keep a lane busy for minutes)
       const int ns = n >= 1 ? s[0] : 0;
       if (ns < 1 || ns > ncomp || n < 1 + 2 * ns + 3) JPEG_PROG_FAIL(1);
       // scan components as indices into the frame's component list (in frame order, as the standard requires)

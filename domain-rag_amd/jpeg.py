@@ -4,7 +4,7 @@
 
 The host's part is reading files: a batch travels as ONE byte blob + offsets; markers are parsed on the device, the only
 read-back is the per-file descriptor (size, sampling, status) needed to size the outputs.  Files the device path does not
-cover (progressive, CMYK, unusual sampling — ``status != 0``) are reported, not guessed: the caller decodes those few with
+cover (CMYK, arithmetic coding, unusual sampling — ``status != 0``; progressive files ARE decoded on the device since round 3) are reported, not guessed: the caller decodes those few with
 PIL (same bytes by definition).
 
     batch = decode_files([bytes, ...], device)      # -> DecodedBatch
@@ -22,9 +22,9 @@ from . import _lib
 from .ops import _p, _stream, check
 
 INFO_WORDS = 48
-STATUS_TEXT = {0: "ok", 1: "not a JPEG", 2: "truncated header", 3: "progressive / arithmetic / lossless", 4: "not 8-bit",
+STATUS_TEXT = {0: "ok", 1: "not a JPEG", 2: "truncated header", 3: "arithmetic / lossless / hierarchical frame type", 4: "not 8-bit",
                5: "not grey or YCbCr", 6: "sampling other than 4:4:4 / 4:2:2 / 4:2:0", 7: "multi-scan", 8: "table problem",
-               9: "chroma at most 2 samples wide", 11: "more than 2^24 pixels", 10: "entropy-coded data does not end at EOI (cut short / trailing data / damaged)"}
+               9: "chroma at most 2 samples wide", 11: "more than 2^24 pixels", 10: "entropy-coded data does not end at EOI (cut short / trailing data / damaged), or a progressive file whose scans stop early"}
 
 
 class DecodedBatch:
@@ -235,4 +235,4 @@ def info_dict(row: np.ndarray) -> dict:
     r = [int(v) for v in row]
     return dict(status=r[0], width=r[1], height=r[2], ncomp=r[3], hs=r[4:7], vs=r[7:10], tq=r[10:13], td=r[13:16], ta=r[16:19],
                 hmax=r[19], vmax=r[20], mcus_x=r[21], mcus_y=r[22], restart_interval=r[23], scan_off=r[24], dqt_off=r[25:29],
-                dqt_16=r[29:33], dht_off=r[33:41])
+                dqt_16=r[29:33], dht_off=r[33:41], progressive=r[41], cid=r[42:45])

@@ -251,7 +251,7 @@ class StemStyle:
     def features_from_files(self, image_paths: list, chunk: int = 2048) -> list:
         """style vectors of many files with everything on the GPU: native file reads -> JPEG decode (``jpeg.decode_files``,
         PIL's bytes) -> OpenCV-linear resize to 256x256 + /255 (``drag_cv_resize_linear_u8_f32``) -> stem.  Returns one float32
-        [128] vector (numpy) or None per path, in order.  Files the device decoder declines (PNG, progressive, damaged, EXIF-
+        [128] vector (numpy) or None per path, in order.  Files the device decoder declines (PNG, CMYK, damaged, EXIF-
         rotated, ...) take ``features_from_path`` on the host with the SAME restated resize, so a cache never mixes algorithms."""
         import ctypes
         from . import _lib, jpeg
@@ -454,7 +454,7 @@ def _embed_files_gpu_decode(model: ClipImageModel, mine: list[str], feats: torch
     2^33 = 64 GB of buffers; 16384 files of 640x480 are 5e9 pixels = 38 GB and stay one piece; $DRAG_JPEG_MAX_PIXELS overrides)
     is decoded in consecutive pieces that each stay within it — a corpus of multi-megapixel files (mini-ImageNet has some) costs more launches, never an
     out-of-memory abort (the reference decodes one file at a time and takes any size).
-    Files outside the device decoder's coverage (progressive, CMYK, PNG, damaged, ...) go through PIL on the host, one by one, like
+    Files outside the device decoder's coverage (CMYK, arithmetic-coded, PNG, damaged, ...) go through PIL on the host, one by one, like
     the reference does for every file; what PIL cannot open is skipped with the reference's message (:290-292).  Returns counters."""
     import concurrent.futures as cf
     import io

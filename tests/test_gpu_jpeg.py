@@ -29,7 +29,7 @@ def pil_rgb(data):
 
 def test_mixed_batch_is_byte_identical_to_pil(gpu):
     """one batch mixing sizes, subsamplings, qualities, optimised tables, grey images, restart markers and files the device
-    path must hand back (progressive, CMYK, a PNG, a truncated header)"""
+    path must hand back (arithmetic-coded, CMYK, a PNG, a truncated header); progressive files decode on the device (round 3)"""
     from domain_rag_amd import jpeg
     rng = np.random.default_rng(0)
     blobs, want = [], []
@@ -41,8 +41,14 @@ def test_mixed_batch_is_byte_identical_to_pil(gpu):
     for kw in ({"restart_marker_blocks": 3}, {"restart_marker_rows": 1}):
         blobs.append(encode(natural_image(rng, 90, 130), quality=80, subsampling=2, **kw))
     blobs.append(encode(Image.fromarray(rng.integers(0, 256, (96, 120, 3), dtype=np.uint8)), quality=5))        # noise: saturation
+    for (w, h) in [(640, 480), (33, 17), (101, 77), (8, 8), (500, 375)]:       # SOF2: libjpeg's default progression, every scan type
+        for sub, kw in ((0, {}), (1, {"optimize": True}), (2, {}), (2, {"restart_marker_blocks": 5})):
+            blobs.append(encode(natural_image(rng, h, w), quality=int(rng.integers(30, 98)), subsampling=sub, progressive=True, **kw))
+        blobs.append(encode(natural_image(rng, h, w).convert("L"), quality=80, progressive=True))
     n_ok = len(blobs)
-    rejected = [(encode(natural_image(rng, 40, 56), quality=80, progressive=True), 3),
+    arith = bytearray(encode(natural_image(rng, 40, 56), quality=80, progressive=True))
+    arith[arith.index(b"\xff\xc2") + 1] = 0xCA                                  # SOF10: arithmetic coding
+    rejected = [(bytes(arith), 3),
                 (encode(natural_image(rng, 40, 56).convert("CMYK"), quality=80), 5),
                 (b"\x89PNG\r\n\x1a\n" + bytes(40), 1), (blobs[0][:40], 2)]
     blobs += [b for b, _ in rejected]
@@ -115,6 +121,8 @@ def test_damaged_files_never_fault_the_gpu(gpu):
     rng = np.random.default_rng(11)
     seeds = [encode(natural_image(rng, h, w), quality=int(rng.integers(20, 98)), subsampling=sub, **kw)
              for (w, h) in ((64, 48), (33, 17), (120, 90)) for sub in (0, 1, 2) for kw in ({}, {"optimize": True}, {"restart_marker_blocks": 2})]
+    seeds += [encode(natural_image(rng, h, w), quality=int(rng.integers(20, 98)), subsampling=sub, progressive=True, **kw)
+              for (w, h) in ((64, 48), (33, 17)) for sub in (0, 2) for kw in ({}, {"restart_marker_blocks": 3})]     # the SOF2 scan walker too
     files = []
     for i in range(1500):
         f = bytearray(seeds[int(rng.integers(len(seeds)))])

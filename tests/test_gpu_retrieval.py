@@ -111,7 +111,7 @@ def test_corpus_features_same_bits_through_decode_processes(gpu, tmp_path):
     c, vc = R.compute_corpus_features(model, None, paths, batch=7, decode_procs=3)
     assert va == vb == vc == [p for p in paths if "bad" not in p] and a.shape == (24, 512)
     assert np.array_equal(a, b) and np.array_equal(a, c)
-    # decode on the GPU (the stage-1 default): the host only reads the files; a progressive JPEG and a PNG in the corpus take
+    # decode on the GPU (the stage-1 default): the host only reads the files; a progressive JPEG (decoded on the device too since round 3) and a PNG in the corpus — the PNG takes
     # the PIL detour inside the same call — same pixels either way, so the same embeddings in the same order
     Image.open(paths[3]).save(tmp_path / "prog.jpg", quality=92, progressive=True)
     Image.open(paths[4]).save(tmp_path / "plain.png")

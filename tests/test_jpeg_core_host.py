@@ -178,6 +178,13 @@ def test_mutation_fuzz_under_address_sanitizer(tmp_path):
         p = tmp_path / f"g{k}.jpg"
         p.write_bytes(encode(natural_image(rng, h, w).convert("L"), quality=70))
         seeds.append(str(p))
+        for sub in (0, 2):                                     # progressive files: the scan walker and the refinement passes
+            for j, kw in enumerate(({}, {"restart_marker_blocks": 3})):
+                p = tmp_path / f"p{k}{sub}{j}.jpg"
+                p.write_bytes(encode(natural_image(rng, h, w), quality=int(rng.integers(20, 98)), subsampling=sub, progressive=True, **kw))
+                seeds.append(str(p))
     r = subprocess.run([exe, "6000"] + seeds, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert "iterations 6000" in r.stdout
+    dec = int(r.stdout.split("decoded")[1].split(",")[0])
+    assert dec > 500, r.stdout                                # (mutations that still decode: the arithmetic paths really ran)
