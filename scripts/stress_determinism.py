@@ -32,13 +32,43 @@ for (M, N, K) in [(512, 3072, 12288), (1024, 3072, 3072), (8, 18432, 3072), (729
     ops.set_option("gemm_kernel", 1)
     ref = ops.gemm(A, W, bias=b, act=1).clone()
     n_bad = 0
-    for code in (0, 42, 43, 22, 23, 24, 13, 14):
+    for code in (0, 42, 43, 22, 23, 24, 13, 14, 113, 123, 133, 143):        # 1xx: the 192-column tiles of round 3
         ops.set_option("gemm_kernel", code)
         for i in range(40):
             n_bad += int(not torch.equal(ops.gemm(A, W, bias=b, act=1), ref))
     ops.set_option("gemm_kernel", 0)
     bad += n_bad
-    print(f"ring gemm {M}x{N}x{K}: mismatches vs t128 over 8 kernels x 40 repeats: {n_bad}", flush=True)
+    print(f"ring gemm {M}x{N}x{K}: mismatches vs t128 over 12 kernels x 40 repeats: {n_bad}", flush=True)
+# round 3: the exact top-k (cross-group LDS-DMA ring, per-wave candidate regions, region-walking selection) — 60 repeats per shape
+for (N, Q, k) in [(118287, 16, 100), (118287, 64, 100), (118287, 1, 100), (300000, 40, 2048), (8191, 3, 17)]:
+    corpus = torch.randn(N, 512, device=dev, generator=g); qs = torch.randn(Q, 512, device=dev, generator=g)
+    D0, I0 = ops.cosine_topk(corpus, qs, k)
+    n_bad = sum(int(not (torch.equal(D, D0) and torch.equal(I, I0))) for D, I in (ops.cosine_topk(corpus, qs, k) for _ in range(60)))
+    bad += n_bad
+    print(f"topk N={N} Q={Q} k={k}: differing repeats {n_bad}/60", flush=True)
+    del corpus
+# round 3: the persistent attention experiment against the product kernel, 20 repeats
+import math
+B, S, H = 2, 5337, 24
+D = H * 128
+qkv = torch.randn(B, S, 3 * D, device=dev, generator=g).bfloat16()
+vt = torch.empty(B, H, 128, (S + 63) // 64 * 64, device=dev, dtype=torch.bfloat16)
+wq = (1 + 0.1 * torch.randn(128, device=dev, generator=g)).bfloat16()
+cos = torch.rand(S, 64, device=dev, generator=g); sin = torch.rand(S, 64, device=dev, generator=g)
+ops.k_norm_rope_vt(qkv, vt, wq, wq, cos, sin, B, S, H, 3 * D, 1241)
+def attn():
+    o = torch.empty(B, S, D, device=dev, dtype=torch.bfloat16)
+    ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128), wq, wq, cos, sin, 1241)
+    return o
+ref = attn()
+n_bad = 0
+for per in (0, 1, 4):
+    ops.set_option("attn_persist", per)
+    n_bad += sum(int(not torch.equal(attn(), ref)) for _ in range(20))
+ops.set_option("attn_persist", 0)
+bad += n_bad
+print(f"attention (product / persistent x2): differing repeats {n_bad}/60", flush=True)
+del qkv, vt
 # GPU PNG encoder: atomicOr packing must be order-independent
 from domain_rag_amd import png
 img = torch.randint(0, 256, (4, 777, 1031, 3), device=dev, dtype=torch.uint8, generator=g)
