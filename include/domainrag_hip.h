@@ -29,9 +29,10 @@ const char* drag_last_error(void);
  *   length), "attn_tune" bit 0: static wave priority, bit 1: 16-byte epilogue stores, "attn_q64" 0 | 1 (the 4-wave x 64-query
  *   experiment kernel for S >= 1024), "attn_persist" 0 | 1 | n >= 3 (persistent attention experiment: off, one workgroup per
  *   CU, n per XCD), "gemm_kernel", "gemm_group_m", "ln_generic", "topk_grid" (workgroups at most of the top-k scan, 0 = 512),
- *   "topk_depth" 0 | 3 (LDS-DMA ring depth of the scan).
+ *   "topk_depth" 0 | 3 (LDS-DMA ring depth of the scan), "topk_qt" 0 | 2 | 4 (query tiles per scan workgroup), "topk_select" 0 | 256 | 1024,
+ *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima).
  * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
- * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH.  Returns 0, or -1 for an unknown name. */
+ * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 
 /* activation codes used by epilogues */

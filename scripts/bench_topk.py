@@ -20,7 +20,7 @@ for N in [int(x) for x in os.environ.get("NS", "1000,118287,1000000").split(",")
     qs = torch.randn(128, 512, device=dev, generator=g); qs /= qs.norm(dim=-1, keepdim=True)
     for grid, depth in [(g_, d_) for g_ in grids for d_ in [int(x) for x in os.environ.get("DEPTHS", "0").split(",")]]:
         ops.set_option("topk_grid", grid); ops.set_option("topk_depth", depth)
-        ops.set_option("topk_select", int(os.environ.get("SELECT", "0")))
+        ops.set_option("topk_select", int(os.environ.get("SELECT", "0"))); ops.set_option("topk_qt", int(os.environ.get("QT", "0")))
         for Q in (1, 16, 32, 64, 128):
             q = qs[:Q].contiguous()
             ms = bench(lambda: ops.cosine_topk(corpus, q, 100))
@@ -33,4 +33,4 @@ for N in [int(x) for x in os.environ.get("NS", "1000,118287,1000000").split(",")
                 b2 = N * 512 * 4 + Q * 512 * 4 + Q * sc.shape[1] * 4
                 line += f" | scan only {ms2*1e3:.1f} us = {b2/ms2/1e6:.0f} GB/s, {2*N*512*Q/ms2/1e9:.1f} TFLOP/s f32"
             print(line, flush=True)
-ops.set_option("topk_grid", 0); ops.set_option("topk_depth", 0); ops.set_option("topk_select", 0)
+ops.set_option("topk_grid", 0); ops.set_option("topk_depth", 0); ops.set_option("topk_select", 0); ops.set_option("topk_qt", 0)

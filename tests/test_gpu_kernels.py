@@ -420,20 +420,23 @@ def test_topk_threshold_and_selection_variants_give_the_same_answer(gpu):
     from domain_rag_amd import ops
     g = torch.Generator(device=gpu).manual_seed(9)
     corpus = torch.randn(50021, 512, generator=g, device=gpu)
-    q = torch.randn(21, 512, generator=g, device=gpu)
+    q = torch.randn(53, 512, generator=g, device=gpu)
     try:
         ref = {k: ops.cosine_topk(corpus, q, k) for k in (1, 100, 128, 129)}
+        sc0 = ops.cosine_scores(corpus, q)
         for opts in ({"topk_dense_sample": 1}, {"topk_select": 256}, {"topk_select": 1024}, {"topk_grid": 1024, "topk_depth": 3},
-                     {"topk_dense_sample": 1, "topk_select": 1024, "topk_grid": 2048}):
+                     {"topk_dense_sample": 1, "topk_select": 1024, "topk_grid": 2048}, {"topk_qt": 2}, {"topk_qt": 4},
+                     {"topk_qt": 4, "topk_grid": 1024}):
             for name, v in opts.items():
                 ops.set_option(name, v)
             for k, (D0, I0) in ref.items():
                 D, I = ops.cosine_topk(corpus, q, k)
                 assert torch.equal(D, D0) and torch.equal(I, I0), (opts, k)
+            assert torch.equal(ops.cosine_scores(corpus, q)[:, :50021], sc0[:, :50021]), opts
             for name in opts:
                 ops.set_option(name, 0)
     finally:
-        for name in ("topk_dense_sample", "topk_select", "topk_grid", "topk_depth"):
+        for name in ("topk_dense_sample", "topk_select", "topk_grid", "topk_depth", "topk_qt"):
             ops.set_option(name, 0)
 
 
