@@ -190,3 +190,37 @@ def test_rfft2_random_sizes_roundtrip_and_reference(gpu):
         back = torch.empty(B, H, W, C, device=gpu)
         ops.irfft2_f32(f, tmp, back, None, B, H, W, C, C, 0, tw_w, tw_h)
         assert (back.cpu() - x).abs().max().item() < 3e-5 * x.abs().max().item(), (B, H, W, C)     # irfft2(rfft2(x)) == x
+
+
+def test_topk_fuzz_with_ties_nonfinite_rows_and_every_measurement_option(gpu):
+    """round 3's top-k (sample threshold, filtered scan into per-wave regions, region-walking selection) on random (N, d, Q, k) with
+    duplicated rows (exact ties -> index order), planted NaN / inf rows and random speed options: (D, I) are the oracle's, bit for bit
+    (scripts/fuzz_topk.py is the long form)"""
+    import numpy as np
+    import torch
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(2024)
+    names = ("topk_qt", "topk_grid", "topk_depth", "topk_dense_sample", "topk_select")
+    try:
+        for c in range(28):
+            d = int(rng.choice([64, 128, 512]))
+            N = int(rng.choice([rng.integers(1, 600), rng.integers(600, 9000), rng.integers(8193, 50000)]))
+            Q = int(rng.choice([1, rng.integers(1, 17), rng.integers(17, 65), rng.integers(65, 140)]))
+            k = int(rng.choice([1, rng.integers(1, 129), rng.integers(129, 2049)]))
+            pool = rng.standard_normal((max(1, int(N * rng.choice([1.0, 0.3, 0.02]))), d)).astype(np.float32)
+            corpus = pool[rng.integers(0, len(pool), N)]
+            if rng.random() < 0.3 and N > 10:
+                corpus[rng.integers(0, N)] = np.nan; corpus[rng.integers(0, N)] = np.inf; corpus[rng.integers(0, N), 0] = -np.inf
+            q = rng.standard_normal((Q, d)).astype(np.float32)
+            opts = dict(zip(names, (int(rng.choice([0, 2, 4])), int(rng.choice([0, 256, 1024, 2048])), int(rng.choice([0, 3])),
+                                    int(rng.integers(0, 2)), int(rng.choice([0, 256, 1024])))))
+            for n_, v in opts.items():
+                ops.set_option(n_, v)
+            D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(q).to(gpu), k)
+            Dr, Ir = oret.cosine_topk(corpus, q, k)
+            assert np.array_equal(I.cpu().numpy(), Ir), (c, N, d, Q, k, opts)
+            assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), (c, N, d, Q, k, opts)
+    finally:
+        for n_ in names:
+            ops.set_option(n_, 0)
