@@ -73,7 +73,27 @@ struct GemmKArgs {
   void* C2;
   int ld2, n_split;
   int group_m;    // M tiles per group of the tile walk (8; "gemm_group_m" option for measurements)
+  // optional second row segment (drag_gemm_bf16_pair): M tiles >= seg_tiles_m belong to a second problem with its own operands and
+  // row maps but the same N, K and epilogue form — a double block's text and image Linears as ONE launch of the non-persistent kernels
+  int seg_tiles_m;          // 0: one segment
+  const bf16_t* A2;
+  const bf16_t* W2;
+  void* Cs2;
+  const bf16_t* bias2;
+  const bf16_t* gate2;
+  const bf16_t* resid2;
+  int M2, ldg2, wide2;
+  RowMap am2, cm2;
 };
+
+// a workgroup whose M tile lies in the second segment swaps that segment's operands in (wave-uniform: scalar moves)
+__device__ __forceinline__ void pick_segment(GemmKArgs& p, int& tm) {
+  if (p.seg_tiles_m > 0 && tm >= p.seg_tiles_m) {
+    tm -= p.seg_tiles_m;
+    p.A = p.A2; p.W = p.W2; p.C = p.Cs2; p.bias = p.bias2; p.gate = p.gate2; p.resid = p.resid2;
+    p.M = p.M2; p.ldg = p.ldg2; p.wide = p.wide2; p.am = p.am2; p.cm = p.cm2;
+  }
+}
 
 // the arguments as the epilogue of the tile at column n0 sees them
 __device__ __forceinline__ GemmKArgs dest_of(const GemmKArgs& p, int n0) {
@@ -365,8 +385,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
   const int first_m = gid * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
   const int rem = wg - gid * in_group;
-  const int tm = first_m + rem % gsz;
+  int tm = first_m + rem % gsz;
   const int tn = rem / gsz;
+  if (MODE == 0) pick_segment(p, tm);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging addresses: wave w stages 8-row chunks {4w..4w+3} of both tiles ----
@@ -482,6 +503,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
   const int wr = w >> 1, wc = w & 1;
   int tm, tn;
   pick_tile(p, (int)blockIdx.x, tm, tn);
+  pick_segment(p, tm);
   const int m0 = tm * TBM, n0 = tn * TBN;
 
   const long long a0 = p.am.off(m0);
@@ -605,8 +627,8 @@ constexpr int T2_BUF = 4 * T2_HALF;            // A0 A1 B0 B1
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
 
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
+template <int MODE, bool SEG>   // SEG: the launch may carry a second row segment (drag_gemm_bf16_pair)
+__device__ __forceinline__ void t256_body(const GemmKArgs& p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * T2_BUF + 8 * 2048];   // + one 2 KiB epilogue slab per wave
   const int w = wave_id();
   const int l = lane_id();
@@ -643,12 +665,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
   auto load_state = [&](int tile) {
     int tm, tn;
     pick_tile(p, tile, tm, tn);
+    const bf16_t* A = p.A;
+    const bf16_t* W = p.W;
+    int M = p.M;
+    RowMap am = p.am;
+    if (SEG && p.seg_tiles_m > 0 && tm >= p.seg_tiles_m) { tm -= p.seg_tiles_m; A = p.A2; W = p.W2; M = p.M2; am = p.am2; }
     const int m0 = tm * 256, n0 = tn * 256;
     // descriptors are based at the tile's first row, so operands of any size work with 32-bit in-tile offsets
-    const long long a0 = MODE == 0 ? p.am.off(m0) : p.cv.off(m0);
-    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a0), 0, 0x7ffffff0u, 0x00020000);
+    const long long a0 = MODE == 0 ? am.off(m0) : p.cv.off(m0);
+    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + a0), 0, 0x7ffffff0u, 0x00020000);
     const int wrows = min(256, p.N - n0);
-    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)n0 * p.K), 0, (unsigned)((long long)wrows * p.K * 2),
+    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long long)n0 * p.K), 0, (unsigned)((long long)wrows * p.K * 2),
                                             0x00020000);
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc)
@@ -658,8 +685,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
         const int row = chunk_row0(pc, c & 7) + (l >> 3);      // this lane's row inside the half
         const int slot = (l & 7) ^ ((row >> 1) & 7);
         if (pc == 0 || pc == 3) {
-          const int ra = min(m0 + half * 128 + row, p.M - 1);  // clamp: rows past the edge are never stored
-          vo[pc][c2] = (unsigned)(((MODE == 0 ? p.am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
+          const int ra = min(m0 + half * 128 + row, M - 1);    // clamp: rows past the edge are never stored
+          vo[pc][c2] = (unsigned)(((MODE == 0 ? am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
         } else {
           const int rw = min(half * 128 + row, wrows - 1);
           vo[pc][c2] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
@@ -773,17 +800,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
     if (!have_next && wr == 0) T2_BARRIER();         // balance the stagger before the last epilogue
     int tm, tn;
     pick_tile(p, vb, tm, tn);
+    GemmKArgs pd = p;
+    if (SEG) pick_segment(pd, tm);
     const int m0 = tm * 256, n0 = tn * 256;
-    const GemmKArgs pd = dest_of(p, n0);
-    if (p.wide) staged_epilogue<8, 256>(pd, m0, m0 + wr * 128, n0, n0 + wc * 64, l, acc, smem + 2 * T2_BUF + w * 2048);
+    pd = dest_of(pd, n0);
+    if (pd.wide) staged_epilogue<8, 256>(pd, m0, m0 + wr * 128, n0, n0 + wc * 64, l, acc, smem + 2 * T2_BUF + w * 2048);
     else wave_epilogue<8, 256>(pd, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 64 + (l >> 4) * 4, acc);
     if (!have_next) break;
-    after_interior_epilogue = m0 + 256 <= p.M && n0 + 256 <= p.N;
+    after_interior_epilogue = m0 + 256 <= pd.M && n0 + 256 <= p.N;
     vb += P;
   }
 #undef T2_MMA
 #undef T2_WAIT
 }
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) { t256_body<MODE, false>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_bf16_t256_pair(GemmKArgs p) { t256_body<0, true>(p); }
 
 }  // namespace
 
@@ -794,12 +827,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) {
 // 504 tiles 1384 vs 1069, but 72 tiles 510 vs 680 and 288 tiles 927 vs 993).
 // A/B switches are read once per process (not per launch)
 static bool env_flag(const char* name) { return getenv(name) != nullptr; }
-static bool use_t256(long long M, int N, int K) {
+// rows of tiles of height tm over one problem, or over the two row segments of a pair (each segment starts on a tile boundary)
+static long long tile_rows(long long M1, long long M2, int tm) { return (M1 + tm - 1) / tm + (M2 > 0 ? (M2 + tm - 1) / tm : 0); }
+
+static bool use_t256(long long M1, long long M2, int N, int K) {
   static const bool force_t128 = env_flag("DRAG_GEMM_T128");
   if (force_t128 || N < 256 || K < 256) return false;
-  if (M >= 2048) return true;
+  const long long M = M1 + M2;
+  if (M >= 2048 && M2 == 0) return true;
   if (M < 1024) return false;
-  const long long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  const long long tiles = tile_rows(M1, M2, 256) * ((N + 255) / 256);
   if (tiles < 128) return false;
   if (tiles <= 256) return true;
   const long long rounds = (tiles + 255) / 256;
@@ -812,32 +849,64 @@ static bool use_t256(long long M, int N, int K) {
 // (8, 18432, 3072) — the AdaLN modulation Linears at batch 8, an HBM stream of the weight — 27 -> 46 (5.7 TB/s), (64, 3072, 3072) 38 -> 68.
 // Round 3, 192-column tiles (gemm_bf16_deep<MI, 3, 6>): such a launch is bound by the L2 -> LDS ingest of its busiest CU, i.e. by
 //   cost = (tile rounds on the busiest CU) x (tile rows + tile columns);
-// a (32 * MI) x 192 tiling replaces the 128-column choice when it is ONE full round (>= 94 % of the CUs, one workgroup each), cuts
-// that cost by >= 10 % and either the K loop is long (K >= 8192: the exposed ring fill + epilogue of a lone workgroup per CU are
-// then < 5 % of it) or the 128-column choice is a one-workgroup-per-CU ring kernel already.  Measured (scripts/bench_gemm_small_m.py,
-// TFLOP/s, isolated): (1536, 3072, 15360) — 288 128x128 tiles, 32 CUs carry two — t128 794 -> 96x192 903; (1024, 3072, 12288)
-// 64x128 703 -> 64x192 757; (1024, 3072, 3072) 622 -> 633.  NOT taken where the model alone would: (1536, 12288, 3072) 3 full rounds
-// of 128x192 847 vs t128 953 and (512, 12288, 3072) one round of 128x192 825 vs t128 879 — at K = 3072 t128's two workgroups per CU
-// overlap each other's fill and epilogue, which one workgroup per CU cannot.
-static int deep_policy(long long M, int N, int K) {
+// the cheapest (32 * MI) x 192 tiling that is ONE round on >= 75 % of the CUs replaces the 128-column choice when it cuts that cost by
+// >= 10 %.  The numbers that decide are taken with COLD weights (COLD=1 in scripts/bench_gemm_small_m.py / bench_gemm_pair.py: every
+// launch reads a matrix no recent launch touched, as inside a batch-1 forward where 24 GB of weights pass a 256 MB Infinity Cache):
+// TFLOP/s, 128-column choice -> 192: (1536, 3072, 15360) t128 677 -> 96x192 865 (128x192 753); (512, 12288, 3072) 580 -> 128x192 798;
+// the pair (1024 + 512, 3072, 12288) with gate + residual 622 -> 128x192 731; (1024, 3072, 12288) 64x128 503 -> 64x192 628.  Hot
+// (one matrix re-read from the Infinity Cache) the K = 3072 cases tip the other way ((512, 12288, 3072) 825 vs t128 879): a pipeline
+// never sees that state.  Ring depths 2 and 4 were measured too (codes 1x2 / 1x4): 4 changes nothing, 2 (two workgroups per CU) loses.
+// Round 3, 96 x 128 tiles (gemm_bf16_deep<3, 2>: 2-stage ring, two workgroups per CU like t128) where t128 has MORE than 256 tiles and the
+// same cost model prefers them — (1024 + 512, 3072, 3072) as a pair: 288 128-row tiles (32 CUs carry two) 696 -> 17 x 24 = 408 96-row
+// tiles 806; (1024 + 512, 3072, 12288) 835 -> 906; (512, 9216, 3072) 673 -> 820; (1536, 12288, 3072) 998 -> 1088; not (512, 12288, 3072): 384 tiles
+// in one paired round 917 vs 576 tiles in two 598; not (1458, 4304, 1152) 699 vs 497 (scripts/bench_gemm_pair.py, bench_gemm_small_m.py).
+// M2 > 0: the rows of a drag_gemm_bf16_pair launch (tile counts are per segment).  *cost_out: the chosen tiling's cost.
+// workgroups the busiest CU runs when a CU holds two at a time (t128, the 2-stage 96 x 128 kernel): past one round the workgroups come
+// in rounds of 512 and a partly filled last round costs a full one ((1536, 12288, 3072): 1152 128x128 tiles = 2.25 such rounds, 998
+// TFLOP/s; 1536 96x128 tiles = exactly 3, 1088)
+static long long paired_rounds(long long tiles) { return tiles <= 256 ? 1 : 2 * ((tiles + 511) / 512); }
+
+static int deep_policy(long long M1, long long M2, int N, int K, long long* cost_out) {
+  const long long M = M1 + M2;
   const long long tn = (N + 127) / 128;
   int pick;
   long long cost;                                   // of the 128-column choice, in the units above
-  const long long tiles128 = ((M + 127) / 128) * tn;
-  if (M <= 32 || ((M + 63) / 64) * tn < 64) return 14;     // 32-row tiles: no MFMA work on rows that do not exist, more workgroups
-  if (tiles128 <= 128) { pick = 24; cost = ((((M + 63) / 64) * tn + 255) / 256) * (64 + 128); }        // <= 256 workgroups of 64 x 128: one per CU, 4-stage ring (96 KiB)
-  else if (tiles128 <= 256) { pick = 23; cost = ((((M + 63) / 64) * tn + 255) / 256) * (64 + 128); }   // <= 512 workgroups: two per CU, 3-stage ring (72 KiB each)
-  else { pick = 0; cost = ((tiles128 + 255) / 256) * (128 + 128); }
+  const long long tiles128 = tile_rows(M1, M2, 128) * tn, tiles64 = tile_rows(M1, M2, 64) * tn;
+  if (M <= 32 || tiles64 < 64) {                   // 32-row tiles: no MFMA work on rows that do not exist, more workgroups
+    if (cost_out) *cost_out = ((tile_rows(M1, M2, 32) * tn + 255) / 256) * (32 + 128);
+    return 14;
+  }
+  if (tiles128 <= 128) { pick = 24; cost = ((tiles64 + 255) / 256) * (64 + 128); }        // <= 256 workgroups of 64 x 128: one per CU, 4-stage ring (96 KiB)
+  else if (tiles128 <= 256) { pick = 23; cost = ((tiles64 + 255) / 256) * (64 + 128); }   // <= 512 workgroups: two per CU, 3-stage ring (72 KiB each)
+  else { pick = 0; cost = paired_rounds(tiles128) * (128 + 128); }
   static const bool no192 = env_flag("DRAG_GEMM_NO_192");
   if (N % 192 == 0 && M >= 256 && !no192) {
+    // the cheapest (32 * MI) x 192 tiling that is ONE round on >= 75 % of the CUs
+    long long c192 = 0;
+    int mi192 = 0;
     for (int mi = 4; mi >= 1; --mi) {
-      const long long tiles = ((M + 32 * mi - 1) / (32 * mi)) * (N / 192);
-      if (tiles > 256 || tiles * 100 < 256 * 94) continue;
-      const long long c192 = 32 * mi + 192;
-      if (c192 * 10 <= cost * 9 && (K >= 8192 || pick != 0)) return 100 + 10 * mi + 3;
-      break;
+      const long long tiles = tile_rows(M1, M2, 32 * mi) * (N / 192);
+      if (tiles > 256 || tiles < 192) continue;
+      if (mi192 == 0 || 32 * mi + 192 < c192) { mi192 = mi; c192 = 32 * mi + 192; }
+    }
+    if (mi192 && c192 * 10 <= cost * 9) {
+      if (cost_out) *cost_out = c192;
+      return 100 + 10 * mi192 + 3;
     }
   }
+  static const bool no96 = env_flag("DRAG_GEMM_NO_96");
+  if (pick == 0 && !no96) {
+    const long long c96 = paired_rounds(tile_rows(M1, M2, 96) * tn) * (96 + 128);
+    if (c96 < cost) { pick = 32; cost = c96; }
+  }
+  // a partly filled second round of 256x256 tiles can still be the cheapest way through ((1536, 12288, 3072), weights cold: 908 TFLOP/s
+  // against 797 for 96x128 and 772 for 128x128 tiles)
+  static const bool force_t128 = env_flag("DRAG_GEMM_T128");
+  if (pick != 24 && pick != 23 && M >= 1024 && N >= 256 && K >= 256 && !force_t128) {
+    const long long c256 = ((tile_rows(M1, M2, 256) * ((N + 255) / 256) + 255) / 256) * (256 + 256);
+    if (c256 < cost) { pick = 2; cost = c256; }
+  }
+  if (cost_out) *cost_out = cost;
   return pick;
 }
 
@@ -866,6 +935,8 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
   k.a_bytes = 0; k.w_bytes = 0;
   k.C2 = nullptr; k.ld2 = 0; k.n_split = 0;
+  k.seg_tiles_m = 0; k.A2 = nullptr; k.W2 = nullptr; k.Cs2 = nullptr; k.bias2 = nullptr; k.gate2 = nullptr; k.resid2 = nullptr;
+  k.M2 = 0; k.ldg2 = 0; k.wide2 = 0; k.am2 = RowMap{1, 0, 0}; k.cm2 = RowMap{1, 0, 0};
   // M tiles per group of the tile walk: the 32 concurrent tiles of an XCD form a group_m x (32 / group_m) super-tile.  4 and 8 tie on
   // the K = 3072 shapes (8 ahead by 1-3 % at N = 3072), 4 is 2-3 % ahead at K >= 12288; 16 / 32 (towards W-stationary) lose 5-10 %
   // everywhere (scripts/bench_gemm_group_m.py, two boxes).  Order only: the bits do not depend on it.
@@ -878,7 +949,8 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   return k.tiles_m * k.tiles_n;
 }
 
-extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
+// argument checks + kernel arguments of one row segment
+static int gemm_prepare(GemmKArgs& k, const drag_gemm_args* a) {
   DRAG_CHECK(a != nullptr, "drag_gemm_bf16: null args");
   DRAG_CHECK(a->A && a->W && a->C, "drag_gemm_bf16: null operand pointer");
   DRAG_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "drag_gemm_bf16: M, N, K must be positive");
@@ -888,9 +960,8 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   DRAG_CHECK(!(a->gate && !a->resid), "drag_gemm_bf16: gate needs resid");
   DRAG_CHECK(a->act == DRAG_ACT_NONE || a->act == DRAG_ACT_GELU_TANH || a->act == DRAG_ACT_SILU || a->act == DRAG_ACT_QUICK_GELU,
              "drag_gemm_bf16: fused activation must be none, gelu-tanh, silu or quick-gelu (erf GELU: use drag_act_bf16)");
-  GemmKArgs k;
-  const int grid = fill_common(k, a->A, a->W, a->C, a->bias, a->gate, a->resid, a->M, a->N, a->K, a->ldc,
-                               a->c_rows_per_batch, a->c_batch_stride, a->ldg, a->act, a->act_n0, a->out_f32);
+  fill_common(k, a->A, a->W, a->C, a->bias, a->gate, a->resid, a->M, a->N, a->K, a->ldc, a->c_rows_per_batch, a->c_batch_stride, a->ldg,
+              a->act, a->act_n0, a->out_f32);
   k.am.rpb = a->a_rows_per_batch > 0 ? a->a_rows_per_batch : a->M;
   k.am.bs = a->a_batch_stride; k.am.ld = a->lda;
   k.cv = ConvMap{1, 1, 1, 1, 64, 1, 0, 0};
@@ -908,36 +979,122 @@ extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
     k.wide = k.wide && a->ldc2 % 8 == 0 && ((uintptr_t)a->C2 & 15) == 0;
     DRAG_CHECK(k.wide || a->ldc2 % 4 == 0, "drag_gemm_bf16: ldc2 % 4 required");
   }
-  // "gemm_kernel" (drag_set_option, measurement only): 0 = policy, 1 = t128, 2 = t256, 10*MI + ST = gemm_bf16_deep<MI, ST>
+  return 0;
+}
+
+// kernel choice for M rows (the sum over the segments of a pair): 2 = t256, 0 = t128, else a gemm_bf16_deep code.
+// "gemm_kernel" (drag_set_option, measurement only): 0 = policy, 1 = t128, 2 = t256, 10*MI + ST = gemm_bf16_deep<MI, ST>
+static int gemm_choice(long long M1, long long M2, int N, int K, long long* cost_out = nullptr) {
   const int force = drag_opt(DRAG_OPT_GEMM_KERNEL);
-  int deep = force >= 10 ? force : 0;
-  const bool t256 = force == 2 ? (a->N >= 256 && a->K >= 256) : (force == 0 && use_t256(a->M, a->N, a->K));
-  if (force == 0 && !t256) deep = deep_policy(a->M, a->N, a->K);
-  if (t256) {
-    k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
-    hipLaunchKernelGGL(gemm_bf16_t256<0>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
-  } else if (deep) {
+  long long cost = 0;
+  int choice;
+  if (force >= 10) choice = force;
+  else if (force == 2) choice = (N >= 256 && K >= 256) ? 2 : 0;
+  else if (force == 1) choice = 0;
+  else if (use_t256(M1, M2, N, K)) {
+    choice = 2;
+    cost = ((tile_rows(M1, M2, 256) * ((N + 255) / 256) + 255) / 256) * (256 + 256);
+  } else choice = deep_policy(M1, M2, N, K, &cost);
+  if (cost_out) *cost_out = cost;
+  return choice;
+}
+
+// one launch over the rows of `a` and, when b != nullptr, of a second segment with the same N, K and epilogue form
+static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* stream) {
+  GemmKArgs k, k2;
+  if (int rc = gemm_prepare(k, a)) return rc;
+  if (b != nullptr) {
+    if (int rc = gemm_prepare(k2, b)) return rc;
+    k.A2 = k2.A; k.W2 = k2.W; k.Cs2 = k2.C; k.bias2 = k2.bias; k.gate2 = k2.gate; k.resid2 = k2.resid;
+    k.M2 = k2.M; k.ldg2 = k2.ldg; k.wide2 = k2.wide; k.am2 = k2.am; k.cm2 = k2.cm;
+  }
+  const int choice = gemm_choice(a->M, b ? b->M : 0, a->N, a->K);
+  const hipStream_t st_ = (hipStream_t)stream;
+  auto tiles_of = [&](int tm) {            // each segment starts on a tile boundary
+    k.tiles_m = (a->M + tm - 1) / tm;
+    if (b) { k.seg_tiles_m = k.tiles_m; k.tiles_m += (b->M + tm - 1) / tm; }
+  };
+  if (choice == 2) {
+    tiles_of(256); k.tiles_n = (a->N + 255) / 256;
+    const dim3 g(t256_grid(k.tiles_m * k.tiles_n));
+    if (b) hipLaunchKernelGGL(gemm_bf16_t256_pair, g, dim3(512), 0, st_, k);
+    else hipLaunchKernelGGL((gemm_bf16_t256<0>), g, dim3(512), 0, st_, k);
+  } else if (choice) {
+    const int deep = choice;
     const int ni = deep >= 100 ? 6 : 4, mi = (deep % 100) / 10, st = deep % 10;
     DRAG_CHECK((mi >= 1 && mi <= 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2, 10*{1,2,4} + {2,3,4} or 100 + 10*{1..4} + 3");
-    k.tiles_m = (a->M + 32 * mi - 1) / (32 * mi); k.tiles_n = (a->N + 32 * ni - 1) / (32 * ni);
+    tiles_of(32 * mi); k.tiles_n = (a->N + 32 * ni - 1) / (32 * ni);
     const dim3 g(k.tiles_m * k.tiles_n);
-    const hipStream_t st_ = (hipStream_t)stream;
 #define DRAG_DEEP(MI_, ST_) case 10 * MI_ + ST_: hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_>), g, dim3(256), 0, st_, k); break
-#define DRAG_DEEP6(MI_) case 100 + 10 * MI_ + 3: hipLaunchKernelGGL((gemm_bf16_deep<MI_, 3, 6>), g, dim3(256), 0, st_, k); break
+#define DRAG_DEEP6(MI_, ST_) case 100 + 10 * MI_ + ST_: hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_, 6>), g, dim3(256), 0, st_, k); break
     switch (deep) {
       DRAG_DEEP(4, 2); DRAG_DEEP(4, 3);
+      DRAG_DEEP(3, 2); DRAG_DEEP(3, 3);
       DRAG_DEEP(2, 2); DRAG_DEEP(2, 3); DRAG_DEEP(2, 4);
       DRAG_DEEP(1, 3); DRAG_DEEP(1, 4);
-      DRAG_DEEP6(1); DRAG_DEEP6(2); DRAG_DEEP6(3); DRAG_DEEP6(4);
-      default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel names a gemm_bf16_deep<MI, ST, NI> that is not built (42 43 22 23 24 13 14 113 123 133 143)");
+      DRAG_DEEP6(1, 3); DRAG_DEEP6(2, 3); DRAG_DEEP6(3, 3); DRAG_DEEP6(4, 3);
+      DRAG_DEEP6(3, 2); DRAG_DEEP6(4, 2); DRAG_DEEP6(3, 4); DRAG_DEEP6(4, 4);
+      default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel names a gemm_bf16_deep<MI, ST, NI> that is not built (42 43 32 33 22 23 24 13 14 113 123 133 143)");
     }
 #undef DRAG_DEEP
 #undef DRAG_DEEP6
   } else {
-    hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    tiles_of(BM); k.tiles_n = (a->N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(k.tiles_m * k.tiles_n), dim3(256), 0, st_, k);
   }
   DRAG_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) { return gemm_launch(a, nullptr, stream); }
+
+// which kernel a launch over M1 (+ M2: a merged pair) rows takes: 2 = the persistent 256x256 kernel, 0 = t128, else
+// 100 * (192-column tiles) + 10 * MI + ST of gemm_bf16_deep<MI, ST, NI> — for callers that account launches per kernel
+extern "C" int drag_gemm_bf16_choice(int M1, int M2, int N, int K) { return gemm_choice(M1, M2 > 0 ? M2 : 0, N, K); }
+// the policy's cost of that launch: tile rounds on the busiest CU x (tile rows + tile columns) — proportional to the bytes the busiest CU
+// pulls through its L2 -> LDS path per K-step, which is what bounds a launch of few tiles.  0 under a forced "gemm_kernel".
+extern "C" int64_t drag_gemm_bf16_cost(int M1, int M2, int N, int K) {
+  long long c = 0;
+  gemm_choice(M1, M2 > 0 ? M2 : 0, N, K, &c);
+  return (int64_t)c;
+}
+
+// Two Linears with their own operands (A, W, bias, gate, residual, output, row maps) but the same N, K, activation and output type as
+// ONE launch: the second problem's rows follow the first one's in the tile walk.  Every output element is computed exactly as by
+// drag_gemm_bf16 on its own problem (same MFMA chain, same epilogue), so pair(a, b) == gemm(a); gemm(b) bit for bit; what changes is
+// the occupancy of launches that are small alone (a double block's 512 text + 1024 image rows at batch 1: BASELINE configs[1]).
+// Merged when the cost model above (tile rounds on the busiest CU x (tile rows + tile columns), each launch under the tiling the policy
+// gives it) puts the one launch below the two, or level with them while at least one of the two is too small for the persistent kernel
+// (a launch of about one round of workgroups pays its ring fill and epilogue in the open; merged, they overlap other workgroups).
+// At batch 1 (1024 image + 512 text rows; TFLOP/s over both problems, isolated, scripts/bench_gemm_pair.py): the q|k|v pair
+// 878 -> 1282, the attention output pair 559 -> 806, the MLP down-projection pair 667 -> 906; NOT the MLP up-projection (N = 12288:
+// one round of 256x256 tiles + 1.5 of t128 alone, 4.5 rounds of t128 merged: 1084 -> 987) and not launches that each fill the chip
+// alone (the headline's 4096 text + 32768 image rows: the merged launch idles what the smaller one idles alone).
+// "gemm_pair": 0 = this rule, 1 = never merge, 2 = always merge.
+extern "C" int drag_gemm_bf16_pair_merges(int M1, int M2, int N, int K) {
+  const int opt = drag_opt(DRAG_OPT_GEMM_PAIR);
+  if (opt == 1) return 0;
+  if (opt == 2) return 1;
+  long long c1 = 0, c2 = 0, cm = 0;
+  const int k1 = gemm_choice(M1, 0, N, K, &c1);
+  const int k2 = gemm_choice(M2, 0, N, K, &c2);
+  gemm_choice(M1, M2, N, K, &cm);
+  if (cm <= 0) return 0;                           // a forced kernel ("gemm_kernel"): no model
+  return cm < c1 + c2 || (cm == c1 + c2 && (k1 != 2 || k2 != 2));
+}
+
+extern "C" int drag_gemm_bf16_pair(const drag_gemm_args* a, const drag_gemm_args* b, void* stream) {
+  DRAG_CHECK(a != nullptr && b != nullptr, "drag_gemm_bf16_pair: null args");
+  DRAG_CHECK(a->N == b->N && a->K == b->K, "drag_gemm_bf16_pair: the two problems must share N and K");
+  DRAG_CHECK(a->act == b->act && a->act_n0 == b->act_n0 && a->out_f32 == b->out_f32, "drag_gemm_bf16_pair: the two problems must share activation and output type");
+  DRAG_CHECK(a->C2 == nullptr && b->C2 == nullptr, "drag_gemm_bf16_pair: no two-destination outputs");
+  DRAG_CHECK((a->gate != nullptr) == (b->gate != nullptr) && (a->resid != nullptr) == (b->resid != nullptr) && (a->bias != nullptr) == (b->bias != nullptr),
+             "drag_gemm_bf16_pair: the two problems must have the same epilogue operands");
+  if (!drag_gemm_bf16_pair_merges(a->M, b->M, a->N, a->K)) {
+    if (int rc = gemm_launch(a, nullptr, stream)) return rc;
+    return gemm_launch(b, nullptr, stream);
+  }
+  return gemm_launch(a, b, stream);
 }
 
 extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
@@ -958,7 +1115,7 @@ extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
   k.am.rpb = (int)M; k.am.bs = 0; k.am.ld = a->Cin;
   k.cv = ConvMap{a->Ho, a->Wo, a->Hp, a->Wp, a->Cin, a->stride, a->oy, a->ox};
   DRAG_CHECK(((long long)(BM * a->stride + 3 * a->Wp * 2) * a->Cin) * 2 < (1ll << 30), "drag_conv3x3_bf16: tile span too large");
-  if (use_t256(M, a->Cout, 9 * a->Cin)) {
+  if (use_t256(M, 0, a->Cout, 9 * a->Cin)) {
     k.tiles_m = (int)((M + 255) / 256); k.tiles_n = (a->Cout + 255) / 256;
     hipLaunchKernelGGL(gemm_bf16_t256<1>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
   } else

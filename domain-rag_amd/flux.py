@@ -27,9 +27,12 @@ from . import ops
 from .flux_params import FluxConfig
 
 _SEPARATE_QPREP = os.environ.get("DRAG_QPREP_SEPARATE", "") not in ("", "0")     # measurement switches, read once
-# single blocks: to_q|k|v + proj_mlp as ONE two-destination launch (54.8 tile rounds instead of 24 + 32).  Measured same-box A/B,
-# two rounds: fused 0.4440 / 0.4435 vs separate 0.4468 / 0.4454 images/s -> the saved partial round does not pay; off by default.
-_FUSED_QKV_MLP = os.environ.get("DRAG_QKV_MLP_FUSED", "") not in ("", "0")
+# single blocks: to_q|k|v + proj_mlp as ONE two-destination launch.  At the headline's 42 696 rows it saves a partial tile round
+# (54.8 instead of 24 + 32) and measured nothing (same-box A/B, two rounds: fused 0.4440 / 0.4435 vs separate 0.4468 / 0.4454 images/s);
+# at BASELINE configs[1]'s 1536 rows the fused launch is two exact rounds of 256x256 tiles (1400 TFLOP/s) where the separate ones are
+# one round + 4.5 rounds of small tiles (1132 / 800-1000).  So the choice follows the library's own cost model per launch shape
+# (ops.gemm_cost: fused when it is >= 10 % cheaper); DRAG_QKV_MLP_FUSED=1 / =0 force it on / off.
+_FUSED_QKV_MLP = {"": None, "0": False}.get(os.environ.get("DRAG_QKV_MLP_FUSED", ""), True)
 
 
 def rope_tables(ids: torch.Tensor, axes_dims=(16, 56, 56), theta: float = 10000.0):
@@ -228,7 +231,8 @@ class FluxTransformerHIP:
         nrm_txt = nrm.view(-1)[Mi * D: (Mi + Mt) * D]
         qkv_img = qkv.view(-1)[St * 3 * D:]
         attn_img = attn.view(-1)[St * D:]
-        hid = catb.view(-1)                   # MLP hidden scratch for double blocks
+        hid = catb.view(-1)                   # MLP hidden scratch for double blocks: image rows, then text rows
+        hid_txt = hid[Mi * F:]
 
         for i, blk in enumerate(self.double):
             mo, cmo = self.mod_off[(i, "norm1")], self.mod_off[(i, "norm1_context")]
@@ -237,10 +241,11 @@ class FluxTransformerHIP:
                           x_batch_stride=S * D, ld_mod=LM)
             ops.layernorm(x, nrm_txt, Mt, D, scale=modv[cmo + D:], shift=modv[cmo:], ldx=D, rows_per_batch=St,
                           x_batch_stride=S * D, ld_mod=LM)
-            ops.gemm(nrm_img, blk["wqkv"], out=qkv_img, bias=blk["bqkv"], M=Mi, lda=D, c_rows_per_batch=Si,
-                     c_batch_stride=S * 3 * D, ldc=3 * D)
-            ops.gemm(nrm_txt, blk["cwqkv"], out=qkv, bias=blk["cbqkv"], M=Mt, lda=D, c_rows_per_batch=St,
-                     c_batch_stride=S * 3 * D, ldc=3 * D)
+            # the image-stream and text-stream Linears of a pair share N and K: one launch when they are small alone (ops.gemm_pair)
+            ops.gemm_pair(dict(a=nrm_img, w=blk["wqkv"], out=qkv_img, bias=blk["bqkv"], M=Mi, lda=D, c_rows_per_batch=Si,
+                               c_batch_stride=S * 3 * D, ldc=3 * D),
+                          dict(a=nrm_txt, w=blk["cwqkv"], out=qkv, bias=blk["cbqkv"], M=Mt, lda=D, c_rows_per_batch=St,
+                               c_batch_stride=S * 3 * D, ldc=3 * D))
             if _SEPARATE_QPREP:     # A/B switch: the round-1 route (q prepared by the pass, plain attention)
                 ops.qk_norm_rope_vt(qkv, vt, blk["cnq"], blk["cnk"], blk["nq"], blk["nk"], cos, sin, B, S, H, 3 * D, St)
                 ops.attention(qkv, qkv.view(-1)[D:], vt, attn, B, S, H, 3 * D, S * 3 * D, D, S * D, scale)
@@ -249,30 +254,32 @@ class FluxTransformerHIP:
                 ops.k_norm_rope_vt(qkv, vt, blk["cnk"], blk["nk"], cos, sin, B, S, H, 3 * D, St)
                 ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, attn, B, S, H, 3 * D, S * 3 * D, D, S * D, scale,
                                     blk["cnq"], blk["nq"], cos, sin, St)
-            ops.gemm(attn_img, blk["wo"], out=x_img, bias=blk["bo"], M=Mi, a_rows_per_batch=Si, a_batch_stride=S * D,
-                     lda=D, c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D, gate=modv[mo + 2 * D:], resid=x_img, ldg=LM)
-            ops.gemm(attn, blk["cwo"], out=x, bias=blk["cbo"], M=Mt, a_rows_per_batch=St, a_batch_stride=S * D,
-                     lda=D, c_rows_per_batch=St, c_batch_stride=S * D, ldc=D, gate=modv[cmo + 2 * D:], resid=x, ldg=LM)
-            # MLPs
+            ops.gemm_pair(dict(a=attn_img, w=blk["wo"], out=x_img, bias=blk["bo"], M=Mi, a_rows_per_batch=Si, a_batch_stride=S * D,
+                               lda=D, c_rows_per_batch=Si, c_batch_stride=S * D, ldc=D, gate=modv[mo + 2 * D:], resid=x_img, ldg=LM),
+                          dict(a=attn, w=blk["cwo"], out=x, bias=blk["cbo"], M=Mt, a_rows_per_batch=St, a_batch_stride=S * D,
+                               lda=D, c_rows_per_batch=St, c_batch_stride=S * D, ldc=D, gate=modv[cmo + 2 * D:], resid=x, ldg=LM))
+            # MLPs (the two streams are independent: both LayerNorms, both up-projections, both down-projections)
             ops.layernorm(x_img, nrm_img, Mi, D, scale=modv[mo + 4 * D:], shift=modv[mo + 3 * D:], ldx=D,
                           rows_per_batch=Si, x_batch_stride=S * D, ld_mod=LM)
-            ops.gemm(nrm_img, blk["w1"], out=hid, bias=blk["b1"], act=ops.ACT_GELU_TANH, M=Mi, lda=D, ldc=F)
-            ops.gemm(hid, blk["w2"], out=x_img, bias=blk["b2"], M=Mi, lda=F, c_rows_per_batch=Si,
-                     c_batch_stride=S * D, ldc=D, gate=modv[mo + 5 * D:], resid=x_img, ldg=LM)
             ops.layernorm(x, nrm_txt, Mt, D, scale=modv[cmo + 4 * D:], shift=modv[cmo + 3 * D:], ldx=D,
                           rows_per_batch=St, x_batch_stride=S * D, ld_mod=LM)
-            ops.gemm(nrm_txt, blk["cw1"], out=hid, bias=blk["cb1"], act=ops.ACT_GELU_TANH, M=Mt, lda=D, ldc=F)
-            ops.gemm(hid, blk["cw2"], out=x, bias=blk["cb2"], M=Mt, lda=F, c_rows_per_batch=St,
-                     c_batch_stride=S * D, ldc=D, gate=modv[cmo + 5 * D:], resid=x, ldg=LM)
+            ops.gemm_pair(dict(a=nrm_img, w=blk["w1"], out=hid, bias=blk["b1"], act=ops.ACT_GELU_TANH, M=Mi, lda=D, ldc=F),
+                          dict(a=nrm_txt, w=blk["cw1"], out=hid_txt, bias=blk["cb1"], act=ops.ACT_GELU_TANH, M=Mt, lda=D, ldc=F))
+            ops.gemm_pair(dict(a=hid, w=blk["w2"], out=x_img, bias=blk["b2"], M=Mi, lda=F, c_rows_per_batch=Si,
+                               c_batch_stride=S * D, ldc=D, gate=modv[mo + 5 * D:], resid=x_img, ldg=LM),
+                          dict(a=hid_txt, w=blk["cw2"], out=x, bias=blk["cb2"], M=Mt, lda=F, c_rows_per_batch=St,
+                               c_batch_stride=S * D, ldc=D, gate=modv[cmo + 5 * D:], resid=x, ldg=LM))
             if taps is not None:
                 taps[f"double.{i}"] = x.clone()
 
         cat_mlp = catb.view(-1)[D:]
+        fused_qkv_mlp = (3 * D) % 256 == 0 and (_FUSED_QKV_MLP if _FUSED_QKV_MLP is not None else
+                                                ops.gemm_cost(M, 3 * D + F, D) * 10 <= (ops.gemm_cost(M, 3 * D, D) + ops.gemm_cost(M, F, D)) * 9)
         for i, blk in enumerate(self.single):
             mo = self.mod_off[("s", i)]      # shift, scale, gate
             ops.layernorm(x, nrm, M, D, scale=modv[mo + D:], shift=modv[mo:], ldx=D, ld_mod=LM, rows_per_batch=S,
                           x_batch_stride=S * D)
-            if (3 * D) % 256 == 0 and _FUSED_QKV_MLP:
+            if fused_qkv_mlp:
                 ops.gemm(nrm, blk["wqkvm"], out=qkv, bias=blk["bqkvm"], act=ops.ACT_GELU_TANH, act_n0=3 * D, M=M, lda=D, ldc=3 * D,
                          out2=cat_mlp, ldc2=D + F, n_split=3 * D)
             else:       # (test-sized widths whose q|k|v block does not end on a tile boundary)

@@ -38,39 +38,21 @@ class GemmRecorder:
 
     @staticmethod
     def kernel_of(shape, conv=False):
-        """the dispatch rule of drag_gemm_bf16 / drag_conv3x3_bf16 (csrc/gemm_bf16.hip: use_t256, deep_policy)"""
+        """the kernel drag_gemm_bf16 / drag_gemm_bf16_pair / drag_conv3x3_bf16 dispatch this launch to (``drag_gemm_bf16_choice``:
+        the library's own tile policy); ``conv`` = ("pair", M1, M2) for a merged pair launch"""
         if conv == "f32":
             return "conv2d_f32_kernel"
         M, N, K = shape
-        big = False
-        if N >= 256 and K >= 256:
-            tiles = ((M + 255) // 256) * ((N + 255) // 256)
-            rounds = (tiles + 255) // 256
-            big = M >= 2048 or (M >= 1024 and tiles >= 128 and (tiles <= 256 or tiles * 10 >= rounds * 256 * 7))
-        if big:
-            return "gemm_bf16_t256" + ("<1>" if conv else "<0>")
-        if not conv:                                         # deep_policy
-            tn = (N + 127) // 128
-            if M <= 32 or ((M + 63) // 64) * tn < 64:
-                return "gemm_bf16_deep<1, 4>"
-            tiles128 = ((M + 127) // 128) * tn
-            if tiles128 <= 128:
-                pick, cost = "gemm_bf16_deep<2, 4>", ((((M + 63) // 64) * tn + 255) // 256) * 192
-            elif tiles128 <= 256:
-                pick, cost = "gemm_bf16_deep<2, 3>", ((((M + 63) // 64) * tn + 255) // 256) * 192
-            else:
-                pick, cost = None, ((tiles128 + 255) // 256) * 256
-            if N % 192 == 0 and M >= 256 and not os.environ.get("DRAG_GEMM_NO_192"):
-                for mi in (4, 3, 2, 1):
-                    tiles = ((M + 32 * mi - 1) // (32 * mi)) * (N // 192)
-                    if tiles > 256 or tiles * 100 < 256 * 94:
-                        continue
-                    if (32 * mi + 192) * 10 <= cost * 9 and (K >= 8192 or pick):
-                        return f"gemm_bf16_deep<{mi}, 3, 6>"
-                    break
-            if pick:
-                return pick
-        return "gemm_bf16_t128" + ("<1>" if conv else "<0>")
+        M1, M2 = (conv[1], conv[2]) if isinstance(conv, tuple) else (M, 0)
+        code = _lib.load().drag_gemm_bf16_choice(M1, M2, N, K)
+        if conv is True:                                     # the 3x3 convolutions take t256 or t128 only
+            return "gemm_bf16_t256<1>" if code == 2 else "gemm_bf16_t128<1>"
+        if code == 2:
+            return "gemm_bf16_t256_pair" if M2 > 0 else "gemm_bf16_t256<0>"
+        if code == 0:
+            return "gemm_bf16_t128<0>"
+        mi, st = (code % 100) // 10, code % 10
+        return f"gemm_bf16_deep<{mi}, {st}, 6>" if code >= 100 else f"gemm_bf16_deep<{mi}, {st}>"
 
     def by_kernel(self):
         """{kernel name: (launches, total_ms, flops)}"""
@@ -119,16 +101,9 @@ def _need(t: torch.Tensor, dtype, name: str):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
-def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, bias=None, act: int = ACT_NONE,
-         act_n0: int = 0, gate=None, resid=None, out_f32: bool = False, M: int | None = None,
-         a_rows_per_batch: int = 0, a_batch_stride: int = 0, lda: int | None = None,
-         c_rows_per_batch: int = 0, c_batch_stride: int = 0, ldc: int | None = None, ldg: int = 0,
-         out2: torch.Tensor | None = None, ldc2: int = 0, n_split: int = 0) -> torch.Tensor:
-    """out = epi(a @ w.T) (``out2``: output columns >= ``n_split`` are written there instead, as dense rows of ``ldc2``
-    elements).  ``a`` / ``out`` may be views into larger buffers: pass the logical row
-    count ``M`` and the batched-row addressing (rows_per_batch, batch_stride, ld) explicitly; by
-    default ``a`` is a dense [M, K] matrix and ``out`` a dense [M, N] one."""
-    lib = _lib.load()
+def _gemm_args(a, w, out, bias, act, act_n0, gate, resid, out_f32, M, a_rows_per_batch, a_batch_stride, lda, c_rows_per_batch,
+               c_batch_stride, ldc, ldg, out2, ldc2, n_split):
+    """(GemmArgs, out, (M, N, K)) of one Linear (argument meaning: ``gemm``)"""
     _need(a, torch.bfloat16, "gemm.a")
     _need(w, torch.bfloat16, "gemm.w")
     N, K = w.shape
@@ -158,17 +133,76 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, b
     if out2 is not None:        # columns >= n_split go to out2 (dense rows of ldc2 elements)
         _need(out2, torch.bfloat16, "gemm.out2")
         args.C2, args.ldc2, args.n_split = out2.data_ptr(), ldc2, n_split
-    if _recorder is not None:
-        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s_ev.record()
-        check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
-        e_ev.record()
-        _recorder.events.append((s_ev, e_ev, 2.0 * M * N * K))
-        _recorder.shapes.append((M, N, K))
-        _recorder.is_conv.append(False)
-        return out
-    check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16")
+    return args, out, (M, N, K)
+
+
+def _recorded(call, shape, kind=False):
+    """run one GEMM launch, bracketed by events when a recorder is installed"""
+    if _recorder is None:
+        call()
+        return
+    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_ev.record()
+    call()
+    e_ev.record()
+    M, N, K = shape
+    _recorder.events.append((s_ev, e_ev, 2.0 * M * N * K))
+    _recorder.shapes.append(shape)
+    _recorder.is_conv.append(kind)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, bias=None, act: int = ACT_NONE,
+         act_n0: int = 0, gate=None, resid=None, out_f32: bool = False, M: int | None = None,
+         a_rows_per_batch: int = 0, a_batch_stride: int = 0, lda: int | None = None,
+         c_rows_per_batch: int = 0, c_batch_stride: int = 0, ldc: int | None = None, ldg: int = 0,
+         out2: torch.Tensor | None = None, ldc2: int = 0, n_split: int = 0) -> torch.Tensor:
+    """out = epi(a @ w.T) (``out2``: output columns >= ``n_split`` are written there instead, as dense rows of ``ldc2``
+    elements).  ``a`` / ``out`` may be views into larger buffers: pass the logical row
+    count ``M`` and the batched-row addressing (rows_per_batch, batch_stride, ld) explicitly; by
+    default ``a`` is a dense [M, K] matrix and ``out`` a dense [M, N] one."""
+    lib = _lib.load()
+    args, out, shape = _gemm_args(a, w, out, bias, act, act_n0, gate, resid, out_f32, M, a_rows_per_batch, a_batch_stride, lda,
+                                  c_rows_per_batch, c_batch_stride, ldc, ldg, out2, ldc2, n_split)
+    _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16"), shape)
     return out
+
+
+def gemm_cost(M: int, N: int, K: int, M2: int = 0) -> int:
+    """the tile policy's cost of one launch (``drag_gemm_bf16_cost``: tile rounds on the busiest CU x (tile rows + columns)) —
+    comparable between launches of equal K; used to choose between one fused launch and two"""
+    return int(_lib.load().drag_gemm_bf16_cost(M, M2, N, K))
+
+
+def gemm_pair(first: dict, second: dict):
+    """Two Linears with their own operands and the same N, K, activation and output type (``drag_gemm_bf16_pair``): ``first`` /
+    ``second`` are the keyword arguments of ``gemm`` (``a``, ``w``, ``out`` included).  One launch unless both problems fill the chip
+    alone; bit-identical to ``gemm(**first); gemm(**second)`` either way.  A FluxTransformerBlock's image-stream / text-stream
+    pairs (to_q|k|v + add_q|k|v_proj, to_out + to_add_out, ff + ff_context)."""
+    lib = _lib.load()
+    packed = []
+    for kw in (first, second):
+        kw = dict(kw)
+        a, w, out = kw.pop("a"), kw.pop("w"), kw.pop("out", None)
+        d = dict(bias=None, act=ACT_NONE, act_n0=0, gate=None, resid=None, out_f32=False, M=None, a_rows_per_batch=0, a_batch_stride=0,
+                 lda=None, c_rows_per_batch=0, c_batch_stride=0, ldc=None, ldg=0)
+        unknown = set(kw) - set(d)
+        if unknown:
+            raise TypeError(f"gemm_pair: unexpected arguments {sorted(unknown)}")
+        d.update(kw)
+        packed.append(_gemm_args(a, w, out, d["bias"], d["act"], d["act_n0"], d["gate"], d["resid"], d["out_f32"], d["M"], d["a_rows_per_batch"],
+                                 d["a_batch_stride"], d["lda"], d["c_rows_per_batch"], d["c_batch_stride"], d["ldc"], d["ldg"], None, 0, 0))
+    (a1, o1, s1), (a2, o2, s2) = packed
+    if s1[1:] != s2[1:]:
+        raise ValueError(f"gemm_pair: the two problems must share N and K (got {s1} and {s2})")
+    if (a1.act, a1.act_n0, a1.out_f32) != (a2.act, a2.act_n0, a2.out_f32):
+        raise ValueError("gemm_pair: the two problems must share activation, act_n0 and output type")
+    if lib.drag_gemm_bf16_pair_merges(s1[0], s2[0], s1[1], s1[2]):
+        _recorded(lambda: check(lib.drag_gemm_bf16_pair(ctypes.byref(a1), ctypes.byref(a2), _stream()), "drag_gemm_bf16_pair"),
+                  (s1[0] + s2[0], s1[1], s1[2]), ("pair", s1[0], s2[0]))
+    else:       # two launches (what the library would issue itself), accounted one by one
+        _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(a1), _stream()), "drag_gemm_bf16"), s1)
+        _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(a2), _stream()), "drag_gemm_bf16"), s2)
+    return o1, o2
 
 
 def qk_norm_rope_vt(qkv: torch.Tensor, vt: torch.Tensor, wq_txt, wk_txt, wq_img, wk_img, rope_cos, rope_sin,

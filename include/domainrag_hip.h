@@ -30,9 +30,10 @@ const char* drag_last_error(void);
  *   experiment kernel for S >= 1024), "attn_persist" 0 | 1 | n >= 3 (persistent attention experiment: off, one workgroup per
  *   CU, n per XCD), "gemm_kernel", "gemm_group_m", "ln_generic", "topk_grid" (workgroups at most of the top-k scan, 0 = 512),
  *   "topk_depth" 0 | 3 (LDS-DMA ring depth of the scan), "topk_qt" 0 | 2 | 4 (query tiles per scan workgroup), "topk_select" 0 | 256 | 1024,
- *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima).
+ *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima), "gemm_pair" 0 | 1 | 2
+ *   (drag_gemm_bf16_pair: merge unless both problems fill the chip alone | never | always).
  * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
- * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE.  Returns 0, or -1 for an unknown name. */
+ * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_GEMM_PAIR.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 
 /* activation codes used by epilogues */
@@ -77,6 +78,22 @@ typedef struct drag_gemm_args {
   int32_t ldc2, n_split;
 } drag_gemm_args;
 int drag_gemm_bf16(const drag_gemm_args* args, void* stream);
+/* drag_gemm_bf16_pair — two Linears with their own operands but the same N, K, activation, output type and epilogue form as ONE
+ * launch (the second problem's rows follow the first one's in the tile walk).  Bit-identical to drag_gemm_bf16(a); drag_gemm_bf16(b):
+ * every output element keeps its MFMA chain and epilogue; what changes is the occupancy of launches that are small alone.  Replaces
+ * the text-stream / image-stream Linear pairs of a FluxTransformerBlock (to_q|k|v + add_q|k|v_proj, to_out + to_add_out, ff + ff_context)
+ * reached from outpainting_updown_sampling_redux.py:1246-1257 and batch_generate_flux_kshot.py:467-474.  No C2 destinations. */
+int drag_gemm_bf16_pair(const drag_gemm_args* a, const drag_gemm_args* b, void* stream);
+/* 1 when drag_gemm_bf16_pair runs these two problems as one launch, 0 when it issues them one after the other (both fill the chip
+ * alone; option "gemm_pair": 1 = never merge, 2 = always) — for callers that account launches */
+int drag_gemm_bf16_pair_merges(int M1, int M2, int N, int K);
+/* which kernel a launch over M1 rows (M2 > 0: a merged pair of M1 + M2 rows) takes under the tile policy: 2 = the persistent 256x256
+ * kernel, 0 = the 128x128 kernel, else 100 * (192-column tiles) + 10 * MI + ST of gemm_bf16_deep<MI, ST, NI>.  Every choice computes the
+ * same bits; the policy is a function of the launch shape only. */
+int drag_gemm_bf16_choice(int M1, int M2, int N, int K);
+/* the policy's cost model for that launch: (tile rounds on the busiest CU) x (tile rows + tile columns), i.e. proportional to what the
+ * busiest CU pulls through its L2 -> LDS path per K-step; comparable between launches of equal K.  0 under a forced "gemm_kernel". */
+int64_t drag_gemm_bf16_cost(int M1, int M2, int N, int K);
 
 /* ---------------------------------------------------------------------------------------
  * drag_conv3x3_bf16 — 3x3 convolution as an implicit GEMM on the same MFMA main loop.

@@ -12,7 +12,7 @@ def bench(fn, iters=20):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-VARIANTS = [("t128", 1), ("t256", 2)] + [(f"d{c}", c) for c in (42, 43, 22, 23, 24, 13, 14, 113, 123, 133, 143)] + [("policy", 0)]
+VARIANTS = [("t128", 1), ("t256", 2)] + [(f"d{c}", c) for c in (42, 43, 32, 33, 22, 23, 24, 13, 14, 113, 123, 133, 143, 132, 142, 134, 144)] + [("policy", 0)]
 SHAPES = [(8, 18432, 3072), (8, 9216, 3072), (8, 3072, 256), (64, 3072, 3072), (729, 4096, 1152), (1458, 4304, 1152), (1458, 1152, 4352),
           (512, 3072, 3072), (512, 9216, 3072), (512, 12288, 3072), (512, 3072, 12288),
           (1024, 3072, 3072), (1024, 9216, 3072), (1024, 12288, 3072), (1024, 3072, 12288),
@@ -20,7 +20,12 @@ SHAPES = [(8, 18432, 3072), (8, 9216, 3072), (8, 3072, 256), (64, 3072, 3072), (
 if os.environ.get("SHAPES"):
     SHAPES = [tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(",")]
 for (M, N, K) in SHAPES:
-    A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    NW = max(2, int(600e6 // (N * K * 2)) + 1) if os.environ.get("COLD") else 1      # COLD=1: a rotation of > 600 MB of weight matrices
+    A = torch.randn(M, K, device=dev).bfloat16(); Ws = [(torch.randn(N, K, device=dev) * 0.02).bfloat16() for _ in range(NW)]
+    W = Ws[0]; it = [0]
+    def nextw():
+        it[0] = (it[0] + 1) % NW
+        return Ws[it[0]]
     bias = torch.randn(N, device=dev).bfloat16()
     t = {k: [] for k, _ in VARIANTS}; t["hipblaslt"] = []
     outs = {}
@@ -28,12 +33,12 @@ for (M, N, K) in SHAPES:
         for name, code in VARIANTS:
             ops.set_option("gemm_kernel", code)
             C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-            run = lambda: ops.gemm(A, W, out=C, bias=bias)
+            run = lambda: ops.gemm(A, nextw(), out=C, bias=bias)
             if rep == 0:
-                bench(run, 3); outs[name] = C.clone()
-            t[name].append(bench(run))
+                it[0] = NW - 1; bench(run, NW if NW > 1 else 3); outs[name] = C.clone()
+            t[name].append(bench(run, max(20, 2 * NW)))
         if rep == 0: bench(lambda: torch.matmul(A, W.t()), 3)
-        t["hipblaslt"].append(bench(lambda: torch.matmul(A, W.t())))
+        t["hipblaslt"].append(bench(lambda: torch.matmul(A, nextw().t()), max(20, 2 * NW)))
     ops.set_option("gemm_kernel", 0)
     same = all(torch.equal(outs["t128"], o) for o in outs.values())
     fl = 2 * M * N * K / 1e9

@@ -69,3 +69,29 @@ def test_f32_stage_entry_points_validate_before_launch(built_lib):
     assert built_lib.drag_attention_small_f32(p, p, 1, 65, 2, 64, 384, 128, 0.125, None) != 0 and b"T <= 64" in built_lib.drag_last_error()
     assert built_lib.drag_layernorm_f32(p, p, p, p, 4, 2048, 2048, 2048, 1e-5, None) != 0 and b"D <= 1024" in built_lib.drag_last_error()
     assert built_lib.drag_lama_prepare_u8(p, p, p, 8, 8, 4, 8, None) != 0 and b"bad shape" in built_lib.drag_last_error()
+
+
+def test_gemm_tile_policy_is_a_function_of_the_launch_shape(built_lib):
+    """drag_gemm_bf16_choice / drag_gemm_bf16_pair_merges are host-only: the policy's decisions on the shapes DESIGN.md quotes, and
+    the property the batch-invariance tests rest on (the policy never looks at data, only at M, N, K)"""
+    c = built_lib.drag_gemm_bf16_choice
+    assert c(42696, 0, 9216, 3072) == 2 and c(42696, 0, 3072, 15360) == 2          # the headline's Linears: persistent 256x256
+    assert c(1536, 0, 3072, 15360) == 133                                           # one exact round of 96x192 tiles (configs[1])
+    assert c(1536, 0, 12288, 3072) == 2 and c(512, 0, 12288, 3072) == 143           # 288 256x256 tiles beat 1536 96x128 | one exact round of 128x192
+    assert c(512, 0, 3072, 3072) == 24 and c(1024, 0, 3072, 3072) == 123 and c(729, 0, 4096, 1152) == 23
+    assert c(1458, 0, 4304, 1152) == 0                                              # 408 128x128 tiles, two per CU: t128
+    assert c(8, 0, 18432, 3072) == 14                                               # AdaLN modulation: 32-row tiles
+    assert c(1024, 512, 9216, 3072) == 2                                            # merged q|k|v pair at batch 1: 216 tiles
+    assert c(1024, 512, 3072, 3072) == 143 and c(1024, 512, 3072, 12288) == 143     # (8 + 4) x 16 = 192 tiles of 128x192: one round
+    m = built_lib.drag_gemm_bf16_pair_merges
+    assert m(1024, 512, 9216, 3072) == 1 and m(1024, 512, 3072, 3072) == 1 and m(1024, 512, 3072, 12288) == 1
+    assert m(1024, 512, 12288, 3072) == 0                                           # one 256x256 round + one 128x192 round alone, two 256x256 rounds merged
+    assert m(32768, 4096, 9216, 3072) == 0 and m(42696, 4096, 3072, 12288) == 0     # each fills the chip alone
+    for name, v in (("gemm_pair", 1), ("gemm_pair", 2)):
+        assert built_lib.drag_set_option(name.encode(), v) == 0
+        assert m(1024, 512, 9216, 3072) == (0 if v == 1 else 1) and m(32768, 4096, 9216, 3072) == (0 if v == 1 else 1)
+    assert built_lib.drag_set_option(b"gemm_pair", 0) == 0
+    k = built_lib.drag_gemm_bf16_cost
+    # the single block's to_q|k|v + proj_mlp: fused at 1536 rows (two exact 256x256 rounds), not at the headline's 42 696 (55 vs 24 + 32 rounds)
+    assert k(1536, 0, 21504, 3072) * 10 <= (k(1536, 0, 9216, 3072) + k(1536, 0, 12288, 3072)) * 9
+    assert k(42696, 0, 21504, 3072) * 10 > (k(42696, 0, 9216, 3072) + k(42696, 0, 12288, 3072)) * 9

@@ -592,6 +592,65 @@ def test_gemm_kernels_are_bit_identical(gpu, M, N, K):
             assert torch.equal(x, y), (code, i)
 
 
+@pytest.mark.parametrize("M1,M2,N,K", [(1024, 512, 768, 256), (1000, 77, 520, 192), (300, 1300, 1536, 320), (40, 24, 384, 128), (2304, 1100, 1024, 256)])
+def test_gemm_pair_equals_two_gemms(gpu, M1, M2, N, K):
+    """round 3: drag_gemm_bf16_pair — a double block's image-stream and text-stream Linears (own A, W, bias, gate, residual, output
+    and row maps; same N, K, epilogue form) as ONE launch must give exactly the bits of the two launches, for every kernel the
+    policy can pick for the merged rows (t128, the persistent 256x256 kernel, gemm_bf16_deep of either tile width), with ragged
+    last tiles in BOTH segments, and must leave everything outside the written rows alone"""
+    from domain_rag_amd import ops
+    a1, a2 = _randn((M1, K), 1).to(gpu), _randn((M2, K), 2).to(gpu)
+    w1, w2 = _randn((N, K), 3, 0.05).to(gpu), _randn((N, K), 4, 0.05).to(gpu)
+    b1, b2 = _randn((N,), 5).to(gpu), _randn((N,), 6).to(gpu)
+    B = 2 if M1 % 2 == 0 and M2 % 2 == 0 else 1
+    g1, g2 = _randn((B, N + 8), 7).to(gpu), _randn((B, N + 8), 8).to(gpu)
+    r1, r2 = _randn((M1 + 3, N), 9).to(gpu), _randn((M2 + 3, N), 10).to(gpu)
+
+    def forms(pair):
+        outs = []
+        # plain + bias, dense
+        o1, o2 = torch.full((M1 + 3, N), 7.0, dtype=torch.bfloat16, device=gpu), torch.full((M2 + 3, N), 7.0, dtype=torch.bfloat16, device=gpu)
+        pair(dict(a=a1, w=w1, out=o1, bias=b1, M=M1, lda=K, ldc=N), dict(a=a2, w=w2, out=o2, bias=b2, M=M2, lda=K, ldc=N))
+        outs += [o1, o2]
+        # activation on the upper columns
+        o1, o2 = torch.empty((M1, N), dtype=torch.bfloat16, device=gpu), torch.empty((M2, N), dtype=torch.bfloat16, device=gpu)
+        pair(dict(a=a1, w=w1, out=o1, bias=b1, act=ops.ACT_GELU_TANH, act_n0=N // 8 * 4), dict(a=a2, w=w2, out=o2, bias=b2, act=ops.ACT_GELU_TANH, act_n0=N // 8 * 4))
+        outs += [o1, o2]
+        # gate + residual in place, batched rows, each stream with its own gate rows
+        o1, o2 = r1.clone(), r2.clone()
+        pair(dict(a=a1, w=w1, out=o1, bias=b1, M=M1, lda=K, ldc=N, c_rows_per_batch=M1 // B, c_batch_stride=(M1 // B) * N, gate=g1, resid=o1, ldg=N + 8),
+             dict(a=a2, w=w2, out=o2, bias=b2, M=M2, lda=K, ldc=N, c_rows_per_batch=M2 // B, c_batch_stride=(M2 // B) * N, gate=g2, resid=o2, ldg=N + 8))
+        outs += [o1, o2]
+        # float32 outputs, no bias
+        o1, o2 = torch.empty((M1, N), dtype=torch.float32, device=gpu), torch.empty((M2, N), dtype=torch.float32, device=gpu)
+        pair(dict(a=a1, w=w1, out=o1, out_f32=True), dict(a=a2, w=w2, out=o2, out_f32=True))
+        outs += [o1, o2]
+        return [o.cpu() for o in outs]
+
+    ref = forms(lambda f, s: (ops.gemm(**f), ops.gemm(**s)))
+    assert (ref[0][M1:] == 7.0).all() and (ref[1][M2:] == 7.0).all()
+    try:
+        ops.set_option("gemm_pair", 2)                     # always one launch
+        for code in (0, 1, 2, 23, 32, 14, 123):
+            if code == 123 and N % 192:
+                continue
+            ops.set_option("gemm_kernel", code)
+            got = forms(ops.gemm_pair)
+            for i, (x, y) in enumerate(zip(ref, got)):
+                assert torch.equal(x, y), (code, i)
+        ops.set_option("gemm_kernel", 0)
+        ops.set_option("gemm_pair", 1)                     # never merged: the library issues the two launches itself
+        got = forms(ops.gemm_pair)
+        assert all(torch.equal(x, y) for x, y in zip(ref, got))
+    finally:
+        ops.set_option("gemm_kernel", 0)
+        ops.set_option("gemm_pair", 0)
+    with pytest.raises(ValueError, match="share N and K"):
+        ops.gemm_pair(dict(a=a1, w=w1), dict(a=a2, w=w2[: N - 64]))
+    with pytest.raises(ValueError, match="activation"):
+        ops.gemm_pair(dict(a=a1, w=w1, act=ops.ACT_SILU), dict(a=a2, w=w2))
+
+
 @pytest.mark.parametrize("M", [300, 2500])
 def test_gemm_two_destinations_equals_two_gemms(gpu, M):
     """one launch over stacked weights writing columns < n_split to one buffer and the rest (with the fused activation, via
