@@ -489,15 +489,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmKArgs p) {
 // carry two: 660 TFLOP/s) and (1536, 12288, 3072) is 1152 of them; 96x192 tiles make the first exactly 256 workgroups (one per
 // CU, 44 % fewer bytes on the busiest CU) and 128x192 tiles make the second exactly 3 rounds of 256.  Same MFMA, same k order per
 // output element: the bits cannot tell (test_gemm_kernels_are_bit_identical), so the choice stays a function of the launch shape.
+// one ds_read_b128 the compiler does not see (no automatic s_waitcnt: the caller counts), N of them 2 KiB apart from BASE
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(bf16x8_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N, int BASE, int I = 0>
+__device__ __forceinline__ void lds_read_frags(bf16x8_t* f, unsigned addr) {
+  if constexpr (I < N) {
+    lds_read_b128<BASE + I * 2048>(f[I], addr);
+    lds_read_frags<N, BASE, I + 1>(f, addr);
+  }
+}
+
 template <int MI, int ST, int NI = 4>
-__global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
+// The ring is DYNAMIC shared memory and the kernel asks for two waves per SIMD: told the static LDS size of a one-workgroup-per-CU ring,
+// hipcc sees a lone wave per SIMD, takes its 512-register budget, parks the accumulators in AGPRs and shuttles the loop-carried fragment
+// set of the pipelined loop through ~300 v_accvgpr moves per K-step; inside 256 unified registers everything stays in arch VGPRs.
+__global__ __launch_bounds__(256, 2) void gemm_bf16_deep(GemmKArgs p) {
   constexpr int TBM = 32 * MI, TBN = 32 * NI;
   constexpr int A_BYTES = TBM * 128, W_BYTES = TBN * 128, STAGE = A_BYTES + W_BYTES;
   constexpr int CA = TBM / 32;                 // A chunks (8 rows, 1 KiB) per wave per stage
   constexpr int CW = TBN / 32;                 // W chunks per wave per stage
   constexpr int CH = CA + CW;                  // DMA instructions per wave per stage
   static_assert(ST >= 2 && ST <= 4 && ST * STAGE >= 4 * 2048 && ST * STAGE <= 160 * 1024 && (NI == 4 || NI == 6), "ring depth / tile");
-  __shared__ __attribute__((aligned(16))) char smem[ST * STAGE];
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // ST * STAGE bytes (deep_lds_bytes)
   const int w = wave_id();
   const int l = lane_id();
   const int wr = w >> 1, wc = w & 1;
@@ -547,41 +563,94 @@ __global__ __launch_bounds__(256) void gemm_bf16_deep(GemmKArgs p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // ---- main loop, software-pipelined ACROSS the barrier.  One workgroup per CU means one wave per SIMD, all four in the same phase:
+  // with "barrier | ds_read | MFMA" per K-step the LDS phase (72 KiB of fragment reads per K-step for a 96x192 tile = the MFMA time)
+  // and the MFMA phase never overlap — (1536, 3072, 15360) ran 167 us where its operand stream alone takes 96 us and its MFMAs 58
+  // (scripts/probe/probe_ingest.hip).  So the fragments live in two register sets (a lone wave per SIMD has 512 VGPRs): the k-half-1
+  // reads of K-step kt issue before its k-half-0 MFMAs, the barrier of K-step kt+1 sits BETWEEN the two MFMA halves, and the k-half-0
+  // reads of K-step kt+1 issue before the k-half-1 MFMAs of kt.  At that barrier every wave has finished reading buffer kt, so K-step
+  // kt+ST is staged into it: ST K-steps in flight instead of ST-1 from the same LDS.  Same MFMA order per accumulator: same bits.
   const int nk = p.K / BK;
 #pragma unroll
-  for (int s2 = 0; s2 < ST - 1; ++s2)
+  for (int s2 = 0; s2 < ST; ++s2)
     if (s2 < nk) stage(s2, s2);
-  int buf = 0, nbuf = ST - 1;                    // buffer of K-step kt / of K-step kt + ST - 1
-  for (int kt = 0; kt < nk; ++kt) {
-    // K-step kt landed; K-steps kt+1 .. min(kt+ST-2, nk-1) may stay in flight
-    const int younger = min(ST - 2, nk - 1 - kt);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+  auto wait_landed = [&](int younger) {      // the K-step awaited has `younger` stages behind it in this wave's (in-order) VMEM queue
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CH) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ... for every wave; and every wave is done reading buffer nbuf (K-step kt-1: its ds_reads were consumed by MFMAs).
-    // A bare s_barrier: __syncthreads() carries a release fence, i.e. s_waitcnt vmcnt(0), which would drain the ring.
+  };
+  // The fragment reads are inline asm and the waits that retire them are counted by hand: left to the compiler, the older register set
+  // is awaited with lgkmcnt(0) — which also drains the reads just issued for the other set, i.e. no overlap at all.  LDS returns in
+  // order, so lgkmcnt(MI + NI) after issuing one set's reads means the previous set has landed.
+  bf16x8_t xa0[MI], wb0[NI], xa1[MI], wb1[NI];
+  const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
+  const unsigned adA = lds0 + (unsigned)fa, adB = lds0 + (unsigned)(fb - A_BYTES);     // + buffer * STAGE + k-half slot
+  auto read_half = [&](int b, int ks, bf16x8_t* xa, bf16x8_t* wb) {
+    const unsigned so = (unsigned)(b * STAGE + ((p0 ^ (ks * 4)) << 4));
+    lds_read_frags<MI, 0>(xa, adA + so);
+    lds_read_frags<NI, A_BYTES>(wb, adB + so);
+  };
+  auto landed = [&](bf16x8_t* xa, bf16x8_t* wb) {      // after a wait: what was read into these registers may be used from here on
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(xa[i]));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(wb[i]));
+  };
+  wait_landed(min(ST - 1, nk - 1));
+  // A bare s_barrier: __syncthreads() carries a release fence, i.e. s_waitcnt vmcnt(0), which would drain the ring.
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_half(0, 0, xa0, wb0);
+  int buf = 0;
+#define DRAG_DEEP_MMA(XA, WB) _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) \
+    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[ni], XA[mi], acc[mi][ni], 0, 0, 0)
+  int kt = 0;
+  // steady state: K-steps kt+1 .. kt+ST-1 are issued and K-step kt+ST exists — one basic block per K-step, nothing conditional
+  for (; kt + ST < nk; ++kt) {
+    const int nb = buf + 1 == ST ? 0 : buf + 1;
+    read_half(buf, 1, xa1, wb1);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");      // k-half 0 of this K-step (read one MFMA half ago) landed
+    landed(xa0, wb0);
+    DRAG_DEEP_MMA(xa0, wb0);
+    __builtin_amdgcn_sched_barrier(0);                           // (the waits below must not rise above the MFMAs)
+    // K-step kt+1 landed for this wave (ST-2 younger stages stay in flight) and its own reads of buffer kt are complete ...
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((ST - 2) * CH) : "memory");
+    // ... for every wave
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + ST - 1 < nk) stage(nbuf, kt + ST - 1);
-    const char* sb = smem + buf * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int so = ((p0 ^ (ks * 4)) << 4);
-      bf16x8_t xa[MI], wb[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) xa[i] = *(const bf16x8_t*)(sb + fa + i * 2048 + so);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) wb[i] = *(const bf16x8_t*)(sb + fb + i * 2048 + so);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ni], xa[mi], acc[mi][ni], 0, 0, 0);
-    }
-    buf = buf + 1 == ST ? 0 : buf + 1;
-    nbuf = nbuf + 1 == ST ? 0 : nbuf + 1;
+    stage(buf, kt + ST);
+    read_half(nb, 0, xa0, wb0);
+    landed(xa1, wb1);                      // (volatile asm keeps its order: this half's MFMAs cannot rise above the reads just issued)
+    DRAG_DEEP_MMA(xa1, wb1);
+    buf = nb;
   }
+  // the last ST K-steps: nothing left to stage, the ring drains
+  for (; kt < nk; ++kt) {
+    const int nb = buf + 1 == ST ? 0 : buf + 1;
+    read_half(buf, 1, xa1, wb1);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");
+    landed(xa0, wb0);
+    DRAG_DEEP_MMA(xa0, wb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      wait_landed(min(ST - 2, nk - 2 - kt));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      read_half(nb, 0, xa0, wb0);
+      landed(xa1, wb1);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      landed(xa1, wb1);
+    }
+    DRAG_DEEP_MMA(xa1, wb1);
+    buf = nb;
+  }
+#undef DRAG_DEEP_MMA
   const GemmKArgs pd = dest_of(p, n0);
   if (p.wide) {
     __syncthreads();                              // the slabs alias the ring
@@ -843,27 +912,31 @@ static bool use_t256(long long M1, long long M2, int N, int K) {
   return tiles * 10 >= rounds * 256 * 7;              // last-round efficiency >= 0.7
 }
 
-// which gemm_bf16_deep<MI, ST, NI> (100 * (NI == 6) + 10 * MI + ST) a launch the 256x256 kernel does not take should use; 0 = the t128 kernel
-// Measured (scripts/bench_gemm_small_m.py, TFLOP/s, t128 -> pick): (512, 3072, 3072) 267 -> 416, (512, 3072, 12288) 310 -> 504,
-// (1024, 3072, 3072) 525 -> 625, (1024, 3072, 12288) 608 -> 715; with more than 256 128x128 tiles t128's two workgroups per CU win.
-// (8, 18432, 3072) — the AdaLN modulation Linears at batch 8, an HBM stream of the weight — 27 -> 46 (5.7 TB/s), (64, 3072, 3072) 38 -> 68.
-// Round 3, 192-column tiles (gemm_bf16_deep<MI, 3, 6>): such a launch is bound by the L2 -> LDS ingest of its busiest CU, i.e. by
-//   cost = (tile rounds on the busiest CU) x (tile rows + tile columns);
-// the cheapest (32 * MI) x 192 tiling that is ONE round on >= 75 % of the CUs replaces the 128-column choice when it cuts that cost by
-// >= 10 %.  The numbers that decide are taken with COLD weights (COLD=1 in scripts/bench_gemm_small_m.py / bench_gemm_pair.py: every
-// launch reads a matrix no recent launch touched, as inside a batch-1 forward where 24 GB of weights pass a 256 MB Infinity Cache):
-// TFLOP/s, 128-column choice -> 192: (1536, 3072, 15360) t128 677 -> 96x192 865 (128x192 753); (512, 12288, 3072) 580 -> 128x192 798;
-// the pair (1024 + 512, 3072, 12288) with gate + residual 622 -> 128x192 731; (1024, 3072, 12288) 64x128 503 -> 64x192 628.  Hot
-// (one matrix re-read from the Infinity Cache) the K = 3072 cases tip the other way ((512, 12288, 3072) 825 vs t128 879): a pipeline
-// never sees that state.  Ring depths 2 and 4 were measured too (codes 1x2 / 1x4): 4 changes nothing, 2 (two workgroups per CU) loses.
-// Round 3, 96 x 128 tiles (gemm_bf16_deep<3, 2>: 2-stage ring, two workgroups per CU like t128) where t128 has MORE than 256 tiles and the
-// same cost model prefers them — (1024 + 512, 3072, 3072) as a pair: 288 128-row tiles (32 CUs carry two) 696 -> 17 x 24 = 408 96-row
-// tiles 806; (1024 + 512, 3072, 12288) 835 -> 906; (512, 9216, 3072) 673 -> 820; (1536, 12288, 3072) 998 -> 1088; not (512, 12288, 3072): 384 tiles
-// in one paired round 917 vs 576 tiles in two 598; not (1458, 4304, 1152) 699 vs 497 (scripts/bench_gemm_pair.py, bench_gemm_small_m.py).
+// Which kernel a launch the 256x256 rule above does not take should use: 0 = t128, 2 = the 256x256 kernel after all, else
+// gemm_bf16_deep<MI, ST, NI> as 100 * (NI == 6) + 10 * MI + ST.  Every choice gives the same bits; the choice is a function of the shape.
+//
+// Model.  A launch of few tiles is bound by what its busiest CU pulls through the L2 -> LDS path:
+//   cost = (workgroups the busiest CU runs) x (tile rows + tile columns)          [per K-step; comparable at equal K]
+// and the measurements that calibrate it are taken with COLD weights (COLD=1 in scripts/bench_gemm_small_m.py / bench_gemm_pair.py:
+// every launch reads a matrix no recent launch touched) — inside a batch-1 forward 24 GB of weights pass a 256 MB Infinity Cache, so a
+// pipeline never sees the hot state in which an isolated benchmark re-reads one matrix (hot, K = 3072 launches tip towards t128's two
+// workgroups per CU: (512, 12288, 3072) t128 879 vs 128x192 825; cold 580 vs 839).
+//
+// Rules, in order (TFLOP/s cold, old choice -> new):
+//  * <= 32 rows or < 64 tiles of 64 rows: 32-row tiles, 4-stage ring — (8, 18432, 3072), the AdaLN modulation at batch 8: an HBM
+//    stream of the weight, 27 -> 46 hot (5.7 TB/s); (64, 3072, 3072) 38 -> 68.
+//  * fallback by tile count: <= 128 tiles of 128x128 -> 64x128 tiles, one workgroup per CU, 4-stage ring; <= 256 -> 64x128, two per CU,
+//    3-stage; more -> t128 (two workgroups per CU, 128x128) or 96x128 tiles with a 2-stage ring (two per CU as well) when the model
+//    prefers them: the pair (1024 + 512, 3072, 3072) 288 128-row tiles (32 CUs carry two) 696 -> 408 96-row tiles 806 hot;
+//    (512, 9216, 3072) 673 -> 820 hot; not (1458, 4304, 1152) 699 vs 497.  Past one round such workgroups come in rounds of 512 and a
+//    partly filled last round costs a full one (paired_rounds).
+//  * ONE round of one-workgroup-per-CU ring tiles on >= 75 % of the CUs — the cheapest (32 MI) x (128 | 192) tiling that is — replaces the
+//    fallback when it cuts the cost by >= 10 %: (1536, 3072, 15360) t128 686 -> 96x192 873 (128x192 821); (512, 12288, 3072) 580 -> 128x192
+//    839; the pair (1024 + 512, 3072, 12288) with gate + residual 622 -> 128x192 781; (1024, 3072, 12288) 64x128 511 -> 128x128 681
+//    (64x192 632); (729, 4096, 1152) 64x128 393 -> 96x128 487.  Ring depths 2 and 4 of the 192-column tiles were measured too (codes
+//    1x2 / 1x4): 4 changes nothing, 2 (two workgroups per CU) loses.
+//  * a partly filled second round of 256x256 tiles when even that is cheaper: (1536, 12288, 3072) 96x128 797 / t128 772 -> 908.
 // M2 > 0: the rows of a drag_gemm_bf16_pair launch (tile counts are per segment).  *cost_out: the chosen tiling's cost.
-// workgroups the busiest CU runs when a CU holds two at a time (t128, the 2-stage 96 x 128 kernel): past one round the workgroups come
-// in rounds of 512 and a partly filled last round costs a full one ((1536, 12288, 3072): 1152 128x128 tiles = 2.25 such rounds, 998
-// TFLOP/s; 1536 96x128 tiles = exactly 3, 1088)
 static long long paired_rounds(long long tiles) { return tiles <= 256 ? 1 : 2 * ((tiles + 511) / 512); }
 
 static int deep_policy(long long M1, long long M2, int N, int K, long long* cost_out) {
@@ -879,28 +952,30 @@ static int deep_policy(long long M1, long long M2, int N, int K, long long* cost
   if (tiles128 <= 128) { pick = 24; cost = ((tiles64 + 255) / 256) * (64 + 128); }        // <= 256 workgroups of 64 x 128: one per CU, 4-stage ring (96 KiB)
   else if (tiles128 <= 256) { pick = 23; cost = ((tiles64 + 255) / 256) * (64 + 128); }   // <= 512 workgroups: two per CU, 3-stage ring (72 KiB each)
   else { pick = 0; cost = paired_rounds(tiles128) * (128 + 128); }
-  static const bool no192 = env_flag("DRAG_GEMM_NO_192");
-  if (N % 192 == 0 && M >= 256 && !no192) {
-    // the cheapest (32 * MI) x 192 tiling that is ONE round on >= 75 % of the CUs
-    long long c192 = 0;
-    int mi192 = 0;
-    for (int mi = 4; mi >= 1; --mi) {
-      const long long tiles = tile_rows(M1, M2, 32 * mi) * (N / 192);
-      if (tiles > 256 || tiles < 192) continue;
-      if (mi192 == 0 || 32 * mi + 192 < c192) { mi192 = mi; c192 = 32 * mi + 192; }
-    }
-    if (mi192 && c192 * 10 <= cost * 9) {
-      if (cost_out) *cost_out = c192;
-      return 100 + 10 * mi192 + 3;
-    }
-  }
   static const bool no96 = env_flag("DRAG_GEMM_NO_96");
   if (pick == 0 && !no96) {
     const long long c96 = paired_rounds(tile_rows(M1, M2, 96) * tn) * (96 + 128);
     if (c96 < cost) { pick = 32; cost = c96; }
   }
-  // a partly filled second round of 256x256 tiles can still be the cheapest way through ((1536, 12288, 3072), weights cold: 908 TFLOP/s
-  // against 797 for 96x128 and 772 for 128x128 tiles)
+  // one round of ring tiles (ties: the larger MI at 128 columns)
+  static const bool no192 = env_flag("DRAG_GEMM_NO_192");
+  long long cbest = 0;
+  int best = 0;
+  if (M >= 256) {
+    for (int mi = 4; mi >= 1; --mi)
+      for (int ni = 4; ni <= 6; ni += 2) {
+        if (ni == 6 && (N % 192 != 0 || no192)) continue;
+        const long long tiles = tile_rows(M1, M2, 32 * mi) * ((N + 32 * ni - 1) / (32 * ni));
+        if (tiles > 256 || tiles < 192) continue;
+        const long long c = 32 * mi + 32 * ni;
+        if (best == 0 || c < cbest) { best = ni == 6 ? 100 + 10 * mi + 3 : (mi >= 3 ? 10 * mi + 3 : 10 * mi + 4); cbest = c; }
+      }
+  }
+  if (best && cbest * 10 <= cost * 9) {
+    if (cost_out) *cost_out = cbest;
+    return best;
+  }
+  // a partly filled second round of 256x256 tiles
   static const bool force_t128 = env_flag("DRAG_GEMM_T128");
   if (pick != 24 && pick != 23 && M >= 1024 && N >= 256 && K >= 256 && !force_t128) {
     const long long c256 = ((tile_rows(M1, M2, 256) * ((N + 255) / 256) + 255) / 256) * (256 + 256);
@@ -1025,8 +1100,17 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
     DRAG_CHECK((mi >= 1 && mi <= 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2, 10*{1,2,4} + {2,3,4} or 100 + 10*{1..4} + 3");
     tiles_of(32 * mi); k.tiles_n = (a->N + 32 * ni - 1) / (32 * ni);
     const dim3 g(k.tiles_m * k.tiles_n);
-#define DRAG_DEEP(MI_, ST_) case 10 * MI_ + ST_: hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_>), g, dim3(256), 0, st_, k); break
-#define DRAG_DEEP6(MI_, ST_) case 100 + 10 * MI_ + ST_: hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_, 6>), g, dim3(256), 0, st_, k); break
+#define DRAG_DEEP_LAUNCH(MI_, ST_, NI_)                                                                                    \
+  {                                                                                                                        \
+    constexpr int lds = ST_ * (32 * MI_ + 32 * NI_) * 128;                                                                 \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_deep<MI_, ST_, NI_>),     \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+    DRAG_CHECK(attr == hipSuccess, "drag_gemm_bf16: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");            \
+    hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_, NI_>), g, dim3(256), lds, st_, k);                                       \
+  }                                                                                                                        \
+  break
+#define DRAG_DEEP(MI_, ST_) case 10 * MI_ + ST_: DRAG_DEEP_LAUNCH(MI_, ST_, 4)
+#define DRAG_DEEP6(MI_, ST_) case 100 + 10 * MI_ + ST_: DRAG_DEEP_LAUNCH(MI_, ST_, 6)
     switch (deep) {
       DRAG_DEEP(4, 2); DRAG_DEEP(4, 3);
       DRAG_DEEP(3, 2); DRAG_DEEP(3, 3);
@@ -1038,6 +1122,7 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
     }
 #undef DRAG_DEEP
 #undef DRAG_DEEP6
+#undef DRAG_DEEP_LAUNCH
   } else {
     tiles_of(BM); k.tiles_n = (a->N + BN - 1) / BN;
     hipLaunchKernelGGL(gemm_bf16_t128<0>, dim3(k.tiles_m * k.tiles_n), dim3(256), 0, st_, k);
