@@ -146,6 +146,7 @@ constexpr int KT_BYTES = 64 * 256;   // K tile   [64 keys][128 d] bf16
 constexpr int VT_BYTES = 128 * 128;  // V^T tile [128 d][64 keys] bf16
 
 // SCHED 0: per KV tile, 16 {S(j+1) MFMA | exp of S(j)} steps, then the 16 P V MFMAs.
+// SCHED 2 (experiment, "attn_sched" 3): SCHED 1 with every V^T fragment read one step ahead of its MFMA.
 // SCHED 1: the P V MFMAs of key group s2 are issued as soon as that group's 16 probabilities are packed (from step 4 on, one
 //          per step next to the S MFMA), so the exp stream is spread over 28 MFMAs instead of 16 and only 4 P V MFMAs trail
 //          the loop.  Same arithmetic, same order per accumulator: bit-identical outputs.
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     u32x4_t pk[4];
     {
       bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[0] + KN));
+      bf16x8_t vpipe;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const bf16x8_t kcur = kf;
@@ -448,6 +450,10 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
         }
         bf16x8_t vfg;
         if (SCHED == 1 && g >= 4) vfg = read_v((g >> 2) - 1, g & 3, VB);
+        if (SCHED == 2) {      // the V^T fragment of step g was read in step g-1: a whole step (2 MFMAs + the softmax slice) covers its latency
+          vfg = vpipe;
+          if (g >= 3 && g < 15) vpipe = read_v(((g + 1) >> 2) - 1, (g + 1) & 3, VB);
+        }
         sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[g & 7], (g & 7) == 0 ? zero16 : sn[g >> 3], 0, 0, 0);
         // unconditional (no branches: a branch here splits the block and hipcc then hoists the whole softmax out of the
         // interleave): past the last tile the K rows clamp to S-1 and the V^T offsets fall outside the descriptor's range
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
         uint32_t wd = pack2bf(e0, e1);
         asm volatile("" : "+v"(wd), "+v"(ps));
         pk[g >> 2][g & 3] = wd;
-        if (SCHED == 1 && g >= 4)       // O^T[dt = g & 3] += V^T[.., keys of group (g >> 2) - 1] P^T: that group was packed >= 1 step ago
+        if (SCHED >= 1 && g >= 4)       // O^T[dt = g & 3] += V^T[.., keys of group (g >> 2) - 1] P^T: that group was packed >= 1 step ago
           oacc[g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfg, __builtin_bit_cast(bf16x8_t, pk[(g >> 2) - 1]), oacc[g & 3], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
     for (int s2 = 0; s2 < 4; ++s2) pf[s2] = __builtin_bit_cast(bf16x8_t, pk[s2]);
     // ---- O^T += V^T P^T ----
 #pragma unroll
-    for (int s2 = (SCHED == 1 ? 3 : 0); s2 < 4; ++s2)
+    for (int s2 = (SCHED >= 1 ? 3 : 0); s2 < 4; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8_t vf = read_v(s2, dt, VB);
@@ -962,7 +968,8 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
 #define DRAG_ATTN_LAUNCH(NW, SC, QP, PM) hipLaunchKernelGGL((attention_d128_kernel<NW, SC, QP, PM>), grid, dim3(NW * 64), 0, st, p)
 #define DRAG_ATTN_PICK(NW)                                                                           \
   do {                                                                                               \
-    if (sched == 2) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, true); else DRAG_ATTN_LAUNCH(NW, 1, false, true); }        \
+    if (sched == 3) { if (qprep) DRAG_ATTN_LAUNCH(NW, 2, true, true); else DRAG_ATTN_LAUNCH(NW, 2, false, true); }        \
+    else if (sched == 2) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, true); else DRAG_ATTN_LAUNCH(NW, 1, false, true); }   \
     else if (sched == 1) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, false); else DRAG_ATTN_LAUNCH(NW, 1, false, false); } \
     else { if (qprep) DRAG_ATTN_LAUNCH(NW, 0, true, false); else DRAG_ATTN_LAUNCH(NW, 0, false, false); }                 \
   } while (0)

@@ -227,7 +227,7 @@ def test_attention_schedules_are_bit_identical(gpu):
     outs = {}
     try:
         for sched, w4, tune, q64 in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 0, 3, 0), (1, 0, 2, 0), (0, 1, 0, 0), (1, 1, 0, 0),
-                                     (2, 1, 3, 0), (2, 0, 0, 1), (2, 0, 2, 1)):
+                                     (2, 1, 3, 0), (2, 0, 0, 1), (2, 0, 2, 1), (3, 0, 2, 0), (3, 1, 3, 0)):
             ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4); ops.set_option("attn_tune", tune)
             ops.set_option("attn_q64", q64)
             o = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
