@@ -32,13 +32,35 @@ for (M, N, K) in [(512, 3072, 12288), (1024, 3072, 3072), (8, 18432, 3072), (729
     ops.set_option("gemm_kernel", 1)
     ref = ops.gemm(A, W, bias=b, act=1).clone()
     n_bad = 0
-    for code in (0, 42, 43, 22, 23, 24, 13, 14, 113, 123, 133, 143):        # 1xx: the 192-column tiles of round 3
+    for code in (0, 42, 43, 32, 33, 22, 23, 24, 13, 14, 113, 123, 133, 143):        # 1xx: the 192-column tiles of round 3
         ops.set_option("gemm_kernel", code)
         for i in range(40):
             n_bad += int(not torch.equal(ops.gemm(A, W, bias=b, act=1), ref))
     ops.set_option("gemm_kernel", 0)
     bad += n_bad
-    print(f"ring gemm {M}x{N}x{K}: mismatches vs t128 over 12 kernels x 40 repeats: {n_bad}", flush=True)
+    print(f"ring gemm {M}x{N}x{K}: mismatches vs t128 over 14 kernels x 40 repeats: {n_bad}", flush=True)
+# round 3: two-segment launches (drag_gemm_bf16_pair) under the policy and forced kernels, gate + residual epilogue, 30 repeats each
+for (M1, M2, N, K) in [(1024, 512, 3072, 12288), (1024, 512, 9216, 3072), (1000, 77, 3072, 3072), (4096, 1241, 3072, 3072)]:
+    A1 = torch.randn(M1, K, device=dev, generator=g).bfloat16(); A2 = torch.randn(M2, K, device=dev, generator=g).bfloat16()
+    W1 = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16(); W2 = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16()
+    b1 = torch.randn(N, device=dev, generator=g).bfloat16(); b2_ = torch.randn(N, device=dev, generator=g).bfloat16()
+    g1 = torch.randn(1, N, device=dev, generator=g).bfloat16(); g2 = torch.randn(1, N, device=dev, generator=g).bfloat16()
+    R1 = torch.randn(M1, N, device=dev, generator=g).bfloat16(); R2 = torch.randn(M2, N, device=dev, generator=g).bfloat16()
+    def pair():
+        o1, o2 = torch.empty_like(R1), torch.empty_like(R2)
+        ops.gemm_pair(dict(a=A1, w=W1, out=o1, bias=b1, gate=g1, resid=R1, ldg=N), dict(a=A2, w=W2, out=o2, bias=b2_, gate=g2, resid=R2, ldg=N))
+        return o1, o2
+    ops.set_option("gemm_pair", 1)
+    ref = pair()
+    n_bad = 0
+    for code in (0, 1, 2, 32, 143, 133, 43):
+        ops.set_option("gemm_pair", 0 if code == 0 else 2); ops.set_option("gemm_kernel", code)
+        for i in range(30):
+            o = pair()
+            n_bad += int(not (torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1])))
+    ops.set_option("gemm_pair", 0); ops.set_option("gemm_kernel", 0)
+    bad += n_bad
+    print(f"gemm pair {M1}+{M2} x {N} x {K}: mismatches vs two launches over 7 kernels x 30 repeats: {n_bad}", flush=True)
 # round 3: the exact top-k (cross-group LDS-DMA ring, per-wave candidate regions, region-walking selection) — 60 repeats per shape
 for (N, Q, k) in [(118287, 16, 100), (118287, 64, 100), (118287, 1, 100), (300000, 40, 2048), (8191, 3, 17)]:
     corpus = torch.randn(N, 512, device=dev, generator=g); qs = torch.randn(Q, 512, device=dev, generator=g)
