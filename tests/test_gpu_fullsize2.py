@@ -208,3 +208,56 @@ def test_scan_only_entry_matches_oracle_scores_bitwise(gpu):
         ops.cosine_scores(torch.zeros(10, 512, device=gpu)[:, :256], torch.zeros(1, 256, device=gpu))
     with pytest.raises(RuntimeError):
         ops.cosine_scores(torch.zeros(10, 512, device=gpu), torch.zeros(65, 512, device=gpu))
+
+
+def test_configs1_shape_routes_are_bit_identical_and_match_oracle(gpu, monkeypatch):
+    """BASELINE configs[1]'s token counts (512 T5 tokens + 1024 latent tokens of a 512^2 image, batch 1, Flux-schnell shape: no guidance
+    embedding) at full width, 1 double + 1 single block.  At these sizes the library merges the double block's image / text Linear
+    pairs into single launches (drag_gemm_bf16_pair) and fuses the single block's q|k|v + proj_mlp (by its cost model): the merged,
+    fused route must give exactly the bits of the plain one (every Linear its own launch), row i of a batch of 4 the bits of image i
+    alone (where the policy takes other kernels again), and the result must sit within the 1.3 x bar of the bf16 oracle's own
+    distance from float32."""
+    from domain_rag_amd import flux as flux_mod, ops
+    from domain_rag_amd.flux import FluxTransformerHIP, latent_image_ids
+    from domain_rag_amd.flux_params import FluxConfig, init_params
+    from oracle import flux as oflux
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    cfg = FluxConfig(in_channels=64, num_layers=1, num_single_layers=1, guidance_embeds=False)
+    params = init_params(cfg, seed=41)
+    g = torch.Generator().manual_seed(42)
+    B, St, h, w = 4, 512, 32, 32
+    hidden = torch.randn(B, h * w, 64, generator=g).bfloat16()
+    enc = torch.randn(B, St, 4096, generator=g).bfloat16()
+    pooled = torch.randn(B, 768, generator=g).bfloat16()
+    t = torch.full((B,), 0.75)
+    img_ids, txt_ids = latent_image_ids(h, w), torch.zeros(St, 3)
+    model = FluxTransformerHIP(cfg, params, gpu)
+    lib = __import__("domain_rag_amd._lib", fromlist=["load"]).load()
+    assert lib.drag_gemm_bf16_pair_merges(h * w, St, 9216, 3072) == 1 and lib.drag_gemm_bf16_pair_merges(h * w, St, 3072, 12288) == 1
+
+    def run(n):
+        return model(hidden[:n].to(gpu), enc[:n].to(gpu), pooled[:n].to(gpu), t[:n], img_ids, txt_ids, None).clone()
+    merged = run(1)
+    try:
+        ops.set_option("gemm_pair", 1)
+        monkeypatch.setattr(flux_mod, "_FUSED_QKV_MLP", False)
+        plain = run(1)
+        monkeypatch.setattr(flux_mod, "_FUSED_QKV_MLP", True)
+        ops.set_option("gemm_pair", 2)
+        forced = run(1)
+    finally:
+        ops.set_option("gemm_pair", 0)
+        monkeypatch.setattr(flux_mod, "_FUSED_QKV_MLP", None)
+    assert torch.equal(merged, plain), "merged / fused route differs from one launch per Linear"
+    assert torch.equal(forced, plain), "always-merged, always-fused route differs"
+    out4 = run(B)
+    for i in range(B):
+        one = model(hidden[i:i + 1].to(gpu), enc[i:i + 1].to(gpu), pooled[i:i + 1].to(gpu), t[:1], img_ids, txt_ids, None)
+        assert torch.equal(one[0], out4[i]), f"image {i}: batch row differs from the single-image run"
+    ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    with torch.no_grad():
+        ref = oflux.flux_forward(params, ocfg, hidden[:1], enc[:1], pooled[:1], t[:1], img_ids, txt_ids, None)
+        ref32 = oflux.flux_forward({k: v.float() for k, v in params.items()}, ocfg, hidden[:1].float(), enc[:1].float(), pooled[:1].float(),
+                                   t[:1], img_ids, txt_ids, None, time_dtype=torch.bfloat16)
+    e, e_or = _rel(merged, ref32), _rel(ref, ref32)
+    assert e < _tol(e_or, 1e-2), _msg("configs[1] shape", e, e_or)
