@@ -1097,7 +1097,7 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
   } else if (choice) {
     const int deep = choice;
     const int ni = deep >= 100 ? 6 : 4, mi = (deep % 100) / 10, st = deep % 10;
-    DRAG_CHECK((mi >= 1 && mi <= 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2, 10*{1,2,4} + {2,3,4} or 100 + 10*{1..4} + 3");
+    DRAG_CHECK((mi >= 1 && mi <= 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2, 10 * MI + ST or 100 + 10 * MI + ST of a gemm_bf16_deep<MI, ST, NI> that is built");
     tiles_of(32 * mi); k.tiles_n = (a->N + 32 * ni - 1) / (32 * ni);
     const dim3 g(k.tiles_m * k.tiles_n);
 #define DRAG_DEEP_LAUNCH(MI_, ST_, NI_)                                                                                    \
@@ -1118,7 +1118,7 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
       DRAG_DEEP(1, 3); DRAG_DEEP(1, 4);
       DRAG_DEEP6(1, 3); DRAG_DEEP6(2, 3); DRAG_DEEP6(3, 3); DRAG_DEEP6(4, 3);
       DRAG_DEEP6(3, 2); DRAG_DEEP6(4, 2); DRAG_DEEP6(3, 4); DRAG_DEEP6(4, 4);
-      default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel names a gemm_bf16_deep<MI, ST, NI> that is not built (42 43 32 33 22 23 24 13 14 113 123 133 143)");
+      default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel names a gemm_bf16_deep<MI, ST, NI> that is not built (42 43 32 33 22 23 24 13 14 | 113 123 133 143 132 142 134 144)");
     }
 #undef DRAG_DEEP
 #undef DRAG_DEEP6
