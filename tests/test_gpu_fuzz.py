@@ -224,3 +224,66 @@ def test_topk_fuzz_with_ties_nonfinite_rows_and_every_measurement_option(gpu):
     finally:
         for n_ in names:
             ops.set_option(n_, 0)
+
+
+def test_gemm_pair_random_configs(gpu):
+    """round 3: seeded random two-segment launches (row counts from 1 to a few thousand per segment, batched row maps, every epilogue
+    form, the policy's kernel and forced ones) against the same two problems as separate launches: equal bits, nothing written
+    outside the rows"""
+    from domain_rag_amd import ops
+    rng = np.random.default_rng(4321)
+    g = torch.Generator().manual_seed(77)
+    codes = [0, 0, 1, 2, 14, 24, 23, 32, 33, 43, 113, 123, 133, 143]
+    try:
+        for case in range(36):
+            K = int(rng.choice([64, 128, 256, 320, 512, 1024]))
+            N = int(rng.choice([8, 72, 192, 256, 264, 384, 576, 768, 1032, 1536]))
+            M = [int(rng.choice([1, 7, 33, 77, 128, 255, 300, 512, 777, 1024, 1241, 2100])) for _ in range(2)]
+            Bt = [int(rng.choice([1, 1, 2, 3])) for _ in range(2)]              # batches per segment (rows per batch = M / B when it divides)
+            act = int(rng.choice([0, 0, 1, 2, 3]))
+            mode = str(rng.choice(["plain", "resid", "gate", "f32"]))
+            use_bias = bool(rng.random() < 0.7)
+            code = int(rng.choice(codes))
+            if code >= 100 and N % 192:
+                code = 0
+            segs = []
+            for sgi in range(2):
+                rows = M[sgi]
+                B = Bt[sgi] if rows % Bt[sgi] == 0 else 1
+                rpb, pad = rows // B, int(rng.integers(0, 9)) * 8
+                a = torch.randn(B, rpb + pad, K, generator=g).bfloat16().to(gpu)
+                w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(gpu)
+                bias = torch.randn(N, generator=g).bfloat16().to(gpu) if use_bias else None
+                x = torch.randn(B, rpb + pad, N + 8, generator=g).to(torch.float32 if mode == "f32" else torch.bfloat16).to(gpu)
+                gate = torch.randn(B, N + 16, generator=g).bfloat16().to(gpu) if mode == "gate" else None
+                kw = dict(a=a, w=w, bias=bias, M=rows, lda=K, a_rows_per_batch=rpb, a_batch_stride=(rpb + pad) * K,
+                          ldc=N + 8, c_rows_per_batch=rpb, c_batch_stride=(rpb + pad) * (N + 8), act=act, act_n0=(N // 8) * 4)
+                if mode == "f32":
+                    kw["out_f32"] = True
+                if mode in ("resid", "gate"):
+                    kw["resid"] = "self"
+                if mode == "gate":
+                    kw.update(gate=gate, ldg=N + 16)
+                segs.append((kw, x))
+
+            def call(fn):
+                outs, kws = [], []
+                for kw, x in segs:
+                    o = x.clone()
+                    k2 = dict(kw, out=o)
+                    if k2.get("resid") == "self":
+                        k2["resid"] = o
+                    outs.append(o); kws.append(k2)
+                fn(kws)
+                return [o.cpu() for o in outs]
+            ops.set_option("gemm_kernel", 0); ops.set_option("gemm_pair", 1)
+            ref = call(lambda kws: [ops.gemm(**{k: v for k, v in kw.items()}) for kw in kws])
+            ops.set_option("gemm_kernel", code); ops.set_option("gemm_pair", 2 if code or rng.random() < 0.5 else 0)
+            got = call(lambda kws: ops.gemm_pair(kws[0], kws[1]))
+            for sgi in range(2):
+                assert torch.equal(ref[sgi], got[sgi]), (case, sgi, M, N, K, code, mode, act)
+                x0 = segs[sgi][1].cpu()
+                rpb = segs[sgi][0]["a_rows_per_batch"]
+                assert torch.equal(got[sgi][:, rpb:], x0[:, rpb:]) and torch.equal(got[sgi][:, :, N:], x0[:, :, N:]), (case, "wrote outside its rows / columns")
+    finally:
+        ops.set_option("gemm_kernel", 0); ops.set_option("gemm_pair", 0)
