@@ -46,7 +46,11 @@ __device__ __forceinline__ bool tap_coord(int o, int k, int n_in, int stride, in
 // TM = tile edge in units of 64: 64x64 (one 32x32 accumulator per wave) or, for launches large enough to still fill the chip,
 // 128x128 (2x2 accumulators per wave: half the global / LDS bytes per flop, 4x the MFMA work per barrier).
 // Every instantiation adds the products of one output element in the same order (taps outer, channels ascending): same bits.
-template <int CT_K, int TM>
+// LIN: a 1x1, stride-1, unpadded convolution whose tiles are all interior and whose channel count is a multiple of the step (every
+// Linear of the float32 CLIP tower at batch sizes that are multiples of 64): no tap arithmetic and no per-load predicates — the general
+// form wraps each of its 8-16 global loads per step in an exec-mask branch (75 % matrix-pipe busy on (51200, 3072, 768)).  Same
+// products in the same order: same bits.
+template <int CT_K, int TM, bool LIN = false>
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
   constexpr int CT_LD = CT_K + 4, NV = CT_K / 16, TILE = 64 * TM;
   __shared__ __attribute__((aligned(16))) float As[2][TILE][CT_LD];
@@ -99,12 +103,18 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvK p) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = kc * CT_K + v * 16 + lk;
+        if constexpr (LIN) {
+          ra[u][v] = *(const f32x4_t*)(arow[u] + c);
+          rb[u][v] = *(const f32x4_t*)(wrow[u] + c);
+          continue;
+        }
         const bool c_ok = c < a.Cin;
         ra[u][v] = (a_ok[u] && c_ok) ? *(const f32x4_t*)(arow[u] + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         rb[u][v] = (n_ok[u] && c_ok) ? *(const f32x4_t*)(wrow[u] + (long long)tap * a.Cin + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
       }
   };
   auto advance = [&]() {
+    if constexpr (LIN) { ++kc; return; }
     if (++kc == kchunks) {
       kc = 0;
       ++tap;
@@ -492,15 +502,23 @@ extern "C" int drag_conv2d_f32(const drag_conv2d_f32_args* a, void* stream) {
   int pick = (a->Cout >= 128 && g128 >= 512) ? 2 : ((a->Cin % 64 == 0 && g64 < 1024) ? 1 : 0);
   if (force) pick = force[0] == '1' ? 2 : (force[3] == '6' ? 1 : 0);
   if (pick == 1 && a->Cin % 64 != 0) pick = 0;
+  static const bool no_lin = getenv("DRAG_CONV_NO_LIN") != nullptr;
+  const int tile = pick == 2 ? 128 : 64, step = pick == 1 ? 64 : 16;
+  const bool lin = !no_lin && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && !a->transposed && a->Hi == a->Ho && a->Wi == a->Wo &&
+                   k.npix % tile == 0 && a->Cout % tile == 0 && a->Cin % step == 0;
   if (pick == 2) {
     dim3 grid((unsigned)((k.npix + 127) / 128), (unsigned)((a->Cout + 127) / 128));
-    hipLaunchKernelGGL((conv2d_f32_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    if (lin) hipLaunchKernelGGL((conv2d_f32_kernel<16, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL((conv2d_f32_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, k);
   } else {
     dim3 grid((unsigned)((k.npix + 63) / 64), (unsigned)((a->Cout + 63) / 64));
-    if (pick == 1)
-      hipLaunchKernelGGL((conv2d_f32_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
-    else
-      hipLaunchKernelGGL((conv2d_f32_kernel<16, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    if (pick == 1) {
+      if (lin) hipLaunchKernelGGL((conv2d_f32_kernel<64, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, k);
+      else hipLaunchKernelGGL((conv2d_f32_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    } else {
+      if (lin) hipLaunchKernelGGL((conv2d_f32_kernel<16, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, k);
+      else hipLaunchKernelGGL((conv2d_f32_kernel<16, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    }
   }
   DRAG_LAUNCH_CHECK();
   return 0;
