@@ -1103,9 +1103,15 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
 #define DRAG_DEEP_LAUNCH(MI_, ST_, NI_)                                                                                    \
   {                                                                                                                        \
     constexpr int lds = ST_ * (32 * MI_ + 32 * NI_) * 128;                                                                 \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_deep<MI_, ST_, NI_>),     \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
-    DRAG_CHECK(attr == hipSuccess, "drag_gemm_bf16: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");            \
+    static unsigned long long ready = 0;        /* one bit per device: the attribute belongs to the device's copy of the kernel */ \
+    int dev_ = 0;                                                                                                          \
+    (void)hipGetDevice(&dev_);                                                                                             \
+    if (!((ready >> (dev_ & 63)) & 1ull)) {                                                                                \
+      DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_deep<MI_, ST_, NI_>),                       \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,                      \
+                 "drag_gemm_bf16: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                               \
+      ready |= 1ull << (dev_ & 63);                                                                                        \
+    }                                                                                                                      \
     hipLaunchKernelGGL((gemm_bf16_deep<MI_, ST_, NI_>), g, dim3(256), lds, st_, k);                                       \
   }                                                                                                                        \
   break
