@@ -73,7 +73,6 @@ struct GemmKArgs {
   void* C2;
   int ld2, n_split;
   int group_m;    // M tiles per group of the tile walk (8; "gemm_group_m" option for measurements)
-  int dbg;        // DRAG_GEMM_DBG (timing experiments only: wrong results): 1 = every K-step fetches K-step 0, 2 = no barrier, 4 = no vmcnt wait
   // optional second row segment (drag_gemm_bf16_pair): M tiles >= seg_tiles_m belong to a second problem with its own operands and
   // row maps but the same N, K and epilogue form — a double block's text and image Linears as ONE launch of the non-persistent kernels
   int seg_tiles_m;          // 0: one segment
@@ -888,225 +887,6 @@ template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_t256(GemmKArgs p) { t256_body<MODE, false>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_pair(GemmKArgs p) { t256_body<0, true>(p); }
 
-// --------------------------------------------------------------------------------------------
-// gemm_bf16_t256s — the same 256x256x64 tile, wave grid, LDS image, tile walk and epilogue as gemm_bf16_t256, with a HAND-PLACED
-// K loop (round 4).  What the counters say about the role-split loop above (profiles/r04_pmc_mfma_util.txt, in the pipeline): the
-// matrix pipe is busy 69 % of the cycles at the clock the chip gives the kernel, LDS bank conflicts 0, and a wave spends 25 % of
-// its time parked at one of the four barriers / waits per K-step and 46 % stalled at issue — the two wave groups take turns, so
-// whenever a load segment (reads + LDS-DMA issue + wait) outlasts the partner's 32 MFMAs the pipe idles until the next barrier.
-// Here every wave is its own pipeline and the two waves of a SIMD are symmetric, so the pipe has two independent instruction
-// streams to draw MFMAs from and ONE barrier per K-step:
-//   * fragments live in two register sets by k-half (set h = the 8 X + 4 W fragments of k-half h: 48 registers each);
-//   * half h of K-step t = 32 MFMAs on set h, with the 12 ds_read_b128 that refill the OTHER set placed one per second MFMA gap
-//     (set 1 <- k-half 1 of K-step t during half 0, set 0 <- k-half 0 of K-step t+1 during half 1): every read has >= 8 MFMAs
-//     (and the partner wave's) to land behind, the waits that retire them are counted by hand (the MFMAs and reads are `asm
-//     volatile`, so hipcc neither reorders them nor inserts its own s_waitcnt);
-//   * between the halves: s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier — this wave's pieces of K-step t+1 have landed and its reads
-//     of buffer t are complete, for every wave; after it the 8 LDS-DMA pieces of K-step t+2 go into buffer t (one per odd MFMA
-//     gap of half 1): an operand tile is in flight for one whole K-step before anyone waits for it.
-// Same MFMA, same k order per accumulator as every other kernel of the family: same bits (test_gemm_kernels_are_bit_identical).
-// The LDS-DMA stream crosses tile boundaries as in t256 (the last two K-steps of a tile fetch K-steps 0 and 1 of the next one).
-// --------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mfma_16x16x32_asm(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-
-// one half of a K-step: MFMA I of 32 (row block I >> 2, column block I & 3) on the set in use, then — after every second MFMA —
-// one fragment read into the other set (8 X fragments from adX, then 4 W fragments from adW), and — after the odd MFMAs 1..15 —
-// one LDS-DMA piece when the half carries the K-step's staging
-template <int I, bool READS, bool DMA, class F>
-__device__ __forceinline__ void t256s_half(f32x4_t (*acc)[4], const bf16x8_t* xa, const bf16x8_t* wb, bf16x8_t* nxa, bf16x8_t* nwb,
-                                           unsigned adX, unsigned adW, F&& dma) {
-  if constexpr (I < 32) {
-    mfma_16x16x32_asm(acc[I >> 2][I & 3], wb[I & 3], xa[I >> 2]);
-    if constexpr (READS && (I & 1) == 0 && I < 24) {
-      constexpr int r = I >> 1;
-      if constexpr (r < 8) lds_read_b128<r * 2048>(nxa[r], adX);
-      else lds_read_b128<(r - 8) * 2048>(nwb[r - 8], adW);
-    }
-    if constexpr (DMA && (I & 1) == 1 && I < 16) dma(I >> 1);
-    t256s_half<I + 1, READS, DMA>(acc, xa, wb, nxa, nwb, adX, adW, dma);
-  }
-}
-
-template <int MODE, bool SEG>
-__device__ __forceinline__ void t256s_body(const GemmKArgs& p) {
-  // 2 K-step buffers {A0 A1 B0 B1} + one 2 KiB slab per wave (epilogue transpose; before that: the NEXT tile's per-lane load offsets) + 64 B
-  // per wave for the next tile's descriptors
-  __shared__ __attribute__((aligned(16))) char smem[2 * T2_BUF + 8 * 2048 + 8 * 64];
-  const int w = wave_id();
-  const int l = lane_id();
-  const int wr = w >> 2, wc = w & 3;
-  const int P = (int)gridDim.x;
-  const int nwg = p.tiles_m * p.tiles_n;
-  int vb = (int)blockIdx.x;
-
-  // ---- staging: per K-step 32 A chunks + 32 W chunks of 8 rows x 128 B; wave w moves A chunks 4w..4w+3 and W chunks 4w..4w+3
-  // (chunk c = rows 8c..8c+7 of the 256-row operand tile = LDS bytes c * 1024 of the operand's two halves)
-  struct LoadState {
-    unsigned long long baseA, baseW;     // first byte of the tile's A rows / W rows
-    unsigned recW;                       // bytes of W the tile may read
-    unsigned vo[8];                      // per-lane byte offsets: [0..3] A chunks, [4..7] W chunks
-  };
-  auto compute_state = [&](int tile, LoadState& st, int l) {      // (l: an opaque copy of the lane id — see below)
-    int tm, tn;
-    pick_tile(p, tile, tm, tn);
-    const bf16_t* A = p.A;
-    const bf16_t* W = p.W;
-    int M = p.M;
-    RowMap am = p.am;
-    if (SEG && p.seg_tiles_m > 0 && tm >= p.seg_tiles_m) { tm -= p.seg_tiles_m; A = p.A2; W = p.W2; M = p.M2; am = p.am2; }
-    const int m0 = tm * 256, n0 = tn * 256;
-    const long long a0 = MODE == 0 ? am.off(m0) : p.cv.off(m0);
-    const int wrows = min(256, p.N - n0);
-    st.baseA = (unsigned long long)(size_t)(A + a0);
-    st.baseW = (unsigned long long)(size_t)(W + (long long)n0 * p.K);
-    st.recW = (unsigned)((long long)wrows * p.K * 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (w * 4 + i) * 8 + (l >> 3);            // row of the 256-row tile
-      const int slot = (l & 7) ^ ((row >> 1) & 7);           // the 16-B slot this lane fetches (XOR swizzle on the source side)
-      const int ra = min(m0 + row, M - 1);                   // clamp: rows past the edge are never stored
-      st.vo[i] = (unsigned)(((MODE == 0 ? am.off(ra) : p.cv.off(ra)) - a0 + slot * 8) * 2);
-      const int rw = min(row, wrows - 1);
-      st.vo[4 + i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
-    }
-  };
-  __amdgpu_buffer_rsrc_t rsA, rsW;
-  unsigned vo[8];
-  auto adopt = [&](unsigned long long baseA, unsigned long long baseW, unsigned recW) {
-    // descriptors are based at the tile's first row, so operands of any size work with 32-bit in-tile offsets
-    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)baseA, 0, 0x7ffffff0u, 0x00020000);
-    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)baseW, 0, recW, 0x00020000);
-  };
-  char* const slab = smem + 2 * T2_BUF + w * 2048;
-  uint32_t* const desc = (uint32_t*)(smem + 2 * T2_BUF + 8 * 2048 + w * 64);
-  // The next tile's load state is computed at the TOP of a tile (integer divisions, 64-bit row offsets: ~60 live registers of
-  // their own) where nothing of the K loop is live, parked in this wave's private LDS, and fetched two K-steps before the tile's end.
-  // hipcc hoists every loop-invariant lane-derived value (row offsets, swizzles, the epilogue's slab addresses ...) out of the tile loop and
-  // keeps it in a register across the K loop, which has 19 registers to spare: the lane id each side phase works from is re-defined by an
-  // empty asm at the phase's start, so what derives from it is computed there.
-  auto park_state = [&](int tile) {
-    int l = lane_id();
-    asm volatile("" : "+v"(l));
-    LoadState st;
-    compute_state(tile, st, l);
-    *(u32x4_t*)(slab + l * 32) = (u32x4_t){st.vo[0], st.vo[1], st.vo[2], st.vo[3]};
-    *(u32x4_t*)(slab + l * 32 + 16) = (u32x4_t){st.vo[4], st.vo[5], st.vo[6], st.vo[7]};
-    if (l == 0) {
-      *(u32x4_t*)desc = (u32x4_t){(uint32_t)st.baseA, (uint32_t)(st.baseA >> 32), (uint32_t)st.baseW, (uint32_t)(st.baseW >> 32)};
-      desc[4] = st.recW;
-    }
-  };
-  auto fetch_state = [&]() {
-    int l = lane_id();
-    asm volatile("" : "+v"(l));
-    const u32x4_t a = *(const u32x4_t*)(slab + l * 32), b = *(const u32x4_t*)(slab + l * 32 + 16);
-    const u32x4_t d = *(const u32x4_t*)desc;
-    const uint32_t r = desc[4];
-    vo[0] = a[0]; vo[1] = a[1]; vo[2] = a[2]; vo[3] = a[3]; vo[4] = b[0]; vo[5] = b[1]; vo[6] = b[2]; vo[7] = b[3];
-    auto sgpr = [](uint32_t v) { return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)v); };     // (zero-extended)
-    const unsigned long long bA = sgpr(d[0]) | (sgpr(d[1]) << 32);
-    const unsigned long long bW = sgpr(d[2]) | (sgpr(d[3]) << 32);
-    adopt(bA, bW, (unsigned)__builtin_amdgcn_readfirstlane(r));
-  };
-  const int cchunks = MODE == 1 ? p.cv.Cin / BK : 1;
-  const int nk = p.K / BK;                          // >= 4 (use_t256)
-  auto issue = [&](int i, int kt, int buf) {        // piece i of K-step kt of the tile in the load state -> LDS buffer buf
-    int soff = kt * (BK * 2);
-    DRAG_LDS char* d = (DRAG_LDS char*)smem + buf * T2_BUF + (w * 4 + (i & 3)) * 1024;
-    if (i < 4) {
-      if (MODE == 1) {
-        const int tap = kt / cchunks, cc = kt - tap * cchunks;
-        const int r = tap / 3, sx = tap - r * 3;
-        soff = ((r * p.cv.Wp + sx) * p.cv.Cin + cc * BK) * 2;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DRAG_LDS void*)d, 16, vo[i], soff, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (DRAG_LDS void*)(d + 2 * T2_HALF), 16, vo[i], soff, 0, 0);
-    }
-  };
-
-  // fragment read addresses (LDS bytes) of k-half 0 in buffer 0; k-half 1 = the 16-B slot index XOR 4, buffer 1 = + T2_BUF
-  const int p0 = (l >> 4) ^ ((l & 15) >> 1);
-  const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
-  const unsigned fx = lds0 + (unsigned)(wr * T2_HALF + (l & 15) * 128);                                  // + mi * 2048
-  const unsigned fw = lds0 + (unsigned)((2 + (wc >> 1)) * T2_HALF + ((wc & 1) * 64 + (l & 15)) * 128);   // + ni * 2048
-  const unsigned s0 = (unsigned)(p0 << 4), s1 = (unsigned)((p0 ^ 4) << 4);
-
-  {
-    LoadState st;
-    compute_state(vb, st, l);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vo[i] = st.vo[i];
-    adopt(st.baseA, st.baseW, st.recW);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) issue(i, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) issue(i, 1, 1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // K-step 0 landed (this wave's pieces)
-  T2_BARRIER();                                        // ... every wave's
-
-  bf16x8_t xa0[8], wb0[4], xa1[8], wb1[4];
-  f32x4_t acc[8][4];
-  int g = 0;                                           // K-steps over all tiles of this workgroup (buffer = g & 1)
-  bool after_interior_epilogue = false;
-  const auto no_dma = [](int) {};
-  for (;;) {
-    const bool have_next = vb + P < nwg;
-    if (have_next) park_state(vb + P);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    {   // set 0 <- k-half 0 of this tile's K-step 0 (landed and published by the previous tile's last wait + barrier, or the prologue's)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the previous tile's last, unused reads of these registers)
-      const unsigned b = (unsigned)((g & 1) * T2_BUF);
-      lds_read_frags<8, 0>(xa0, fx + b + s0);
-      lds_read_frags<4, 0>(wb0, fw + b + s0);
-    }
-    // One K-step t (buffer g & 1), the same instruction stream for every t: the second half stages K-step t + 2 into this K-step's buffer
-    // and reads k-half 0 of K-step t + 1 into set 0.  Past the tile's end "t + 2" / "t + 1" are K-steps 1 / 0 of the NEXT tile (its load
-    // state is fetched two K-steps before the end); with no next tile they are this tile's own K-steps 0 / 1 again — 128 KiB per
-    // workgroup and launch that nobody reads, instead of a second, conditional copy of the loop body (two copies + the branches between
-    // them cost hipcc's register allocator ~600 spilled registers).  The reads of the last K-step land in registers the next tile's
-    // first instruction overwrites (set 0 is not live across the epilogue).
-    for (int t = 0; t < nk; ++t) {
-      if (t == nk - 2 && have_next) fetch_state();
-      const unsigned bc = (unsigned)((g & 1) * T2_BUF), bn = (unsigned)(((g + 1) & 1) * T2_BUF);
-      const int gb = g & 1, ktd = (p.dbg & 1) ? 0 : (t + 2 < nk ? t + 2 : t + 2 - nk);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // set 0 landed
-      t256s_half<0, true, false>(acc, xa0, wb0, xa1, wb1, fx + bc + s1, fw + bc + s1, no_dma);
-      if (after_interior_epilogue && t == 0) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");   // only the last tile's 16 epilogue stores are younger
-      else if (p.dbg & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // K-step g+1 landed; set 1 landed = this wave's reads of buffer g are complete
-      if (!(p.dbg & 2)) T2_BARRIER();
-      t256s_half<0, true, true>(acc, xa1, wb1, xa0, wb0, fx + bn + s0, fw + bn + s0, [&](int i) { issue(i, ktd, gb); });
-      ++g;
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results (hipcc does not see MFMAs inside asm: no hazard padding)
-    int tm, tn;
-    pick_tile(p, vb, tm, tn);
-    GemmKArgs pd = p;
-    if (SEG) pick_segment(pd, tm);
-    const int m0 = tm * 256, n0 = tn * 256;
-    pd = dest_of(pd, n0);
-    int le = lane_id();
-    asm volatile("" : "+v"(le));
-    if (pd.wide) staged_epilogue<8, 256>(pd, m0, m0 + wr * 128, n0, n0 + wc * 64, le, acc, slab);
-    else wave_epilogue<8, 256>(pd, m0, m0 + wr * 128 + (le & 15), n0, n0 + wc * 64 + (le >> 4) * 4, acc);
-    if (!have_next) break;
-    after_interior_epilogue = m0 + 256 <= pd.M && n0 + 256 <= p.N;
-    vb += P;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last tile's two surplus K-steps: no LDS-DMA may outlive the workgroup's LDS allocation
-}
-
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_t256s(GemmKArgs p) { t256s_body<MODE, false>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_bf16_t256s_pair(GemmKArgs p) { t256s_body<0, true>(p); }
-
 }  // namespace
 
 // tile policy: the 256x256 kernel needs enough tiles to fill 256 CUs and rows to amortise its prologue
@@ -1235,7 +1015,6 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   // M tiles per group of the tile walk: the 32 concurrent tiles of an XCD form a group_m x (32 / group_m) super-tile.  4 and 8 tie on
   // the K = 3072 shapes (8 ahead by 1-3 % at N = 3072), 4 is 2-3 % ahead at K >= 12288; 16 / 32 (towards W-stationary) lose 5-10 %
   // everywhere (scripts/bench_gemm_group_m.py, two boxes).  Order only: the bits do not depend on it.
-  { static const int dbg = getenv("DRAG_GEMM_DBG") ? atoi(getenv("DRAG_GEMM_DBG")) : 0; k.dbg = dbg; }
   k.group_m = drag_opt(DRAG_OPT_GEMM_GROUP_M) > 0 ? drag_opt(DRAG_OPT_GEMM_GROUP_M) : (K >= 8192 ? 4 : 8);
   static const bool narrow = env_flag("DRAG_GEMM_NARROW");
   k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&
@@ -1313,13 +1092,8 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
   if (choice == 2) {
     tiles_of(256); k.tiles_n = (a->N + 255) / 256;
     const dim3 g(t256_grid(k.tiles_m * k.tiles_n));
-    if (drag_opt(DRAG_OPT_GEMM_T256_LOOP) == 1) {        // the round-3 role-split loop (A/B measurements only)
-      if (b) hipLaunchKernelGGL(gemm_bf16_t256_pair, g, dim3(512), 0, st_, k);
-      else hipLaunchKernelGGL((gemm_bf16_t256<0>), g, dim3(512), 0, st_, k);
-    } else {
-      if (b) hipLaunchKernelGGL(gemm_bf16_t256s_pair, g, dim3(512), 0, st_, k);
-      else hipLaunchKernelGGL((gemm_bf16_t256s<0>), g, dim3(512), 0, st_, k);
-    }
+    if (b) hipLaunchKernelGGL(gemm_bf16_t256_pair, g, dim3(512), 0, st_, k);
+    else hipLaunchKernelGGL((gemm_bf16_t256<0>), g, dim3(512), 0, st_, k);
   } else if (choice) {
     const int deep = choice;
     const int ni = deep >= 100 ? 6 : 4, mi = (deep % 100) / 10, st = deep % 10;
@@ -1434,10 +1208,7 @@ extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
   DRAG_CHECK(((long long)(BM * a->stride + 3 * a->Wp * 2) * a->Cin) * 2 < (1ll << 30), "drag_conv3x3_bf16: tile span too large");
   if (use_t256(M, 0, a->Cout, 9 * a->Cin)) {
     k.tiles_m = (int)((M + 255) / 256); k.tiles_n = (a->Cout + 255) / 256;
-    if (drag_opt(DRAG_OPT_GEMM_T256_LOOP) == 1)
-      hipLaunchKernelGGL(gemm_bf16_t256<1>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
-    else
-      hipLaunchKernelGGL(gemm_bf16_t256s<1>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(gemm_bf16_t256<1>, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(512), 0, (hipStream_t)stream, k);
   } else
     hipLaunchKernelGGL(gemm_bf16_t128<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
   DRAG_LAUNCH_CHECK();
