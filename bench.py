@@ -209,6 +209,30 @@ def _pick_threads() -> int:
     return best
 
 
+def _host_cpu() -> dict:
+    """what the CPU legs ran on: logical CPUs the OS reports, physical cores and the model name from /proc/cpuinfo, and the torch thread
+    count the probe in _pick_threads chose (north_star asks for the core count next to the CPU number)"""
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name") and model is None:
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    cid = ln.split(":", 1)[1].strip()
+                elif not ln.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return {"host_cpus": logical, "cores": len(phys) or logical, "cpu_model": model, "threads": torch.get_num_threads()}
+
+
 def _median_time(fn, repeats=3):
     ts = []
     for _ in range(repeats):
@@ -269,7 +293,7 @@ def cpu_baseline_generate(res: int, denoise_steps: int):
     # encode ~ 0.48 x decode in FLOPs (dec 10.5, 2 x enc ~ 10 TFLOP)
     sec_vae = tv * vae_scale * (1.0 + 2 * 0.48)
     sec_per_img = denoise_steps * (19 * td + 38 * ts) + sec_vae + tp
-    return {"value": 1.0 / sec_per_img, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": 1.0 / sec_per_img, "unit": "images/s", **_host_cpu(), "kind": "port",
             "extrapolated": True, "seconds_per_image": sec_per_img,
             "legs_s": {"double_block": tds, "single_block": tss, "vae_decode_sample": tvs, "redux_prior": tps},
             "sample": f"oracle bf16 on CPU, median of 3: 1 double ({td:.2f}s) + 1 single ({ts:.2f}s) Flux block at S={St + Si}, B=1; "
@@ -318,7 +342,7 @@ def cpu_baseline_retrieval(topk: int, budget_s: float = 60.0):
     oret.cosine_topk(corpus, q, min(topk, corpus.shape[0]))
     t_top = time.perf_counter() - t0
     total = t_pre + t_emb + t_top
-    return {"value": done / total, "unit": "corpus images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": done / total, "unit": "corpus images/s", **_host_cpu(), "kind": "port",
             "legs_s": {"pil_resize_crop": t_pre, "clip_vit_b32_fp32": t_emb, "top%d_16_queries" % topk: t_top},
             "sample": f"BASELINE configs[0] on the host cores: {done} of 1000 synthetic 640x480 images (PIL bicubic preprocess + upstream "
                       f"transformers CLIP ViT-B/32 fp32 in batches of {bs} + oracle/topk.c for 16 queries)"
@@ -339,6 +363,28 @@ def _pmc_traffic(kernel_substr: str):
         except Exception:
             continue
     return None, None
+
+
+def _pmc_mfma_util():
+    """counter-based matrix-pipe utilisation of the two dominant kernels from the NEWEST committed profiles/rNN_pmc_mfma_util.json
+    (scripts/pmc_mfma_util.sh: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs), both from one --pmc pass over this bench's default
+    workload; the effective clock = GRBM_GUI_ACTIVE / launch duration of the same pass)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_mfma_util.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            out = {"source": os.path.relpath(path, ROOT)}
+            for label, sub in (("gemm_bf16_t256<0>", "gemm_bf16_t256ILi0"), ("attention_d128_kernel<8,...>", "attention_d128_kernelILi8")):
+                key = next(k for k in pm if sub in k)
+                r = pm[key]
+                out[label] = {"mfma_util": r["mfma_util"], "clock_ghz": r["clock_ghz"], "avg_us_profiled": r["avg_us_profiled"],
+                              "wave_parked_frac": r.get("sq_wait_any_per_wave_cycle"), "wave_issue_stall_frac": r.get("sq_wait_inst_any_per_wave_cycle"),
+                              "lds_bank_conflict_frac": r.get("sq_lds_bank_conflict_per_wave_cycle")}
+            return out
+        except Exception:
+            continue
+    return None
 
 
 # ----------------------------------------------------------------------------------------------- workloads
@@ -394,12 +440,15 @@ def run_generate(args, d: Dist):
                                                 "by_kernel": {k: {"launches": v[0], "avg_launch_ms": v[1] / max(v[0], 1),
                                                                   "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0}
                                                               for k, v in bk.items()}},
-                     "e2e_mfma_frac": job.flops_per_image() * images / d.world / dt / (MFMA_BF16_PEAK_TF * 1e12)},
+                     "e2e_mfma_frac": job.flops_per_image() * images / d.world / dt / (MFMA_BF16_PEAK_TF * 1e12),
+                     "mfma_util_pmc": _pmc_mfma_util()},
     }
     if not args.no_side_configs and d.world == 1:
         del job
         torch.cuda.empty_cache()
         out["side_configs"] = {"configs1": side_config1(d.dev)}
+        torch.cuda.empty_cache()
+        out["side_configs"]["stage3_2048"] = side_stage3(d.dev)
         torch.cuda.empty_cache()
         out["side_configs"]["retrieval"] = side_retrieval(d.dev, cpu_budget_s=0.0 if args.no_cpu_baseline else 10.0)
     if not args.no_cpu_baseline and d.world == 1:
@@ -436,6 +485,52 @@ def side_config1(dev) -> dict:
     return {"workload": "BASELINE configs[1]: Flux-schnell shape 512x512, 4 steps, batch=1 (latency case: 1536 joint rows)",
             "value": 1.0 / dt, "unit": "images/s", "ms_per_image": dt * 1e3, "achieved_tflops": flops / dt / 1e12,
             "mfma_frac": flops / dt / (MFMA_BF16_PEAK_TF * 1e12)}
+
+
+def side_stage3(dev, res: int = 2048, batch: int = 2, steps: int = 3) -> dict:
+    """the reference's stage 3 composites at sides in [1024, 2800] (outpainting_updown_sampling_redux.py:72-82, 104-105; UODD is up-scaled to
+    2048): the same Fill pipeline at 2048 x 2048 (17 625 joint tokens: attention is > half of a block's FLOPs), batch 2, 3 denoise steps —
+    whole-pipeline time, per-kernel GEMM TFLOP/s (events around every GEMM launch) and the attention kernel alone at that shape.  A side
+    field, outside the timed region; oracle parity at these sizes: tests/test_gpu_stage3_sizes.py."""
+    import math
+    from domain_rag_amd import ops
+    from domain_rag_amd.fill_pipeline import SyntheticFillJob
+    job = SyntheticFillJob(batch=batch, res=res, denoise_steps=steps, device=dev, seed=77)
+    job.run_batch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    job.run_batch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec = ops.GemmRecorder(every=1)
+    job.run_batch(recorder=rec)
+    flops, ms, launches = rec.totals()
+    bk = rec.by_kernel()
+    del job
+    torch.cuda.empty_cache()
+    S, H = (res // 16) ** 2 + 512 + 729, 24
+    D = H * 128
+    g = torch.Generator(device=dev).manual_seed(3)
+    qkv = torch.randn(batch, S, 3 * D, generator=g, device=dev).bfloat16()
+    s_pad = (S + 63) // 64 * 64
+    vt = torch.empty(batch, H, 128, s_pad, dtype=torch.bfloat16, device=dev)
+    ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, batch, S, H, 3 * D, 0)
+    o = torch.empty(batch, S, D, dtype=torch.bfloat16, device=dev)
+    run = lambda: ops.attention(qkv, qkv.view(-1)[D:], vt, o, batch, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))   # noqa: E731
+    run(); run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    att_ms = e0.elapsed_time(e1) / 5
+    att_tf = 4.0 * S * S * 128 * H * batch / (att_ms * 1e-3) / 1e12
+    return {"workload": f"Fill pipeline {res}x{res} (S = {S} joint tokens), batch {batch}, {steps} denoise steps — the reference's stage-3 sizes",
+            "seconds_per_batch": dt, "images_per_s_at_30_steps_extrapolated": None,
+            "gemm": {"launches": launches, "achieved_tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                     "by_kernel": {k: {"launches": v[0], "achieved_tflops": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in bk.items()}},
+            "attention": {"shape": f"B={batch}, S={S}, 24 heads x 128", "ms_per_launch": att_ms, "achieved_tflops": att_tf, "mfma_frac": att_tf / MFMA_BF16_PEAK_TF}}
 
 
 def side_retrieval(dev, k: int = 100, cpu_budget_s: float = 10.0) -> dict:

@@ -54,6 +54,7 @@ SIGNATURES = {
     "drag_gemm_bf16_pair": (c_int, [ctypes.POINTER(GemmArgs), ctypes.POINTER(GemmArgs), c_void_p]),
     "drag_gemm_bf16_pair_merges": (c_int, [c_int, c_int, c_int, c_int]),
     "drag_gemm_bf16_choice": (c_int, [c_int, c_int, c_int, c_int]),
+    "drag_conv3x3_bf16_choice": (c_int, [c_int64, c_int, c_int]),
     "drag_gemm_bf16_cost": (c_int64, [c_int, c_int, c_int, c_int]),
     "drag_qk_norm_rope_vt_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "drag_attention_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float, c_void_p]),

@@ -148,7 +148,7 @@ def process_dataset(engine, results, dataset, shot, args, rank, world):
         print(f"跳过数据集 {dataset} {shot}-shot，因为找不到样本")
         return 0, 0
     result_dir = f"{args.output_dir}/{dataset}_{shot}shot_retrieval"
-    ts = run_timestamp(world)
+    ts = getattr(args, "run_ts", None) or run_timestamp(world)       # several ranks: the run's one stamp (main); one process: now
     base = os.path.join(result_dir, f"results_coco_{COCO_IMAGE_SCALE}_target_{TARGET_IMAGE_SCALE}_cocotext_{COCO_TEXT_SCALE}"
                                     f"_targettext_{TARGET_TEXT_SCALE}_{ts}")
     os.makedirs(base, exist_ok=True)
@@ -210,24 +210,28 @@ def run_timestamp(world: int) -> str:
     over directories whenever the ranks cross a second boundary): $DRAG_TIMESTAMP if the launcher exports one; else rank 0's
     clock, BROADCAST over a gloo process group (works across nodes and under any launcher that provides RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT — torchrun, srun + env, mpirun wrappers; the data path itself needs no collective, the group exists
-    for this one string); only if no rendezvous is possible, the start time of the common parent process read from /proc (same
-    node, same parent only — the warning says so)."""
+    for this one string); only if no rendezvous is POSSIBLE (no MASTER_ADDR / MASTER_PORT, or the group cannot be created), the start
+    time of the common parent process read from /proc (same node, same parent only — the warning says so).  Once a group exists a
+    failing broadcast is an error, never a silent fall-back: ranks that disagree about the directory corrupt the run.
+    main() calls this ONCE, before any work, while the ranks are still in step, and every (dataset, shot) of the run re-uses the
+    stamp (directory names already carry dataset and shot): a collective per dataset would be reached minutes apart by ranks whose
+    shards differ in cost."""
     env = os.environ.get("DRAG_TIMESTAMP")
     if env:
         return env
     if world > 1:
-        try:
-            import torch.distributed as dist
-            if not dist.is_initialized():
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            try:
                 if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
                     raise RuntimeError("MASTER_ADDR / MASTER_PORT are not set")
-                from datetime import timedelta
-                dist.init_process_group("gloo", timeout=timedelta(seconds=300))
+                dist.init_process_group("gloo")
+            except Exception as e:
+                print(f"警告：无法建立进程组来广播时间戳 ({e})；退回到父进程启动时间（仅限同一节点、同一父进程）")
+        if dist.is_initialized():
             box = [datetime.now().strftime("%Y%m%d_%H%M%S")]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        except Exception as e:
-            print(f"警告：无法通过进程组广播时间戳 ({e})；退回到父进程启动时间（仅限同一节点、同一父进程）")
         try:
             with open(f"/proc/{os.getppid()}/stat") as f:
                 ticks = int(f.read().rsplit(")", 1)[1].split()[19])          # field 22: start time in clock ticks since boot
@@ -245,6 +249,9 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
+    # several ranks: ONE results-directory stamp for the whole run, agreed here — before the weights load and before any rank can
+    # run ahead of the others; one process keeps the reference's now() per dataset
+    args.run_ts = run_timestamp(world) if world > 1 else None
     if args.tiny and args.size == SIZE:
         args.size = 64
     rf = os.path.join(args.retrieval_results_dir, "all_shots_retrieval_results.json")

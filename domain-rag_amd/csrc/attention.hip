@@ -195,9 +195,20 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
   // ---- Q fragments stay in registers: B operand, lane -> query (l&31), k = 16ks + 8hh .. +8 (loaded below, after the
   // first K / V^T tiles have been requested: one workgroup per CU, so nothing else hides this prologue's latency) ----
   bf16x8_t qf[8];
-  // ---- staging descriptors: the WHOLE K tensor / V^T tensor; the item is the scalar offset ----
-  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, p.k_bytes_all, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(VROW ? p.v : p.vt), 0, VROW ? p.k_bytes_all : p.vt_bytes_all, 0x00020000);
+  // ---- staging descriptors.  One item per workgroup (the product): based at the item's (batch, head), spanning that (batch, head) only —
+  // tensors of any size work as long as ONE (batch, head) stays below 2 GiB (whole-tensor descriptors had put a 4 GiB cap on
+  // B x S for the sake of the persistent experiment).  PERSIST: the WHOLE K / V^T tensor, the item is a scalar offset.
+  __amdgpu_buffer_rsrc_t rsK, rsV;
+  if constexpr (PERSIST) {
+    rsK = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, p.k_bytes_all, 0x00020000);
+    rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(VROW ? p.v : p.vt), 0, VROW ? p.k_bytes_all : p.vt_bytes_all, 0x00020000);
+  } else {
+    const long long kb = ((long long)b * p.qk_bs + h * 128) * 2;
+    rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.k + kb), 0, p.k_bytes, 0x00020000);
+    if constexpr (VROW) rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.v + kb), 0, p.k_bytes, 0x00020000);
+    else rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.vt + (long long)(b * p.H + h) * 128 * p.s_pad * 2), 0, p.vt_bytes, 0x00020000);
+    soK = 0; soV = 0;
+  }
   unsigned soKn = soK, soVn = soV;    // the NEXT item's offsets (PERSIST; = this item's when there is none: harmless re-reads)
   // K chunk c (1 KiB) = key rows 4c..4c+3; lane: row 4c + (l>>4), physical slot l&15
   // V chunk c (1 KiB) = d rows 8c..8c+7;   lane: row 8c + (l>>3), physical slot l&7
@@ -543,6 +554,7 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
 
 
 // --------------------------------------------------------------------------------------------
+#if DRAG_EXP
 // EXPERIMENT (drag_set_option "attn_q64"): 4 waves x 64 queries, ONE wave per SIMD with the whole 512-entry register file.
 // Each wave owns two 32-query groups and runs both against every K / V^T fragment it reads, which halves the LDS fragment
 // reads per flop (the 8-wave kernel's other cost besides the exp stream).  Same arithmetic per query group, same deferred-
@@ -838,6 +850,8 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   }
 }
 
+#endif  // DRAG_EXP
+
 }  // namespace
 
 extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt, const void* wk_txt,
@@ -921,6 +935,7 @@ extern "C" int drag_attention_v_bf16(const void* q, const void* k, const void* v
                           rope_sin, s_txt, eps, stream, true);
 }
 
+#if DRAG_EXP
 // workgroups per XCD of the persistent attention kernel
 static int persist_slots() {
   const int opt = drag_opt(DRAG_OPT_ATTN_PERSIST);
@@ -933,6 +948,7 @@ static int persist_slots() {
   }
   return ncu8;
 }
+#endif
 
 static int attention_launch(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S, int32_t H,
                             int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale,
@@ -953,11 +969,12 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   DRAG_CHECK(kspan < (1ll << 31), "drag_attention_bf16: K span must be < 2 GiB per (batch, head)");
   p.k_bytes = (unsigned)kspan; p.vt_bytes = (unsigned)vspan;
   const long long kall = ((long long)(B - 1) * qk_batch_stride + (H - 1) * 128) * 2 + kspan, vall = (long long)B * H * vspan;
-  DRAG_CHECK(kall < (1ll << 32) && vall < (1ll << 32), "drag_attention_bf16: the K / V^T tensors must span < 4 GiB (32-bit offsets)");
-  p.k_bytes_all = (unsigned)kall; p.vt_bytes_all = (unsigned)vall;
+  // (whole-tensor spans: only the persistent experiment addresses through them — its launch condition below checks they fit 32 bits)
+  const bool fits32 = kall < (1ll << 32) && vall < (1ll << 32);
+  p.k_bytes_all = fits32 ? (unsigned)kall : 0u; p.vt_bytes_all = fits32 ? (unsigned)vall : 0u;
   const int groups = (B * H + 7) / 8;
   const bool w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
-  const int QB = (w8 || (!vrow && drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024)) ? 256 : 128;
+  const int QB = (w8 || (DRAG_EXP && !vrow && drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024)) ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
   const int sched = drag_opt(DRAG_OPT_ATTN_SCHED);          // 0, 1, or 2 = schedule 1 + pipelined row maxima
@@ -968,8 +985,8 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
 #define DRAG_ATTN_LAUNCH(NW, SC, QP, PM) hipLaunchKernelGGL((attention_d128_kernel<NW, SC, QP, PM>), grid, dim3(NW * 64), 0, st, p)
 #define DRAG_ATTN_PICK(NW)                                                                           \
   do {                                                                                               \
-    if (sched == 3) { if (qprep) DRAG_ATTN_LAUNCH(NW, 2, true, true); else DRAG_ATTN_LAUNCH(NW, 2, false, true); }        \
-    else if (sched == 2) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, true); else DRAG_ATTN_LAUNCH(NW, 1, false, true); }   \
+    if (DRAG_EXP && sched == 3) { if (qprep) DRAG_ATTN_LAUNCH(NW, DRAG_EXP ? 2 : 1, true, true); else DRAG_ATTN_LAUNCH(NW, DRAG_EXP ? 2 : 1, false, true); }        \
+    else if (sched >= 2) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, true); else DRAG_ATTN_LAUNCH(NW, 1, false, true); }   \
     else if (sched == 1) { if (qprep) DRAG_ATTN_LAUNCH(NW, 1, true, false); else DRAG_ATTN_LAUNCH(NW, 1, false, false); } \
     else { if (qprep) DRAG_ATTN_LAUNCH(NW, 0, true, false); else DRAG_ATTN_LAUNCH(NW, 0, false, false); }                 \
   } while (0)
@@ -978,10 +995,11 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
               else hipLaunchKernelGGL((attention_d128_kernel<8, 1, false, true, true>), grid, dim3(512), 0, st, p); }
     else { if (qprep) hipLaunchKernelGGL((attention_d128_kernel<4, 1, true, true, true>), grid, dim3(256), 0, st, p);
            else hipLaunchKernelGGL((attention_d128_kernel<4, 1, false, true, true>), grid, dim3(256), 0, st, p); }
+#if DRAG_EXP
   } else if (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024) {
     if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attention_q64_kernel<false>), grid, dim3(256), 0, st, p);
-  } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 0 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&
+  } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 0 && fits32 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&
              nqb2 * groups > persist_slots()) {
     // EXPERIMENT, off by default ("attn_persist": 0 = off, 1 = one workgroup per CU, n >= 3 = n workgroups per XCD — tests: many items
     // per workgroup): the persistent form, whose K / V^T stream runs on across a workgroup's items (the KV loop is unrolled by two: an
@@ -994,6 +1012,7 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
     const dim3 pgrid(8 * persist_slots());
     if (qprep) hipLaunchKernelGGL((attention_d128_kernel<8, 1, true, true, false, true>), pgrid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((attention_d128_kernel<8, 1, false, true, false, true>), pgrid, dim3(512), 0, st, p);
+#endif  // DRAG_EXP
   } else if (w8) DRAG_ATTN_PICK(8); else DRAG_ATTN_PICK(4);
 #undef DRAG_ATTN_PICK
 #undef DRAG_ATTN_LAUNCH

@@ -1188,6 +1188,10 @@ extern "C" int drag_gemm_bf16_pair(const drag_gemm_args* a, const drag_gemm_args
   return gemm_launch(a, b, stream);
 }
 
+// which kernel drag_conv3x3_bf16 takes for M = B * Ho * Wo output pixels: 2 = the persistent 256x256 kernel, 0 = t128 (the convolutions use
+// use_t256 alone, not the ring kernels of gemm_choice) — for callers that account launches per kernel
+extern "C" int drag_conv3x3_bf16_choice(int64_t M, int Cout, int Cin) { return use_t256(M, 0, Cout, 9 * Cin) ? 2 : 0; }
+
 extern "C" int drag_conv3x3_bf16(const drag_conv_args* a, void* stream) {
   DRAG_CHECK(a != nullptr && a->x && a->w && a->y, "drag_conv3x3_bf16: null pointer");
   DRAG_CHECK(a->B > 0 && a->Ho > 0 && a->Wo > 0 && a->Hp > 0 && a->Wp > 0, "drag_conv3x3_bf16: bad shape");

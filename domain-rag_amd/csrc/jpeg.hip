@@ -61,11 +61,22 @@ __global__ __launch_bounds__(64) void jpeg_parse_kernel(const uint8_t* data, con
   jpeg_parse(data + off[i], off[i + 1] - off[i], &o);
   if (o.status == 0) {                               // the Huffman kernel keeps four code tables per lane: DC 0/1, AC 0/1,
     const uint8_t* d = data + off[i];                // and 16 symbol slots per DC table (8-bit JPEG has at most 12 categories)
-    for (int c = 0; c < o.ncomp; ++c) {
-      if (o.td[c] > 1 || o.ta[c] > 1) { o.status = JPEG_ERR_TABLES; break; }
-      int cnt = 0;
-      for (int l = 0; l < 16; ++l) cnt += d[o.dht_off[o.td[c]] + l];
-      if (cnt > 16) { o.status = JPEG_ERR_TABLES; break; }
+    if (o.progressive) {
+      // td / ta belong to the scans (jpeg_parse stops at the first SOS and leaves them 0): what can be checked here is every DC table
+      // defined BEFORE the first scan — jpeg_decode_progressive builds them unchecked (it checks the ones defined between scans itself)
+      for (int id = 0; id < 2; ++id) {
+        if (o.dht_off[id] < 0) continue;
+        int cnt = 0;
+        for (int l = 0; l < 16; ++l) cnt += d[o.dht_off[id] + l];
+        if (cnt > 16) { o.status = JPEG_ERR_TABLES; break; }
+      }
+    } else {
+      for (int c = 0; c < o.ncomp; ++c) {
+        if (o.td[c] > 1 || o.ta[c] > 1) { o.status = JPEG_ERR_TABLES; break; }
+        int cnt = 0;
+        for (int l = 0; l < 16; ++l) cnt += d[o.dht_off[o.td[c]] + l];
+        if (cnt > 16) { o.status = JPEG_ERR_TABLES; break; }
+      }
     }
   }
   info[i] = o;

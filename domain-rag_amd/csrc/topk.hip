@@ -507,7 +507,8 @@ inline int scan_grid(long long niter, int ntile) {
   // workgroups at most (speed only; 0 = the measured default: two resident workgroups per CU, each wave walks many groups with
   // the next group's first chunk prefetched — scan at Q = 16, N = 118 287: 40.2 us with 512, 41.8 with 1024, 46.9 with 1856)
   const int opt = drag_opt(DRAG_OPT_TOPK_GRID);
-  const long long cap = (long long)(min(opt > 0 ? opt : 512, 2048) / unit) * unit;
+  long long cap = (long long)(min(opt > 0 ? opt : 512, 2048) / unit) * unit;
+  if (cap < unit) cap = unit;                               // a "topk_grid" below one unit (a zero grid, and a division by zero downstream)
   return (int)(want < unit ? unit : (want > cap ? cap : want));
 }
 template <int NBUF, int QT>
@@ -529,7 +530,7 @@ int launch_scan_n(ScanArgs& sa, hipStream_t st) {
 // the L2 re-reads of the sibling form; only the longest, matrix-core-bound launch gains (7 %).  The default stays 1.
 // scan_qt(Q, d) is what the launcher and the candidate-region sizing both use.
 inline int scan_qt(int Q, int d) {
-  const int opt = drag_opt(DRAG_OPT_TOPK_QT);
+  const int opt = DRAG_EXP ? drag_opt(DRAG_OPT_TOPK_QT) : 0;
   int qt = opt > 0 ? opt : 1;
   if (qt != 1 && qt != 2 && qt != 4) qt = 1;
   while (qt > 1 && (qt * (d / 64) * 4096 + 4 * 2 * 4096 > 160 * 1024 || 16 * (qt / 2) >= Q)) qt >>= 1;    // LDS; no empty tiles
@@ -542,8 +543,10 @@ inline int scan_qt(int Q, int d) {
 int launch_scan(ScanArgs& sa, hipStream_t st) {
   const int qt = scan_qt(sa.Q, sa.d);
   sa.ntile = ((sa.Q + 15) / 16 + qt - 1) / qt;
+#if DRAG_EXP
   if (qt == 4) return launch_scan_n<2, 4>(sa, st);
   if (qt == 2) return launch_scan_n<2, 2>(sa, st);
+#endif
   if (drag_opt(DRAG_OPT_TOPK_DEPTH) == 3) return launch_scan_n<3, 1>(sa, st);
   return launch_scan_n<2, 1>(sa, st);
 }

@@ -44,9 +44,9 @@ class GemmRecorder:
             return "conv2d_f32_kernel"
         M, N, K = shape
         M1, M2 = (conv[1], conv[2]) if isinstance(conv, tuple) else (M, 0)
+        if conv is True:                                     # the 3x3 convolutions take t256 or t128 only, by their own predicate
+            return "gemm_bf16_t256<1>" if _lib.load().drag_conv3x3_bf16_choice(M, N, K // 9) == 2 else "gemm_bf16_t128<1>"
         code = _lib.load().drag_gemm_bf16_choice(M1, M2, N, K)
-        if conv is True:                                     # the 3x3 convolutions take t256 or t128 only
-            return "gemm_bf16_t256<1>" if code == 2 else "gemm_bf16_t128<1>"
         if code == 2:
             return "gemm_bf16_t256_pair" if M2 > 0 else "gemm_bf16_t256<0>"
         if code == 0:
@@ -84,6 +84,16 @@ def set_recorder(rec: GemmRecorder | None) -> None:
 def set_option(name: str, value: int) -> None:
     """measurement switch of the library (``drag_set_option``): "attn_sched", "attn_w4" """
     check(_lib.load().drag_set_option(name.encode(), int(value)), "drag_set_option")
+
+
+def experiments_built() -> bool:
+    """True when libdomainrag_hip.so was built with DRAG_EXPERIMENTS=1 (csrc/drag_common.h): only then does it carry the kernels behind
+    "attn_persist", "attn_q64", "attn_sched" = 3 and "topk_qt" — measured non-improvements kept for their A/B records, not product code"""
+    lib = _lib.load()
+    if lib.drag_set_option(b"attn_persist", 1) != 0:
+        return False
+    lib.drag_set_option(b"attn_persist", 0)
+    return True
 
 
 def _stream() -> int:

@@ -91,6 +91,8 @@ int drag_gemm_bf16_pair_merges(int M1, int M2, int N, int K);
  * kernel, 0 = the 128x128 kernel, else 100 * (192-column tiles) + 10 * MI + ST of gemm_bf16_deep<MI, ST, NI>.  Every choice computes the
  * same bits; the policy is a function of the launch shape only. */
 int drag_gemm_bf16_choice(int M1, int M2, int N, int K);
+/* the kernel drag_conv3x3_bf16 dispatches M = B*Ho*Wo output pixels x Cout x (9*Cin) to: 2 = the 256x256 kernel, 0 = the 128x128 one */
+int drag_conv3x3_bf16_choice(int64_t M, int Cout, int Cin);
 /* the policy's cost model for that launch: (tile rounds on the busiest CU) x (tile rows + tile columns), i.e. proportional to what the
  * busiest CU pulls through its L2 -> LDS path per K-step; comparable between launches of equal K.  0 under a forced "gemm_kernel". */
 int64_t drag_gemm_bf16_cost(int M1, int M2, int N, int K);

@@ -213,8 +213,10 @@ def test_topk_fuzz_with_ties_nonfinite_rows_and_every_measurement_option(gpu):
             if rng.random() < 0.3 and N > 10:
                 corpus[rng.integers(0, N)] = np.nan; corpus[rng.integers(0, N)] = np.inf; corpus[rng.integers(0, N), 0] = -np.inf
             q = rng.standard_normal((Q, d)).astype(np.float32)
-            opts = dict(zip(names, (int(rng.choice([0, 2, 4])), int(rng.choice([0, 256, 1024, 2048])), int(rng.choice([0, 3])),
+            opts = dict(zip(names, (int(rng.choice([0, 2, 4])), int(rng.choice([0, 16, 256, 1024, 2048])), int(rng.choice([0, 3])),
                                     int(rng.integers(0, 2)), int(rng.choice([0, 256, 1024])))))
+            if not ops.experiments_built():
+                opts["topk_qt"] = 0                 # several query tiles per workgroup: DRAG_EXPERIMENTS builds only
             for n_, v in opts.items():
                 ops.set_option(n_, v)
             D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(q).to(gpu), k)

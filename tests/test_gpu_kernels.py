@@ -225,9 +225,16 @@ def test_attention_schedules_are_bit_identical(gpu):
     vt = torch.empty((B, H, 128, s_pad), dtype=torch.bfloat16, device=gpu)
     ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
     outs = {}
+    combos = [(0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 0, 3, 0), (1, 0, 2, 0), (0, 1, 0, 0), (1, 1, 0, 0), (2, 1, 3, 0)]
+    if ops.experiments_built():      # the 4-wave x 64-query kernel and the V-one-step-ahead schedule: DRAG_EXPERIMENTS builds only
+        combos += [(2, 0, 0, 1), (2, 0, 2, 1), (3, 0, 2, 0), (3, 1, 3, 0)]
+    else:
+        with pytest.raises(RuntimeError, match="experiments"):
+            ops.set_option("attn_sched", 3)
+        with pytest.raises(RuntimeError, match="experiments"):
+            ops.set_option("attn_q64", 1)
     try:
-        for sched, w4, tune, q64 in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 0, 3, 0), (1, 0, 2, 0), (0, 1, 0, 0), (1, 1, 0, 0),
-                                     (2, 1, 3, 0), (2, 0, 0, 1), (2, 0, 2, 1), (3, 0, 2, 0), (3, 1, 3, 0)):
+        for sched, w4, tune, q64 in combos:
             ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4); ops.set_option("attn_tune", tune)
             ops.set_option("attn_q64", q64)
             o = torch.full((B, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
@@ -252,6 +259,10 @@ def test_persistent_attention_equals_the_one_item_kernel(gpu, B, S, H, s_txt):
     crosses many item seams, ragged last query blocks and key tiles included) and with one per CU"""
     from domain_rag_amd import ops
     from oracle import flux as oflux
+    if not ops.experiments_built():
+        with pytest.raises(RuntimeError, match="experiments"):
+            ops.set_option("attn_persist", 1)
+        pytest.skip("the persistent attention kernel is an experiment (measured 1 % slower): DRAG_EXPERIMENTS=1 builds carry it")
     D = H * 128
     qkv = _randn((B, S, 3 * D), 77 + S).to(gpu)
     g = torch.Generator().manual_seed(S)
@@ -281,6 +292,38 @@ def test_persistent_attention_equals_the_one_item_kernel(gpu, B, S, H, s_txt):
                 assert torch.equal(run(qp), ref[qp]), (slots, qp)
     finally:
         ops.set_option("attn_persist", 0)
+
+
+def test_attention_tensors_beyond_4_gib(gpu):
+    """the one-item-per-workgroup attention kernel addresses K and V^T through descriptors based at the item's (batch, head),
+    so only ONE (batch, head) has to stay below 2 GiB — a K tensor whose batches lie more than 4 GiB apart (B >= 48 at S = 5337 with
+    fused q|k|v) must work, and give the bits of the same batches computed one by one"""
+    from domain_rag_amd import ops
+    S, H = 300, 2
+    D = H * 128
+    stride = (5 << 30) // 2 + 8 * 3 * D                       # batch stride in elements: > 5 GiB in bytes
+    big = torch.empty(stride + S * 3 * D, dtype=torch.bfloat16, device=gpu)
+    parts = [_randn((1, S, 3 * D), 400 + b).to(gpu) for b in range(2)]
+    big[:S * 3 * D] = parts[0].view(-1)
+    big[stride:stride + S * 3 * D] = parts[1].view(-1)
+    s_pad = (S + 63) // 64 * 64
+    scale = 1 / math.sqrt(128)
+
+    def prep(x, B, bs):
+        vt = torch.empty((B, H, 128, s_pad), dtype=torch.bfloat16, device=gpu)
+        for b in range(B):            # (the prep pass takes dense batches: one call per batch)
+            xb = x[b * bs:b * bs + S * 3 * D].view(1, S, 3 * D)
+            ops.qk_norm_rope_vt(xb, vt[b:b + 1], None, None, None, None, None, None, 1, S, H, 3 * D, 0)
+        return vt
+    vt2 = prep(big, 2, stride)
+    o2 = torch.full((2, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
+    ops.attention(big, big[D:], vt2, o2, 2, S, H, 3 * D, stride, D, S * D, scale)
+    for b in range(2):
+        x = parts[b].clone()
+        vt = prep(x.view(-1), 1, 0)
+        o = torch.full((1, S, D), float("nan"), dtype=torch.bfloat16, device=gpu)
+        ops.attention(x, x.view(-1)[D:], vt, o, 1, S, H, 3 * D, S * 3 * D, D, S * D, scale)
+        assert torch.isfinite(o.float()).all() and torch.equal(o[0], o2[b]), b
 
 
 @pytest.mark.parametrize("B,S,H,s_txt", [(2, 4300, 2, 1241), (1, 5337, 1, 512), (3, 300, 2, 10), (2, 64, 1, 0), (1, 1753, 3, 77), (2, 129, 1, 129)])
@@ -424,9 +467,11 @@ def test_topk_threshold_and_selection_variants_give_the_same_answer(gpu):
     try:
         ref = {k: ops.cosine_topk(corpus, q, k) for k in (1, 100, 128, 129)}
         sc0 = ops.cosine_scores(corpus, q)
-        for opts in ({"topk_dense_sample": 1}, {"topk_select": 256}, {"topk_select": 1024}, {"topk_grid": 1024, "topk_depth": 3},
-                     {"topk_dense_sample": 1, "topk_select": 1024, "topk_grid": 2048}, {"topk_qt": 2}, {"topk_qt": 4},
-                     {"topk_qt": 4, "topk_grid": 1024}):
+        variants = [{"topk_dense_sample": 1}, {"topk_select": 256}, {"topk_select": 1024}, {"topk_grid": 1024, "topk_depth": 3},
+                    {"topk_dense_sample": 1, "topk_select": 1024, "topk_grid": 2048}, {"topk_grid": 16}]      # (a grid below one unit of workgroups is clamped)
+        if ops.experiments_built():
+            variants += [{"topk_qt": 2}, {"topk_qt": 4}, {"topk_qt": 4, "topk_grid": 1024}]
+        for opts in variants:
             for name, v in opts.items():
                 ops.set_option(name, v)
             for k, (D0, I0) in ref.items():
