@@ -73,6 +73,7 @@ struct GemmKArgs {
   void* C2;
   int ld2, n_split;
   int group_m;    // M tiles per group of the tile walk (8; "gemm_group_m" option for measurements)
+  int epi_generic; // "gemm_epilogue" = 1: every tile takes the general staged epilogue (tests compare it with the specialised one bit for bit)
   // optional second row segment (drag_gemm_bf16_pair): M tiles >= seg_tiles_m belong to a second problem with its own operands and
   // row maps but the same N, K and epilogue form — a double block's text and image Linears as ONE launch of the non-persistent kernels
   int seg_tiles_m;          // 0: one segment
@@ -342,10 +343,110 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
   }
 }
 
+// Fast form of the staged epilogue for the common tile: interior, inside ONE batch of the output's row map, four column blocks per wave
+// that are all alike (activation on all of them or on none).  Same arithmetic, operation for operation, as staged_rows — what goes is
+// everything staged_rows decides at run time per row block (residual? gate? which columns are activated? does the tile cross a batch?
+// the row map's integer division per store when it does): the ablations of round 4 (profiles/r04_gemm_epilogue_ablations.log) put the
+// epilogue at 10 % of a K = 3072 tile with only 1.5-2.6 % of it in the LDS transpose and < 2 % in HBM writes — the rest is its own
+// instruction stream.  FORM: 0 = y, 1 = resid + y, 3 = resid + gate * y;  ACT: the activation applies to every column of the tile.
+template <int MI, int FORM, bool ACT>
+__device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long off0, int bidx, int nw0, int l, f32x4_t (*acc)[4], char* scr) {
+  const int q = l >> 4, r16 = l & 15;
+  const int c = l & 7, rl = l >> 3;
+  const ActCoef ac = act_coef(p.act);
+  float bias[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    bias[ni][0] = bias[ni][1] = bias[ni][2] = bias[ni][3] = 0.f;
+    if (p.bias) {
+      const u32x2_t bb = *(const u32x2_t*)(p.bias + nw0 + ni * 16 + q * 4);
+      bias[ni][0] = bf_lo(bb[0]); bias[ni][1] = bf_hi(bb[0]); bias[ni][2] = bf_lo(bb[1]); bias[ni][3] = bf_hi(bb[1]);
+    }
+  }
+  int woff[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+    woff[ni] = r16 * 128 + (((2 * ni + (q >> 1)) ^ (r16 & 7)) << 4) + (((q & 1) ^ (r16 >> 3)) << 3);
+  const int roff = rl * 128 + ((c ^ rl) << 4);
+  const int n = nw0 + c * 8;
+  float g[8];
+  if constexpr (FORM == 3) {
+    const u32x4_t gg = *(const u32x4_t*)(p.gate + (long long)bidx * p.ldg + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[2 * i] = bf_lo(gg[i]); g[2 * i + 1] = bf_hi(gg[i]); }
+  }
+  // row (mi, j, rl) of the wave's sub-tile lives at off0 + (16 mi + 8 j + rl) * ld: a wave-uniform base per (mi, j) + one 32-bit lane offset
+  const unsigned lane_off = (unsigned)(rl * p.cm.ld + n);
+  bf16_t* const Cb = (bf16_t*)p.C + off0;
+  const bf16_t* const Rb = FORM ? p.resid + off0 : nullptr;
+  constexpr int RD = MI < 2 ? MI : 2;
+  u32x4_t rres[RD][2];
+  auto load_resid = [&](int mi2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rres[mi2 % RD][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off);
+  };
+  if constexpr (FORM != 0) {
+#pragma unroll
+    for (int mi = 0; mi < RD; ++mi) load_resid(mi);
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float v[4] = {acc[mi][ni][0] + bias[ni][0], acc[mi][ni][1] + bias[ni][1], acc[mi][ni][2] + bias[ni][2], acc[mi][ni][3] + bias[ni][3]};
+      if constexpr (ACT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = rbf(v[r]);
+          v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
+        }
+      }
+      u32x2_t o;
+      o[0] = pack2bf(v[0], v[1]);
+      o[1] = pack2bf(v[2], v[3]);
+      *(u32x2_t*)(scr + woff[ni]) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4_t y = *(const u32x4_t*)(scr + roff + j * 1024);
+      if (j == 1) y = (u32x4_t){y[2], y[3], y[0], y[1]};
+      if constexpr (FORM != 0) {
+        const u32x4_t x = rres[mi % RD][j];
+        if constexpr (FORM == 3) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            y[i] = pack2bf(bf_lo(x[i]) + rbf(g[2 * i] * bf_lo(y[i])), bf_hi(x[i]) + rbf(g[2 * i + 1] * bf_hi(y[i])));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = pack2bf(bf_lo(x[i]) + bf_lo(y[i]), bf_hi(x[i]) + bf_hi(y[i]));
+        }
+      }
+      *(u32x4_t*)(Cb + (long long)(mi * 16 + j * 8) * p.cm.ld + lane_off) = y;
+    }
+    if constexpr (FORM != 0) {
+      if (mi + RD < MI) load_resid(mi + RD);
+    }
+  }
+}
+
 template <int MI, int TM, int TN = TM, int NI = 4>
 __device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[NI],
                                                 char* scr) {
   constexpr int G0 = NI < 4 ? NI : 4;
+  if constexpr (NI == 4) {
+    const int b_first = m0 / p.cm.rpb;
+    const bool fast = m0 + TM <= p.M && n0 + TN <= p.N && b_first == (m0 + TM - 1) / p.cm.rpb && (long long)8 * p.cm.ld + p.N < (1ll << 31);
+    const bool act_none = p.act == DRAG_ACT_NONE || p.act_n0 >= n0 + TN, act_all = p.act != DRAG_ACT_NONE && p.act_n0 <= n0;
+    if (fast && !p.epi_generic && (act_none || (act_all && !p.resid)) && !(p.gate && !p.resid)) {
+      const long long off0 = p.cm.off(mw0);
+      if (!p.resid) {
+        if (act_none) staged_rows_fast<MI, 0, false>(p, off0, b_first, nw0, l, acc, scr);
+        else staged_rows_fast<MI, 0, true>(p, off0, b_first, nw0, l, acc, scr);
+      } else if (p.gate) staged_rows_fast<MI, 3, false>(p, off0, b_first, nw0, l, acc, scr);
+      else staged_rows_fast<MI, 1, false>(p, off0, b_first, nw0, l, acc, scr);
+      return;
+    }
+  }
   if (m0 + TM <= p.M && n0 + TN <= p.N) {
     staged_rows<MI, TM, false, NI, 0, G0>(p, m0, mw0, n0, nw0, l, acc, scr);
     if constexpr (NI > 4) staged_rows<MI, TM, false, NI, 4, NI - 4>(p, m0, mw0, n0, nw0 + 64, l, acc, scr);
@@ -1015,6 +1116,7 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   // M tiles per group of the tile walk: the 32 concurrent tiles of an XCD form a group_m x (32 / group_m) super-tile.  4 and 8 tie on
   // the K = 3072 shapes (8 ahead by 1-3 % at N = 3072), 4 is 2-3 % ahead at K >= 12288; 16 / 32 (towards W-stationary) lose 5-10 %
   // everywhere (scripts/bench_gemm_group_m.py, two boxes).  Order only: the bits do not depend on it.
+  k.epi_generic = drag_opt(DRAG_OPT_GEMM_EPILOGUE) == 1;
   k.group_m = drag_opt(DRAG_OPT_GEMM_GROUP_M) > 0 ? drag_opt(DRAG_OPT_GEMM_GROUP_M) : (K >= 8192 ? 4 : 8);
   static const bool narrow = env_flag("DRAG_GEMM_NARROW");
   k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&

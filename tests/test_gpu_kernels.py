@@ -637,6 +637,42 @@ def test_gemm_kernels_are_bit_identical(gpu, M, N, K):
             assert torch.equal(x, y), (code, i)
 
 
+@pytest.mark.parametrize("M,N,K,rpb", [(2560, 1024, 256, 1280), (2304, 1100, 320, 2304), (5337 * 2, 768, 256, 5337), (4100, 3072, 512, 4100), (1536, 512, 256, 512)])
+def test_specialised_epilogue_equals_the_general_one(gpu, M, N, K, rpb):
+    """round 4: interior tiles inside one batch take a specialised, branch-free epilogue (csrc/gemm_bf16.hip staged_rows_fast: plain / bias,
+    bias + activation on every column, residual, gate + residual); "gemm_epilogue" = 1 sends every tile through the general one.  Same
+    arithmetic operation for operation: the outputs must be identical for every kernel family, with tiles that cross a batch of the row
+    map (rpb not a multiple of the tile), ragged edges, activation starting inside the matrix (act_n0) and with no bias at all"""
+    from domain_rag_amd import ops
+    a, w, b = _randn((M, K), 31).to(gpu), _randn((N, K), 32, 0.05).to(gpu), _randn((N,), 33).to(gpu)
+    nb = M // rpb
+    gate, resid = _randn((nb, N), 34).to(gpu), _randn((M, N), 35).to(gpu)
+
+    def run_all():
+        outs = [ops.gemm(a, w), ops.gemm(a, w, bias=b), ops.gemm(a, w, bias=b, act=ops.ACT_GELU_TANH),
+                ops.gemm(a, w, bias=b, act=ops.ACT_SILU, act_n0=(N // 2) // 256 * 256), ops.gemm(a, w, bias=b, act=ops.ACT_GELU_TANH, act_n0=(N // 3) // 4 * 4)]
+        x = resid.clone()
+        ops.gemm(a, w, out=x, bias=b, M=M, lda=K, ldc=N, c_rows_per_batch=rpb, c_batch_stride=rpb * N, gate=gate, resid=x, ldg=N)
+        outs.append(x)
+        y = resid.clone()
+        ops.gemm(a, w, out=y, M=M, lda=K, ldc=N, resid=y)
+        outs.append(y)
+        return [o.cpu() for o in outs]
+
+    codes = [0, 1, 43, 23, 14] + ([2] if N >= 256 and K >= 256 else [])
+    try:
+        for code in codes:
+            ops.set_option("gemm_kernel", code)
+            ops.set_option("gemm_epilogue", 1)
+            ref = run_all()
+            ops.set_option("gemm_epilogue", 0)
+            got = run_all()
+            for i, (x, y) in enumerate(zip(ref, got)):
+                assert torch.isfinite(x.float()).all() and torch.equal(x, y), (code, i)
+    finally:
+        ops.set_option("gemm_kernel", 0); ops.set_option("gemm_epilogue", 0)
+
+
 @pytest.mark.parametrize("M1,M2,N,K", [(1024, 512, 768, 256), (1000, 77, 520, 192), (300, 1300, 1536, 320), (40, 24, 384, 128), (2304, 1100, 1024, 256)])
 def test_gemm_pair_equals_two_gemms(gpu, M1, M2, N, K):
     """round 3: drag_gemm_bf16_pair — a double block's image-stream and text-stream Linears (own A, W, bias, gate, residual, output
