@@ -22,15 +22,16 @@ for (M, N, K, form) in [(42696, 9216, 3072, "bias"), (42696, 12288, 3072, "gelu"
         elif form == "bias": ops.gemm(A, W, out=C, bias=b)
         elif form == "gelu": ops.gemm(A, W, out=C, bias=b, act=ops.ACT_GELU_TANH)
         else: ops.gemm(A, W, out=C, bias=b, M=M, lda=K, ldc=N, c_rows_per_batch=S if M == B * S else M, c_batch_stride=S * N, gate=gate, resid=x0, ldg=N)
-    best = {"0": 1e9, "1": 1e9}
+    VARS = tuple(os.environ.get("VARS", "1,0").split(","))
+    best = {v: 1e9 for v in VARS}
     outs = {}
     for rnd in range(4):
-        for d in ("1", "0"):
+        for d in VARS:
             ops.set_option("gemm_epilogue", int(d))
             best[d] = min(best[d], bench(run))
-    for d in ("1", "0"):
+    for d in VARS:
         ops.set_option("gemm_epilogue", int(d))
         C.zero_(); run(); outs[d] = C.clone()
     tf = {k: 2 * M * N * K / v / 1e9 for k, v in best.items()}
-    print(f"gemm {M}x{N}x{K} {form}: generic {tf['1']:.0f}  specialised {tf['0']:.0f} TFLOP/s ({100 * (tf['0'] / tf['1'] - 1):+.1f} %) same bits: {torch.equal(outs['0'], outs['1'])}", flush=True)
+    print(f"gemm {M}x{N}x{K} {form}: gemm_epilogue={VARS[0]}: {tf[VARS[0]]:.0f}  gemm_epilogue={VARS[1]}: {tf[VARS[1]]:.0f} TFLOP/s ({100 * (tf[VARS[1]] / tf[VARS[0]] - 1):+.1f} %) same bits: {torch.equal(outs[VARS[0]], outs[VARS[1]])}", flush=True)
     del A, W, C, x0
