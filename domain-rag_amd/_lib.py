@@ -6,6 +6,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libdomainrag_hip.so")
+if os.environ.get("DRAG_LIB"):          # A/B across builds of the library (scripts/): another libdomainrag_hip.so, same ABI
+    LIB_PATH = os.environ["DRAG_LIB"]
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 

@@ -12,12 +12,12 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() { echo "== $*" >&2; "$@"; }
-run rocprofv3 --kernel-trace -d "$OUT" -o bench -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+run rocprofv3 --kernel-trace -d "$OUT" -o bench -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-side-configs > "$OUT/bench_under_rocprof.log" 2>&1
 python "$R/scripts/rocpd_stats.py" "$OUT/bench_results.db" > "$OUT/kernel_stats_bench_default.txt" 2>&1
 run rocprofv3 --kernel-trace -d "$OUT" -o retr -- python "$R/bench.py" --workload retrieval --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/retrieval_under_rocprof.log" 2>&1
 python "$R/scripts/rocpd_stats.py" "$OUT/retr_results.db" > "$OUT/kernel_stats_bench_retrieval.txt" 2>&1
-run rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT" -o fetch -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
-run rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT" -o write -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
+run rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT" -o fetch -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-side-configs > "$OUT/pmc_fetch.log" 2>&1
+run rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT" -o write -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-side-configs > "$OUT/pmc_write.log" 2>&1
 python "$R/scripts/rocpd_pmc.py" "$OUT/fetch_results.db" "$OUT/write_results.db" "$OUT/pmc_traffic.json" > "$OUT/pmc_passes_summary.txt" 2>&1
 # retrieval scan: FETCH_SIZE calibrated on the kernel's own access pattern (guide: "calibrate on a known byte count in your own access
 # pattern"): one pass over scan-only launches at N = 1 000 000 (2.05 GB per launch, 8x the Infinity Cache) gives the factor, the passes
