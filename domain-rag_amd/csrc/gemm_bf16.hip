@@ -383,7 +383,7 @@ __device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long o
   u32x4_t rres[RD][2];
   auto load_resid = [&](int mi2) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { if (p.epi_generic == 3) rres[mi2 % RD][j] = (u32x4_t){0u, 0u, 0u, 0u}; else rres[mi2 % RD][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off); }
+    for (int j = 0; j < 2; ++j) rres[mi2 % RD][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off);
   };
   if constexpr (FORM != 0) {
 #pragma unroll
@@ -413,7 +413,6 @@ __device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long o
       if constexpr (FORM != 0) {
         const u32x4_t x = rres[mi % RD][j];
         if constexpr (FORM == 3) {
-          if (p.epi_generic == 4) { asm volatile("" ::"v"(x)); } else
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             y[i] = pack2bf(bf_lo(x[i]) + rbf(g[2 * i] * bf_lo(y[i])), bf_hi(x[i]) + rbf(g[2 * i + 1] * bf_hi(y[i])));
@@ -438,7 +437,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int 
     const int b_first = m0 / p.cm.rpb;
     const bool fast = m0 + TM <= p.M && n0 + TN <= p.N && b_first == (m0 + TM - 1) / p.cm.rpb && (long long)8 * p.cm.ld + p.N < (1ll << 31);
     const bool act_none = p.act == DRAG_ACT_NONE || p.act_n0 >= n0 + TN, act_all = p.act != DRAG_ACT_NONE && p.act_n0 <= n0;
-    if (fast && p.epi_generic != 1 && (act_none || (act_all && !p.resid)) && !(p.gate && !p.resid)) {
+    if (fast && !p.epi_generic && (act_none || (act_all && !p.resid)) && !(p.gate && !p.resid)) {
       const long long off0 = p.cm.off(mw0);
       if (!p.resid) {
         if (act_none) staged_rows_fast<MI, 0, false>(p, off0, b_first, nw0, l, acc, scr);
@@ -1117,7 +1116,7 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   // M tiles per group of the tile walk: the 32 concurrent tiles of an XCD form a group_m x (32 / group_m) super-tile.  4 and 8 tie on
   // the K = 3072 shapes (8 ahead by 1-3 % at N = 3072), 4 is 2-3 % ahead at K >= 12288; 16 / 32 (towards W-stationary) lose 5-10 %
   // everywhere (scripts/bench_gemm_group_m.py, two boxes).  Order only: the bits do not depend on it.
-  k.epi_generic = drag_opt(DRAG_OPT_GEMM_EPILOGUE);
+  k.epi_generic = drag_opt(DRAG_OPT_GEMM_EPILOGUE) == 1;
   k.group_m = drag_opt(DRAG_OPT_GEMM_GROUP_M) > 0 ? drag_opt(DRAG_OPT_GEMM_GROUP_M) : (K >= 8192 ? 4 : 8);
   static const bool narrow = env_flag("DRAG_GEMM_NARROW");
   k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&
