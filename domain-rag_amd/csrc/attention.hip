@@ -573,6 +573,26 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
 #define Q64_SETTLE_S(s4) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s4[0][0]), "+v"(s4[0][1]), "+v"(s4[1][0]), "+v"(s4[1][1]))
 #define Q64_SETTLE_O(o, qg) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[qg][0]), "+a"(o[qg][1]), "+a"(o[qg][2]), "+a"(o[qg][3]))
 
+// pieces of the hand-placed stream (round 4): every one is ONE instruction hipcc neither moves nor waits for
+template <int OFF>
+__device__ __forceinline__ void q64_lds_read(bf16x8_t& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N>
+__device__ __forceinline__ void q64_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void q64_fma(float& y, float s, float c, float nm) { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(s), "s"(c), "v"(nm)); }
+__device__ __forceinline__ void q64_exp(float& e, float y) { asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(y)); }
+__device__ __forceinline__ void q64_add(float& d, float a, float b) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void q64_max3(float& d, float a, float b, float c) { asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); }
+__device__ __forceinline__ void q64_cvt(uint32_t& w, float a, float b) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b)); }
+// P V: the packed P words were written >= one step (dozens of instructions) before: no VALU -> MFMA wait states to pad
+#define Q64P_MFMA_O(d, a, pw) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(pw))
+template <class F, int G = 0>
+__device__ __forceinline__ void q64_unroll16(F&& f) {
+  if constexpr (G < 16) {
+    f(std::integral_constant<int, G>{});
+    q64_unroll16<F, G + 1>(f);
+  }
+}
+
 template <bool QPREP>
 __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
@@ -728,13 +748,59 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
 #pragma unroll
   for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(scur[qg], 0);
 
-  auto body = [&](const int it, auto par, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2]) {
+  // ---- round 4: the KV loop as a HAND-PLACED instruction stream.  One wave per SIMD issues in order: two MFMAs back to back stall the wave
+  // for the 28 cycles the first one still occupies the pipe, and nothing behind them issues — the round-2 form of this loop (hipcc's order
+  // between sched_barriers: PV PV reads QK QK, then the step's 18 VALU as one block) kept the pipe busy 42 % of the time (PMC).  Here every
+  // MFMA is followed by its share of the step's other work — at most 5 single-issue instructions per gap, what a lone wave hides behind
+  // a 32-cycle MFMA: the step's 14 softmax VALU in a hazard-free order (a transcendental's input / result is never produced / consumed by
+  // the neighbouring instruction), the two fragment reads of step g + 2 (the reads run TWO steps ahead: nobody else covers a lone wave's
+  // LDS latency) and one LDS-DMA piece.  Everything is `asm volatile`: hipcc keeps the order and inserts no waits; lgkmcnt is counted by hand.
+  // Same arithmetic per query group as before: same bits as the 8-wave kernel.
+  // The last key group's P V (8 MFMAs on fragments and P words already in registers) and the row maxima of the tile that follows are
+  // one block at the TOP of the next iteration: behind the barrier, with the first K fragment reads of the new tile already issued, the
+  // eight MFMAs cover both the reads' latency and the 32 v_max3 of the two row-maximum trees (4 per gap).
+  bf16x8_t vtr[4];              // the four V^T fragments of the trailing P V MFMAs (read in steps 14 / 15, used after the next barrier)
+  u32x4_t pk[2][4];             // packed P: key group kg of a tile is consumed in its steps 4 kg + 4 .. 4 kg + 7, group 3 after the next barrier
+  auto body = [&](const int it, auto par, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2], auto firstc) {
     constexpr int PAR = decltype(par)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
     constexpr int KN = ((PAR + 1) & 1) * KT_BYTES;
     constexpr int VB = 2 * KT_BYTES + PAR * VT_BYTES;
     const int kv0 = it * 64;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
+    bf16x8_t kfr[3], vfr[3];      // fragment rings (step g uses slot g % 3)
+    // K(0), K(1) of the next tile first: their latency hides behind the block below
+    q64_lds_read<KN>(kfr[0], lds0 + (unsigned)ak[0]);
+    q64_lds_read<KN>(kfr[1], lds0 + (unsigned)ak[1]);
+    if constexpr (!FIRST) {
+      // row maxima of sc (32 scores per lane and query group) as two v_max3 trees: 10 + 4 + 2 instructions each, group A and B interleaved
+      float ta[10], tb[10], ua[4], ub[4], ra, rb;
+      auto el = [&](int qg, int i) -> float { return sc[qg][i >> 4][i & 15]; };
+      auto L1 = [&](float* t, int qg, int i) { q64_max3(t[i], el(qg, 3 * i), el(qg, 3 * i + 1), el(qg, 3 * i + 2)); };
+      auto L2 = [&](float* u, const float* t, int qg, int i) {
+        if (i < 3) q64_max3(u[i], t[3 * i], t[3 * i + 1], t[3 * i + 2]);
+        else q64_max3(u[3], t[9], el(qg, 30), el(qg, 31));
+      };
+#define Q64P_T(dt, qg) Q64P_MFMA_O(oacc[qg][dt], vtr[dt], pk[qg][3])
+      Q64P_T(0, 0); L1(ta, 0, 0); L1(ta, 0, 1); L1(ta, 0, 2); L1(ta, 0, 3);
+      Q64P_T(0, 1); L1(ta, 0, 4); L1(ta, 0, 5); L1(ta, 0, 6); L1(ta, 0, 7);
+      Q64P_T(1, 0); L1(ta, 0, 8); L1(ta, 0, 9); L1(tb, 1, 0); L1(tb, 1, 1);
+      Q64P_T(1, 1); L1(tb, 1, 2); L1(tb, 1, 3); L1(tb, 1, 4); L1(tb, 1, 5);
+      Q64P_T(2, 0); L1(tb, 1, 6); L1(tb, 1, 7); L1(tb, 1, 8); L1(tb, 1, 9);
+      Q64P_T(2, 1); L2(ua, ta, 0, 0); L2(ua, ta, 0, 1); L2(ua, ta, 0, 2); L2(ua, ta, 0, 3);
+      Q64P_T(3, 0); L2(ub, tb, 1, 0); L2(ub, tb, 1, 1); L2(ub, tb, 1, 2); L2(ub, tb, 1, 3);
+      Q64P_T(3, 1); q64_max3(ra, ua[0], ua[1], ua[2]); q64_max3(rb, ub[0], ub[1], ub[2]);
+#undef Q64P_T
+      ra = fmaxf(ra, ua[3]); rb = fmaxf(rb, ub[3]);
+      mt_carry[0] = fmaxf(ra, __shfl_xor(ra, 32, 64));
+      mt_carry[1] = fmaxf(rb, __shfl_xor(rb, 32, 64));
+      if (kv0 + 64 > p.S) {       // the ragged last tile: keys >= S do not exist (the trees above saw them) — once per (batch, head, query block)
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(sc[qg], kv0);
+      }
+    }
     float nmc[2];
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
@@ -753,65 +819,75 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       nmc[qg] = -(m_run[qg] * p.c);
     }
     float ps[2] = {0.f, 0.f};
-    u32x4_t pk[2][4];
-    {
-      bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[0] + KN));
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const bf16x8_t kcur = kf;
-        if (g < 15) {
-          const int t1 = (g + 1) >> 3, ks1 = (g + 1) & 7;
-          kf = *(const bf16x8_t*)(smem + (ak[ks1] + (KN + t1 * (32 * 256))));
-        }
-        bf16x8_t vfg;
-        if (g >= 4) vfg = *(const bf16x8_t*)(smem + (av[(g >> 2) - 1] + (VB + (g & 3) * (32 * 128))));
-#pragma unroll
-        for (int qg = 0; qg < 2; ++qg) {
-          if ((g & 7) == 0) Q64_MFMA_S0(sn[qg][g >> 3], kcur, qa[qg][g & 7]);
-          else Q64_MFMA_S(sn[qg][g >> 3], kcur, qa[qg][g & 7]);
-        }
-        if (g < CPW) stage_k1(PAR, kv0 + 128, g);
-        else if (g < 2 * CPW) stage_v1((PAR + 1) & 1, kv0 + 64, g - CPW);
-#pragma unroll
-        for (int qg = 0; qg < 2; ++qg) {
-          float y0, y1;
-          asm volatile("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %5"
-                       : "=&v"(y0), "=&v"(y1) : "v"(sc[qg][g >> 3][(2 * g) & 15]), "v"(sc[qg][g >> 3][((2 * g) & 15) + 1]), "s"(p.c), "v"(nmc[qg]));
-          const float e0 = __builtin_amdgcn_exp2f(y0);
-          const float e1 = __builtin_amdgcn_exp2f(y1);
-          ps[qg] += e0 + e1;
-          uint32_t wd = pack2bf(e0, e1);
-          asm volatile("" : "+v"(wd), "+v"(ps[qg]));
-          pk[qg][g >> 2][g & 3] = wd;
-        }
-        if (g >= 4) {
-#pragma unroll
-          for (int qg = 0; qg < 2; ++qg) {
-            const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pk[qg][(g >> 2) - 1]);
-            Q64_MFMA_O(oacc[qg][g & 3], vfg, pfr);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    // one step; G is a compile-time constant (ring slots, immediate offsets, which pieces exist)
+    auto step = [&](auto gc) {
+      constexpr int G = decltype(gc)::value;
+      constexpr int T = G >> 3, E0 = (2 * G) & 15;
+      // reads issued in step s (in order): K(s+2) if s+2 <= 15; V(s+2) if 4 <= s+2 <= 15; the 4 trailing fragments in steps 14 / 15
+      constexpr int prev = G - 1;
+      constexpr int younger = prev < 0 ? 1 : ((prev + 2 <= 15) + (prev + 2 >= 4 && prev + 2 <= 15) + (prev >= 14 ? 2 : 0));
+      q64_lgkmcnt<younger>();                                   // K(G) (and V(G)) landed; step G-1's reads stay in flight
+      float yA0, yA1, yB0, yB1, eA0, eA1, eB0, eB1, sA, sB;
+      uint32_t wA, wB;
+      auto readK = [&]() { if constexpr (G + 2 <= 15) q64_lds_read<KN + ((G + 2) >> 3) * (32 * 256)>(kfr[(G + 2) % 3], lds0 + (unsigned)ak[(G + 2) & 7]); };
+      auto readV = [&]() {
+        if constexpr (G + 2 >= 4 && G + 2 <= 15) q64_lds_read<VB + ((G + 2) & 3) * (32 * 128)>(vfr[(G + 2) % 3], lds0 + (unsigned)av[((G + 2) >> 2) - 1]);
+        if constexpr (G == 14) { q64_lds_read<VB + 0 * (32 * 128)>(vtr[0], lds0 + (unsigned)av[3]); q64_lds_read<VB + 1 * (32 * 128)>(vtr[1], lds0 + (unsigned)av[3]); }
+        if constexpr (G == 15) { q64_lds_read<VB + 2 * (32 * 128)>(vtr[2], lds0 + (unsigned)av[3]); q64_lds_read<VB + 3 * (32 * 128)>(vtr[3], lds0 + (unsigned)av[3]); }
+      };
+      auto dma = [&]() { if constexpr (G < CPW) stage_k1(PAR, kv0 + 128, G); else if constexpr (G < 2 * CPW) stage_v1((PAR + 1) & 1, kv0 + 64, G - CPW); };
+      // the softmax slice of this step in issue order V1..V14 (A = query group 0, B = group 1)
+      auto V1 = [&]() { q64_fma(yA0, sc[0][T][E0], p.c, nmc[0]); };
+      auto V2 = [&]() { q64_fma(yA1, sc[0][T][E0 + 1], p.c, nmc[0]); };
+      auto V3 = [&]() { q64_exp(eA0, yA0); };
+      auto V4 = [&]() { q64_fma(yB0, sc[1][T][E0], p.c, nmc[1]); };
+      auto V5 = [&]() { q64_exp(eA1, yA1); };
+      auto V6 = [&]() { q64_fma(yB1, sc[1][T][E0 + 1], p.c, nmc[1]); };
+      auto V7 = [&]() { q64_add(sA, eA0, eA1); };
+      auto V8 = [&]() { q64_exp(eB0, yB0); };
+      auto V9 = [&]() { q64_add(ps[0], ps[0], sA); };
+      auto V10 = [&]() { q64_exp(eB1, yB1); };
+      auto V11 = [&]() { q64_cvt(wA, eA0, eA1); };
+      auto V12 = [&]() { q64_add(sB, eB0, eB1); };
+      auto V13 = [&]() { q64_add(ps[1], ps[1], sB); };
+      auto V14 = [&]() { q64_cvt(wB, eB0, eB1); };
+      if constexpr (G >= 4) {
+        Q64P_MFMA_O(oacc[0][G & 3], vfr[G % 3], pk[0][(G >> 2) - 1]);
+        readK(); V1(); V2(); V3();
+        Q64P_MFMA_O(oacc[1][G & 3], vfr[G % 3], pk[1][(G >> 2) - 1]);
+        readV(); V4(); V5(); V6();
+        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[0][T], kfr[G % 3], qa[0][G & 7]); else Q64_MFMA_S(sn[0][T], kfr[G % 3], qa[0][G & 7]);
+        dma(); V7(); V8(); V9(); V10();
+        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[1][T], kfr[G % 3], qa[1][G & 7]); else Q64_MFMA_S(sn[1][T], kfr[G % 3], qa[1][G & 7]);
+        V11(); V12(); V13(); V14();
+      } else {
+        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[0][T], kfr[G % 3], qa[0][G & 7]); else Q64_MFMA_S(sn[0][T], kfr[G % 3], qa[0][G & 7]);
+        readK(); readV(); V1(); V2(); V3(); V4(); V5(); V6(); V7();
+        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[1][T], kfr[G % 3], qa[1][G & 7]); else Q64_MFMA_S(sn[1][T], kfr[G % 3], qa[1][G & 7]);
+        dma(); V8(); V9(); V10(); V11(); V12(); V13(); V14();
       }
-    }
+      pk[0][G >> 2][G & 3] = wA;
+      pk[1][G >> 2][G & 3] = wB;
+    };
+    q64_unroll16(step);
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) l_run[qg] += ps[qg];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const bf16x8_t vf = *(const bf16x8_t*)(smem + (av[3] + (VB + dt * (32 * 128))));
-#pragma unroll
-      for (int qg = 0; qg < 2; ++qg) {
-        const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pk[qg][3]);
-        Q64_MFMA_O(oacc[qg][dt], vf, pfr);
-      }
-    }
-    Q64_SETTLE_S(sn);
-#pragma unroll
-    for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(sn[qg], kv0 + 64);
+    q64_lgkmcnt<0>();                                           // the trailing fragments landed: every read of this tile's buffers is complete
   };
-  for (int it = 0; it < nkv; it += 2) {
-    body(it, std::integral_constant<int, 0>{}, scur, snext);
-    if (it + 1 < nkv) body(it + 1, std::integral_constant<int, 1>{}, snext, scur);
+  {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    body(0, P0{}, scur, snext, std::true_type{});                // (the first tile's row maxima come from the prologue)
+    if (nkv > 1) body(1, P1{}, snext, scur, std::false_type{});
+    for (int it = 2; it < nkv; it += 2) {
+      body(it, P0{}, scur, snext, std::false_type{});
+      if (it + 1 < nkv) body(it + 1, P1{}, snext, scur, std::false_type{});
+    }
+    // the last tile's last key group
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg) Q64P_MFMA_O(oacc[qg][dt], vtr[dt], pk[qg][3]);
   }
 
 #pragma unroll
