@@ -375,8 +375,8 @@ def _pmc_mfma_util():
             with open(path) as f:
                 pm = json.load(f)
             out = {"source": os.path.relpath(path, ROOT)}
-            for label, sub in (("gemm_bf16_t256<0>", "gemm_bf16_t256ILi0"), ("attention_d128_kernel<8,...>", "attention_d128_kernelILi8")):
-                key = next(k for k in pm if sub in k)
+            for label, subs in (("gemm_bf16_t256<0>", ("gemm_bf16_t256ILi0",)), ("attention", ("attention_q64_kernel", "attention_d128_kernelILi8"))):
+                key = next(k for sub in subs for k in pm if sub in k)          # (the 64-query kernel since round 4)
                 r = pm[key]
                 out[label] = {"mfma_util": r["mfma_util"], "clock_ghz": r["clock_ghz"], "avg_us_profiled": r["avg_us_profiled"],
                               "wave_parked_frac": r.get("sq_wait_any_per_wave_cycle"), "wave_issue_stall_frac": r.get("sq_wait_inst_any_per_wave_cycle"),

@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libdomainrag_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
          "-ffp-contract=on"]
-# DRAG_EXPERIMENTS=1: also compile the kernels behind the experiment switches (attn_persist, attn_q64, attn_sched 3, topk_qt: measured
+# DRAG_EXPERIMENTS=1: also compile the kernels behind the experiment switches (attn_persist, attn_sched 3, topk_qt: measured
 # non-improvements, kept for their A/B records — csrc/drag_common.h); the flag is part of every object's digest, so switching rebuilds
 if os.environ.get("DRAG_EXPERIMENTS", "") not in ("", "0"):
     FLAGS.append("-DDRAG_EXPERIMENTS")

@@ -554,11 +554,16 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
 
 
 // --------------------------------------------------------------------------------------------
-#if DRAG_EXP
-// EXPERIMENT (drag_set_option "attn_q64"): 4 waves x 64 queries, ONE wave per SIMD with the whole 512-entry register file.
+// attention_q64_kernel — 4 waves x 64 queries, ONE wave per SIMD with the whole 512-entry register file: the kernel of the long
+// sequences (S >= 4096: the DiT's joint attention) since round 4.
 // Each wave owns two 32-query groups and runs both against every K / V^T fragment it reads, which halves the LDS fragment
-// reads per flop (the 8-wave kernel's other cost besides the exp stream).  Same arithmetic per query group, same deferred-
-// rescale decisions (taken per group), so the outputs equal the 8-wave kernel's bit for bit.  Schedule = SCHED 1 + PMAX.
+// reads per flop.  Same arithmetic per query group, same deferred-rescale decisions (taken per group), so the outputs equal the 8-wave
+// kernel's bit for bit (test_attention_schedules_are_bit_identical).  Why it wins (profiles/r04_pmc_attention_8wave_vs_q64_hand_placed.txt,
+// B = 8, S = 5337, isolated, one --pmc pass): both kernels keep the matrix pipe busy 61-62 % of the time, but the chip — power-limited in
+// attention — gives the 8-wave kernel 1.61 GHz and this one 1.82 GHz: half the LDS traffic (SQ_LDS_IDX_ACTIVE 185 M vs 360 M per launch)
+// is the difference.  Round 2's form of it (hipcc's instruction order) kept the pipe busy 42 % of the time and lost (0.86 x); the KV loop
+// below is a hand-placed instruction stream (see `body`).  1200-1208 vs 1148-1158 TFLOP/s isolated, 2410 vs 2533 us for the DiT's call with the
+// fused q preparation, +0.7 % on the whole composite batch (profiles/r04_attention_q64_*.log).
 // --------------------------------------------------------------------------------------------
 // MFMAs of the 64-query kernel are inline asm so that the operand FILES are fixed: O accumulators and the Q fragments live
 // in the AGPR half (only MFMAs touch them), the S accumulators in arch VGPRs (the softmax reads them).  With builtins hipcc
@@ -794,8 +799,14 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       Q64P_T(3, 1); q64_max3(ra, ua[0], ua[1], ua[2]); q64_max3(rb, ub[0], ub[1], ub[2]);
 #undef Q64P_T
       ra = fmaxf(ra, ua[3]); rb = fmaxf(rb, ub[3]);
-      mt_carry[0] = fmaxf(ra, __shfl_xor(ra, 32, 64));
-      mt_carry[1] = fmaxf(rb, __shfl_xor(rb, 32, 64));
+      // the other 32 keys of a query live in lane ^ 32: v_permlane32_swap pairs the halves of both groups (no LDS round trip: a
+      // ds_bpermute here waits out the K fragment reads already in flight).  swap(ra, rb) = ((ra.lo | rb.lo), (ra.hi | rb.hi)):
+      // lanes < 32 then hold group A's two halves of query l, lanes >= 32 group B's of query l - 32
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ra), __builtin_bit_cast(unsigned, rb), false, false);
+      const float mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+      const auto sw2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
+      mt_carry[0] = __builtin_bit_cast(float, sw2[0]);      // (mx.lo | mx.lo): group A's maximum in both lane halves
+      mt_carry[1] = __builtin_bit_cast(float, sw2[1]);      // (mx.hi | mx.hi): group B's
       if (kv0 + 64 > p.S) {       // the ragged last tile: keys >= S do not exist (the trees above saw them) — once per (batch, head, query block)
 #pragma unroll
         for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(sc[qg], kv0);
@@ -926,8 +937,6 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   }
 }
 
-#endif  // DRAG_EXP
-
 }  // namespace
 
 extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt, const void* wk_txt,
@@ -1050,7 +1059,11 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   p.k_bytes_all = fits32 ? (unsigned)kall : 0u; p.vt_bytes_all = fits32 ? (unsigned)vall : 0u;
   const int groups = (B * H + 7) / 8;
   const bool w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
-  const int QB = (w8 || (DRAG_EXP && !vrow && drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024)) ? 256 : 128;
+  // "attn_q64": 0 = policy (the 4-wave x 64-query kernel for S >= 4096, where it is 4-5 % ahead; below that its 256-query blocks fill
+  // the chip worse: S = 1753 911 vs 982 TFLOP/s), 1 = whenever S >= 1024, 2 = never (the 8-wave / 4-wave x 32-query family: measurements, tests)
+  const int q64opt = drag_opt(DRAG_OPT_ATTN_Q64);
+  const bool q64 = !vrow && q64opt != 2 && ((q64opt == 1 && S >= 1024) || (q64opt == 0 && w8 && (!DRAG_EXP || drag_opt(DRAG_OPT_ATTN_PERSIST) == 0)));
+  const int QB = (w8 || q64) ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);
   const int sched = drag_opt(DRAG_OPT_ATTN_SCHED);          // 0, 1, or 2 = schedule 1 + pipelined row maxima
@@ -1071,10 +1084,10 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
               else hipLaunchKernelGGL((attention_d128_kernel<8, 1, false, true, true>), grid, dim3(512), 0, st, p); }
     else { if (qprep) hipLaunchKernelGGL((attention_d128_kernel<4, 1, true, true, true>), grid, dim3(256), 0, st, p);
            else hipLaunchKernelGGL((attention_d128_kernel<4, 1, false, true, true>), grid, dim3(256), 0, st, p); }
-#if DRAG_EXP
-  } else if (drag_opt(DRAG_OPT_ATTN_Q64) && S >= 1024) {
+  } else if (q64) {
     if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attention_q64_kernel<false>), grid, dim3(256), 0, st, p);
+#if DRAG_EXP
   } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 0 && fits32 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&
              nqb2 * groups > persist_slots()) {
     // EXPERIMENT, off by default ("attn_persist": 0 = off, 1 = one workgroup per CU, n >= 3 = n workgroups per XCD — tests: many items

@@ -29,7 +29,7 @@ static void opt_init() {
   g_opt[DRAG_OPT_ATTN_SCHED] = getenv(g_opt_env[DRAG_OPT_ATTN_SCHED]) ? g_opt[DRAG_OPT_ATTN_SCHED] : DRAG_ATTN_SCHED_DEFAULT;
   g_opt[DRAG_OPT_ATTN_TUNE] = getenv(g_opt_env[DRAG_OPT_ATTN_TUNE]) ? g_opt[DRAG_OPT_ATTN_TUNE] : DRAG_ATTN_TUNE_DEFAULT;
   if (!DRAG_EXP) {        // the product library has no experiment kernels: their environment switches are ignored
-    g_opt[DRAG_OPT_ATTN_PERSIST] = g_opt[DRAG_OPT_ATTN_Q64] = g_opt[DRAG_OPT_TOPK_QT] = 0;
+    g_opt[DRAG_OPT_ATTN_PERSIST] = g_opt[DRAG_OPT_TOPK_QT] = 0;
     if (g_opt[DRAG_OPT_ATTN_SCHED] == 3) g_opt[DRAG_OPT_ATTN_SCHED] = DRAG_ATTN_SCHED_DEFAULT;
   }
   g_opt_init = true;
@@ -45,9 +45,9 @@ extern "C" int drag_set_option(const char* name, int32_t value) {
   opt_init();
   for (int i = 0; i < DRAG_OPT_COUNT; ++i)
     if (strcmp(name, g_opt_names[i]) == 0) {
-      const bool experiment = i == DRAG_OPT_ATTN_PERSIST || i == DRAG_OPT_ATTN_Q64 || i == DRAG_OPT_TOPK_QT || (i == DRAG_OPT_ATTN_SCHED && value == 3);
+      const bool experiment = i == DRAG_OPT_ATTN_PERSIST || i == DRAG_OPT_TOPK_QT || (i == DRAG_OPT_ATTN_SCHED && value == 3);
       DRAG_CHECK(DRAG_EXP || !experiment || (value == 0 && i != DRAG_OPT_ATTN_SCHED),
-                 "drag_set_option: attn_persist, attn_q64, topk_qt and attn_sched = 3 are experiments (measured non-improvements): build the library with DRAG_EXPERIMENTS=1");
+                 "drag_set_option: attn_persist, topk_qt and attn_sched = 3 are experiments (measured non-improvements): build the library with DRAG_EXPERIMENTS=1");
       g_opt[i] = value;
       return 0;
     }

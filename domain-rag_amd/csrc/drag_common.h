@@ -93,8 +93,8 @@ enum { DRAG_OPT_ATTN_SCHED = 0, DRAG_OPT_ATTN_W4 = 1, DRAG_OPT_ATTN_TUNE = 2, DR
 #define DRAG_ATTN_SCHED_DEFAULT 2
 #define DRAG_ATTN_TUNE_DEFAULT 2
 int drag_opt(int idx);
-// Experiments: code paths whose A/B is recorded and negative (the persistent attention kernel -1 %, the 4-wave x 64-query attention
-// kernel 0.86x, the V-one-step-ahead attention schedule 0, several query tiles per top-k workgroup -20 %) are compiled only into a
+// Experiments: code paths whose A/B is recorded and negative (the persistent attention kernel -1 %, the V-one-step-ahead attention
+// schedule 0, several query tiles per top-k workgroup -20 %) are compiled only into a
 // -DDRAG_EXPERIMENTS library (DRAG_EXPERIMENTS=1 python -m domain_rag_amd.build); the product library neither carries their kernels nor accepts their
 // switches (drag_set_option says so), so nothing has to keep them bit-identical through every test run.
 #ifdef DRAG_EXPERIMENTS

@@ -88,7 +88,7 @@ def set_option(name: str, value: int) -> None:
 
 def experiments_built() -> bool:
     """True when libdomainrag_hip.so was built with DRAG_EXPERIMENTS=1 (csrc/drag_common.h): only then does it carry the kernels behind
-    "attn_persist", "attn_q64", "attn_sched" = 3 and "topk_qt" — measured non-improvements kept for their A/B records, not product code"""
+    "attn_persist", "attn_sched" = 3 and "topk_qt" — measured non-improvements kept for their A/B records, not product code"""
     lib = _lib.load()
     if lib.drag_set_option(b"attn_persist", 1) != 0:
         return False

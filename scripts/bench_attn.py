@@ -10,8 +10,9 @@ def bench(fn, iters=10):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-VARIANTS = {"sched0": {"attn_sched": 0}, "sched2": {"attn_sched": 2}, "sched2+wide": {"attn_sched": 2, "attn_tune": 2}, "sched3+wide": {"attn_sched": 3, "attn_tune": 2},
-            "q64+wide": {"attn_q64": 1, "attn_tune": 2}}
+# attn_q64: 2 = the 8-wave / 4-wave x 32-query family, 1 = the 4-wave x 64-query kernel (the policy's choice for S >= 4096)
+VARIANTS = {"sched0": {"attn_sched": 0, "attn_q64": 2}, "sched2": {"attn_sched": 2, "attn_q64": 2}, "sched2+wide": {"attn_sched": 2, "attn_tune": 2, "attn_q64": 2},
+            "q64+wide": {"attn_sched": 2, "attn_q64": 1, "attn_tune": 2}, "policy": {"attn_sched": 2, "attn_tune": 2, "attn_q64": 0}}
 for (B, S, H) in [(1, 5337, 24), (8, 5337, 24), (8, 1753, 24), (8, 729, 16)]:
     D = H * 128
     qkv = torch.randn(B, S, 3 * D, device=dev).bfloat16()

@@ -37,6 +37,8 @@ res = {l: [] for l in libs}
 for rnd in range(4):
     for i, l in enumerate(libs):
         env = dict(os.environ, DRAG_LIB=os.path.abspath(l), OUT_PT=f"/tmp/ab_attn_{i}.pt")
+        if os.environ.get(f"ENV{i}"):            # extra environment of build i, e.g. ENV1="DRAG_ATTN_Q64=1"
+            env.update(kv.split("=", 1) for kv in os.environ[f"ENV{i}"].split(","))
         out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         try:
             res[l].append(float(out.stdout.strip().splitlines()[-1]))

@@ -11,7 +11,7 @@ s_pad = (S + 63) // 64 * 64
 vt = torch.empty(B, H, 128, s_pad, device=dev, dtype=torch.bfloat16)
 ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
 o = torch.empty(B, S, D, device=dev, dtype=torch.bfloat16)
-for q64 in (0, 1):
+for q64 in (2, 1):           # 2 = the 8-wave kernel, 1 = the 4-wave x 64-query kernel
     ops.set_option("attn_q64", q64)
     for _ in range(6):
         ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))

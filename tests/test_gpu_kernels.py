@@ -225,14 +225,15 @@ def test_attention_schedules_are_bit_identical(gpu):
     vt = torch.empty((B, H, 128, s_pad), dtype=torch.bfloat16, device=gpu)
     ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
     outs = {}
-    combos = [(0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 0, 3, 0), (1, 0, 2, 0), (0, 1, 0, 0), (1, 1, 0, 0), (2, 1, 3, 0)]
-    if ops.experiments_built():      # the 4-wave x 64-query kernel and the V-one-step-ahead schedule: DRAG_EXPERIMENTS builds only
-        combos += [(2, 0, 0, 1), (2, 0, 2, 1), (3, 0, 2, 0), (3, 1, 3, 0)]
+    # (sched, w4, tune, q64): q64 = 2 keeps the 8-wave / 4-wave x 32-query family, 1 forces the 4-wave x 64-query kernel, 0 is the policy
+    # (the 64-query kernel for S >= 4096 — this S)
+    combos = [(0, 0, 0, 2), (1, 0, 0, 2), (2, 0, 0, 2), (2, 0, 3, 2), (1, 0, 2, 2), (0, 1, 0, 2), (1, 1, 0, 2), (2, 1, 3, 2),
+              (2, 0, 0, 1), (2, 0, 2, 1), (2, 0, 2, 0), (2, 1, 2, 0)]
+    if ops.experiments_built():      # the V-one-step-ahead schedule: DRAG_EXPERIMENTS builds only
+        combos += [(3, 0, 2, 2), (3, 1, 3, 2)]
     else:
         with pytest.raises(RuntimeError, match="experiments"):
             ops.set_option("attn_sched", 3)
-        with pytest.raises(RuntimeError, match="experiments"):
-            ops.set_option("attn_q64", 1)
     try:
         for sched, w4, tune, q64 in combos:
             ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4); ops.set_option("attn_tune", tune)
@@ -243,7 +244,7 @@ def test_attention_schedules_are_bit_identical(gpu):
     finally:
         ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2)   # the library's defaults
         ops.set_option("attn_q64", 0)
-    ref = outs[(0, 0, 0, 0)]
+    ref = outs[(0, 0, 0, 2)]
     assert torch.isfinite(ref.float()).all()
     for key, o in outs.items():
         assert torch.equal(o, ref), key
