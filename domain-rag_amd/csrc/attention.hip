@@ -764,6 +764,19 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   // The last key group's P V (8 MFMAs on fragments and P words already in registers) and the row maxima of the tile that follows are
   // one block at the TOP of the next iteration: behind the barrier, with the first K fragment reads of the new tile already issued, the
   // eight MFMAs cover both the reads' latency and the 32 v_max3 of the two row-maximum trees (4 per gap).
+  // LDS byte addresses of this lane's K / V^T fragment slots: one register each, added once (inside the steps hipcc re-derived them per read)
+  unsigned akl[8], avl[4];
+  {
+    const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) akl[i] = lds0 + (unsigned)ak[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) avl[i] = lds0 + (unsigned)av[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(akl[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(avl[i]));
+  }
   bf16x8_t vtr[4];              // the four V^T fragments of the trailing P V MFMAs (read in steps 14 / 15, used after the next barrier)
   u32x4_t pk[2][4];             // packed P: key group kg of a tile is consumed in its steps 4 kg + 4 .. 4 kg + 7, group 3 after the next barrier
   auto body = [&](const int it, auto par, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2], auto firstc) {
@@ -774,11 +787,10 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
     const int kv0 = it * 64;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
     bf16x8_t kfr[3], vfr[3];      // fragment rings (step g uses slot g % 3)
     // K(0), K(1) of the next tile first: their latency hides behind the block below
-    q64_lds_read<KN>(kfr[0], lds0 + (unsigned)ak[0]);
-    q64_lds_read<KN>(kfr[1], lds0 + (unsigned)ak[1]);
+    q64_lds_read<KN>(kfr[0], akl[0]);
+    q64_lds_read<KN>(kfr[1], akl[1]);
     if constexpr (!FIRST) {
       // row maxima of sc (32 scores per lane and query group) as two v_max3 trees: 10 + 4 + 2 instructions each, group A and B interleaved
       float ta[10], tb[10], ua[4], ub[4], ra, rb;
@@ -840,11 +852,11 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       q64_lgkmcnt<younger>();                                   // K(G) (and V(G)) landed; step G-1's reads stay in flight
       float yA0, yA1, yB0, yB1, eA0, eA1, eB0, eB1, sA, sB;
       uint32_t wA, wB;
-      auto readK = [&]() { if constexpr (G + 2 <= 15) q64_lds_read<KN + ((G + 2) >> 3) * (32 * 256)>(kfr[(G + 2) % 3], lds0 + (unsigned)ak[(G + 2) & 7]); };
+      auto readK = [&]() { if constexpr (G + 2 <= 15) q64_lds_read<KN + ((G + 2) >> 3) * (32 * 256)>(kfr[(G + 2) % 3], akl[(G + 2) & 7]); };
       auto readV = [&]() {
-        if constexpr (G + 2 >= 4 && G + 2 <= 15) q64_lds_read<VB + ((G + 2) & 3) * (32 * 128)>(vfr[(G + 2) % 3], lds0 + (unsigned)av[((G + 2) >> 2) - 1]);
-        if constexpr (G == 14) { q64_lds_read<VB + 0 * (32 * 128)>(vtr[0], lds0 + (unsigned)av[3]); q64_lds_read<VB + 1 * (32 * 128)>(vtr[1], lds0 + (unsigned)av[3]); }
-        if constexpr (G == 15) { q64_lds_read<VB + 2 * (32 * 128)>(vtr[2], lds0 + (unsigned)av[3]); q64_lds_read<VB + 3 * (32 * 128)>(vtr[3], lds0 + (unsigned)av[3]); }
+        if constexpr (G + 2 >= 4 && G + 2 <= 15) q64_lds_read<VB + ((G + 2) & 3) * (32 * 128)>(vfr[(G + 2) % 3], avl[((G + 2) >> 2) - 1]);
+        if constexpr (G == 14) { q64_lds_read<VB + 0 * (32 * 128)>(vtr[0], avl[3]); q64_lds_read<VB + 1 * (32 * 128)>(vtr[1], avl[3]); }
+        if constexpr (G == 15) { q64_lds_read<VB + 2 * (32 * 128)>(vtr[2], avl[3]); q64_lds_read<VB + 3 * (32 * 128)>(vtr[3], avl[3]); }
       };
       auto dma = [&]() { if constexpr (G < CPW) stage_k1(PAR, kv0 + 128, G); else if constexpr (G < 2 * CPW) stage_v1((PAR + 1) & 1, kv0 + 64, G - CPW); };
       // the softmax slice of this step in issue order V1..V14 (A = query group 0, B = group 1)
