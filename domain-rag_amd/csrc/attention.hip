@@ -583,6 +583,18 @@ template <int OFF>
 __device__ __forceinline__ void q64_lds_read(bf16x8_t& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
 template <int N>
 __device__ __forceinline__ void q64_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+// the same wait, naming the fragments it retires as in/out operands: whatever the compiler does with a fragment (a copy to split its live
+// range, a v_accvgpr_write to park it) then depends on the WAIT, not on the read — a copy of the read's own result can be scheduled straight
+// behind the ds_read, in front of the next asm statement, before the LDS has written the registers (asm volatile orders asm statements,
+// not the compiler's instructions around them)
+template <int N>
+__device__ __forceinline__ void q64_landed(bf16x8_t& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void q64_landed(bf16x8_t& a, bf16x8_t& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void q64_landed(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
 __device__ __forceinline__ void q64_fma(float& y, float s, float c, float nm) { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(s), "s"(c), "v"(nm)); }
 __device__ __forceinline__ void q64_exp(float& e, float y) { asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(y)); }
 __device__ __forceinline__ void q64_add(float& d, float a, float b) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); }
@@ -788,9 +800,17 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bf16x8_t kfr[3], vfr[3];      // fragment rings (step g uses slot g % 3)
-    // K(0), K(1) of the next tile first: their latency hides behind the block below
+    // RULE of this kernel: a fragment requested by an asm ds_read reaches compiler-visible code only through q64_landed (the s_waitcnt
+    // that retires it, with the fragment as an in/out operand), and between the read and that wait there are asm statements only.  hipcc
+    // takes the read's destination for defined the moment the statement ends: a build that kept K(0) / K(1) in flight across the rescale
+    // branch below had them parked in AGPRs one instruction after the request (v_accvgpr_write of registers the LDS had not written yet:
+    // NaNs that came and went with register allocation).  scripts/check_asm_loads.py walks the compiled kernel for exactly that
+    // (tests/test_asm_load_discipline.py).
+    // K(0), K(1) of the next tile first: their latency hides behind the trailing P V block, which is asm only; they have landed before
+    // the compiler's code (maxima across lane halves, rescale decision) begins
     q64_lds_read<KN>(kfr[0], akl[0]);
     q64_lds_read<KN>(kfr[1], akl[1]);
+    if constexpr (FIRST) q64_landed<0>(kfr[0], kfr[1]);
     if constexpr (!FIRST) {
       // row maxima of sc (32 scores per lane and query group) as two v_max3 trees: 10 + 4 + 2 instructions each, group A and B interleaved
       float ta[10], tb[10], ua[4], ub[4], ra, rb;
@@ -810,6 +830,7 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       Q64P_T(3, 0); L2(ub, tb, 1, 0); L2(ub, tb, 1, 1); L2(ub, tb, 1, 2); L2(ub, tb, 1, 3);
       Q64P_T(3, 1); q64_max3(ra, ua[0], ua[1], ua[2]); q64_max3(rb, ub[0], ub[1], ub[2]);
 #undef Q64P_T
+      q64_landed<0>(kfr[0], kfr[1]);
       ra = fmaxf(ra, ua[3]); rb = fmaxf(rb, ub[3]);
       // the other 32 keys of a query live in lane ^ 32: v_permlane32_swap pairs the halves of both groups (no LDS round trip: a
       // ds_bpermute here waits out the K fragment reads already in flight).  swap(ra, rb) = ((ra.lo | rb.lo), (ra.hi | rb.hi)):
@@ -848,8 +869,9 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       constexpr int T = G >> 3, E0 = (2 * G) & 15;
       // reads issued in step s (in order): K(s+2) if s+2 <= 15; V(s+2) if 4 <= s+2 <= 15; the 4 trailing fragments in steps 14 / 15
       constexpr int prev = G - 1;
-      constexpr int younger = prev < 0 ? 1 : ((prev + 2 <= 15) + (prev + 2 >= 4 && prev + 2 <= 15) + (prev >= 14 ? 2 : 0));
-      q64_lgkmcnt<younger>();                                   // K(G) (and V(G)) landed; step G-1's reads stay in flight
+      constexpr int younger = prev < 0 ? 0 : ((prev + 2 <= 15) + (prev + 2 >= 4 && prev + 2 <= 15) + (prev >= 14 ? 2 : 0));
+      // K(G) (and V(G)) landed; step G-1's reads stay in flight
+      if constexpr (G >= 4) q64_landed<younger>(kfr[G % 3], vfr[G % 3]); else if constexpr (G > 0) q64_landed<younger>(kfr[G % 3]);
       float yA0, yA1, yB0, yB1, eA0, eA1, eB0, eB1, sA, sB;
       uint32_t wA, wB;
       auto readK = [&]() { if constexpr (G + 2 <= 15) q64_lds_read<KN + ((G + 2) >> 3) * (32 * 256)>(kfr[(G + 2) % 3], akl[(G + 2) & 7]); };
@@ -893,9 +915,9 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       pk[1][G >> 2][G & 3] = wB;
     };
     q64_unroll16(step);
+    q64_landed<0>(vtr[0], vtr[1], vtr[2], vtr[3]);              // the trailing fragments landed: every read of this tile's buffers is complete
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) l_run[qg] += ps[qg];
-    q64_lgkmcnt<0>();                                           // the trailing fragments landed: every read of this tile's buffers is complete
   };
   {
     using P0 = std::integral_constant<int, 0>;
