@@ -569,24 +569,23 @@ __global__ __launch_bounds__(512, 2) void attention_d128_kernel(AttnArgs p) {
 // in the AGPR half (only MFMAs touch them), the S accumulators in arch VGPRs (the softmax reads them).  With builtins hipcc
 // puts S into AGPRs as well and copies 200-400 registers per KV tile back and forth (measured: 473-668 v_accvgpr / scratch
 // instructions per 64 MFMAs).  hipcc neither counts nor pads what is inside an asm statement (guide 5.7):
-//   * a VALU-written B operand (packed P) needs 2 wait states before the MFMA reads it: `s_nop 1` opens the P V statement;
+//   * a VALU-written A / B operand needs 2 wait states before the MFMA reads it — the packed P words are a step old when their P V MFMA
+//     issues, but hipcc may also RESTORE an operand it parked (v_accvgpr_read) in the instruction right before an asm statement: the step
+//     statements open with two softmax instructions for that reason, and scripts/check_asm_loads.py checks every MFMA of the compiled kernel;
 //   * an MFMA result needs 18 wait states (16-pass op) before anything but the next MFMA of its chain touches it: Q64_SETTLE
 //     passes the registers through a nop statement before compiler-generated code may read them.
 #define Q64_MFMA_S0(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b))
 #define Q64_MFMA_S(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b))
-#define Q64_MFMA_O(d, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b))
 #define Q64_SETTLE_S(s4) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s4[0][0]), "+v"(s4[0][1]), "+v"(s4[1][0]), "+v"(s4[1][1]))
 #define Q64_SETTLE_O(o, qg) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[qg][0]), "+a"(o[qg][1]), "+a"(o[qg][2]), "+a"(o[qg][3]))
 
-// pieces of the hand-placed stream (round 4): every one is ONE instruction hipcc neither moves nor waits for
+// pieces of the hand-placed stream (round 4) that are single statements: hipcc neither moves them against each other nor waits for them
 template <int OFF>
 __device__ __forceinline__ void q64_lds_read(bf16x8_t& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
-template <int N>
-__device__ __forceinline__ void q64_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
-// the same wait, naming the fragments it retires as in/out operands: whatever the compiler does with a fragment (a copy to split its live
-// range, a v_accvgpr_write to park it) then depends on the WAIT, not on the read — a copy of the read's own result can be scheduled straight
-// behind the ds_read, in front of the next asm statement, before the LDS has written the registers (asm volatile orders asm statements,
-// not the compiler's instructions around them)
+// the wait that retires asm-issued fragment reads names the fragments as in/out operands: whatever the compiler does with a fragment (a
+// copy to split its live range, a v_accvgpr_write to park it) then depends on the WAIT, not on the read — a copy of the read's own result
+// can be scheduled straight behind the ds_read, in front of the next asm statement, before the LDS has written the registers (asm volatile
+// orders asm statements, not the compiler's instructions around them)
 template <int N>
 __device__ __forceinline__ void q64_landed(bf16x8_t& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N>
@@ -595,13 +594,67 @@ template <int N>
 __device__ __forceinline__ void q64_landed(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
-__device__ __forceinline__ void q64_fma(float& y, float s, float c, float nm) { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(s), "s"(c), "v"(nm)); }
-__device__ __forceinline__ void q64_exp(float& e, float y) { asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(y)); }
-__device__ __forceinline__ void q64_add(float& d, float a, float b) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void q64_max3(float& d, float a, float b, float c) { asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); }
-__device__ __forceinline__ void q64_cvt(uint32_t& w, float a, float b) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b)); }
 // P V: the packed P words were written >= one step (dozens of instructions) before: no VALU -> MFMA wait states to pad
 #define Q64P_MFMA_O(d, a, pw) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(pw))
+// A step of the stream as TWO asm statements (the LDS-DMA piece of the step, which is compiler code, sits between them).  hipcc cannot see
+// into an asm statement, so whenever a statement reads a register that an earlier STATEMENT wrote and no instruction of its own has been
+// issued since, its hazard recogniser pads with an s_nop (asm statements count as zero wait states): with one instruction per statement the
+// softmax chain fma -> exp -> add -> cvt cost six s_nop per step, an eighth of the wave's issue slots.  Inside a statement nothing is padded
+// and nothing needs to be: every v_exp result has one instruction between it and its first non-transcendental reader (the one software
+// hazard of this stream on gfx950), the packed P words an MFMA reads were written a step or more before.
+// softmax of two elements per query group (a: group 0, b: group 1), in place: y = s c - m c ; y = 2^y ; ps += y0 + y1 ; w = bf16x2(y0, y1)
+#define Q64_V1 "v_fma_f32 %[ya0], %[sa0], %[c], %[nma]\n\t"
+#define Q64_V2 "v_fma_f32 %[ya1], %[sa1], %[c], %[nma]\n\t"
+#define Q64_V3 "v_exp_f32 %[ya0], %[ya0]\n\t"
+#define Q64_V4 "v_fma_f32 %[yb0], %[sb0], %[c], %[nmb]\n\t"
+#define Q64_V5 "v_exp_f32 %[ya1], %[ya1]\n\t"
+#define Q64_V6 "v_fma_f32 %[yb1], %[sb1], %[c], %[nmb]\n\t"
+#define Q64_V7 "v_add_f32 %[ta], %[ya0], %[ya1]\n\t"
+#define Q64_V8 "v_exp_f32 %[yb0], %[yb0]\n\t"
+#define Q64_V9 "v_add_f32 %[psa], %[psa], %[ta]\n\t"
+#define Q64_V10 "v_exp_f32 %[yb1], %[yb1]\n\t"
+#define Q64_V11 "v_cvt_pk_bf16_f32 %[wa], %[ya0], %[ya1]\n\t"
+#define Q64_V12 "v_add_f32 %[tb], %[yb0], %[yb1]\n\t"
+#define Q64_V13 "v_add_f32 %[psb], %[psb], %[tb]\n\t"
+#define Q64_V14 "v_cvt_pk_bf16_f32 %[wb], %[yb0], %[yb1]"
+#define Q64_SC_IN(sc, T, E0) [sa0] "v"(sc[0][T][E0]), [sa1] "v"(sc[0][T][E0 + 1]), [sb0] "v"(sc[1][T][E0]), [sb1] "v"(sc[1][T][E0 + 1])
+// Every statement that holds an MFMA opens with two VALU instructions of the softmax (or more): hipcc may restore a parked operand (a K / V^T
+// fragment or packed P word it kept in AGPRs across the rescale branch: v_accvgpr_read) in the instruction right before the statement, and an
+// MFMA reads a VALU-written operand correctly only two wait states later — a hazard hipcc pads for its own MFMAs, not for one inside asm.
+// steps 4..15, first half: wait | V1 V2 | P V (group 0) | read | V3 | P V (group 1) | read | V4-V6 | S (group 0).  C0 = "0" opens a key half
+#define Q64_STEP_HI_A(C0, S0CONS, N, o0_, o1_, vf_, p0_, p1_, s0_, kf_, q0_, d1_, a1_, F1, d2_, a2_, F2, sc, T, E0, cc, nma_, nmb_)        \
+  asm volatile("s_waitcnt lgkmcnt(%[n])\n\t" Q64_V1 Q64_V2                                                                                \
+               "v_mfma_f32_32x32x16_bf16 %[o0], %[vf], %[p0], %[o0]\n\t"                                                                  \
+               "ds_read_b128 %[d1], %[a1] offset:%[f1]\n\t" Q64_V3                                                                        \
+               "v_mfma_f32_32x32x16_bf16 %[o1], %[vf], %[p1], %[o1]\n\t"                                                                  \
+               "ds_read_b128 %[d2], %[a2] offset:%[f2]\n\t" Q64_V4 Q64_V5 Q64_V6                                                          \
+               "v_mfma_f32_32x32x16_bf16 %[s0], %[kf], %[q0], " C0                                                                        \
+               : [o0] "+a"(o0_), [o1] "+a"(o1_), [s0] S0CONS(s0_), [d1] "=&v"(d1_), [d2] "=&v"(d2_), [ya0] "=&v"(yA0), [ya1] "=&v"(yA1),  \
+                 [yb0] "=&v"(yB0), [yb1] "=&v"(yB1)                                                                                       \
+               : [n] "n"(N), [vf] "v"(vf_), [p0] "v"(p0_), [p1] "v"(p1_), [kf] "v"(kf_), [q0] "a"(q0_), [a1] "v"(a1_), [f1] "n"(F1),      \
+                 [a2] "v"(a2_), [f2] "n"(F2), Q64_SC_IN(sc, T, E0), [c] "s"(cc), [nma] "v"(nma_), [nmb] "v"(nmb_))
+// steps 4..15, second half: V7-V10 | S (group 1) | V11-V14
+#define Q64_STEP_HI_B(C1, S1CONS, s1_, kf_, q1_)                                                                                          \
+  asm volatile(Q64_V7 Q64_V8 Q64_V9 Q64_V10 "v_mfma_f32_32x32x16_bf16 %[s1], %[kf], %[q1], " C1 "\n\t" Q64_V11 Q64_V12 Q64_V13 Q64_V14    \
+               : [s1] S1CONS(s1_), [yb0] "+v"(yB0), [yb1] "+v"(yB1), [psa] "+v"(ps[0]), [psb] "+v"(ps[1]), [wa] "=&v"(wA),                \
+                 [wb] "=&v"(wB), [ta] "=&v"(sA), [tb] "=&v"(sB)                                                                           \
+               : [kf] "v"(kf_), [q1] "a"(q1_), [ya0] "v"(yA0), [ya1] "v"(yA1))
+// steps 0..3 (no P V yet), first half: [wait] | V1 V2 | S (group 0) | read [| read] | V3-V7 | S (group 1)
+#define Q64_STEP_LO_A(WAIT, READ2, C0, C1, SCONS, N, s0_, s1_, kf_, q0_, q1_, d1_, a1_, F1, d2_, a2_, F2, sc, T, E0, cc, nma_, nmb_)       \
+  asm volatile(WAIT Q64_V1 Q64_V2 "v_mfma_f32_32x32x16_bf16 %[s0], %[kf], %[q0], " C0 "\n\t"                                              \
+               "ds_read_b128 %[d1], %[a1] offset:%[f1]\n\t" READ2 Q64_V3 Q64_V4 Q64_V5 Q64_V6 Q64_V7                                      \
+               "v_mfma_f32_32x32x16_bf16 %[s1], %[kf], %[q1], " C1                                                                        \
+               : [s0] SCONS(s0_), [s1] SCONS(s1_), [d1] "=&v"(d1_), [d2] "=&v"(d2_), [ya0] "=&v"(yA0), [ya1] "=&v"(yA1), [yb0] "=&v"(yB0),\
+                 [yb1] "=&v"(yB1), [ta] "=&v"(sA)                                                                                         \
+               : [n] "n"(N), [kf] "v"(kf_), [q0] "a"(q0_), [q1] "a"(q1_), [a1] "v"(a1_), [f1] "n"(F1), [a2] "v"(a2_), [f2] "n"(F2),       \
+                 Q64_SC_IN(sc, T, E0), [c] "s"(cc), [nma] "v"(nma_), [nmb] "v"(nmb_))
+// steps 0..3, second half: V8-V14 (the K fragment stays an operand: its registers are not the compiler's to reuse for the LDS-DMA address
+// arithmetic between the two halves while the MFMA that closed the first half is a few cycles old)
+#define Q64_STEP_LO_B(kf_)                                                                                                                \
+  asm volatile(Q64_V8 Q64_V9 Q64_V10 Q64_V11 Q64_V12 Q64_V13 Q64_V14                                                                      \
+               : [yb0] "+v"(yB0), [yb1] "+v"(yB1), [psa] "+v"(ps[0]), [psb] "+v"(ps[1]), [wa] "=&v"(wA), [wb] "=&v"(wB), [tb] "=&v"(sB)   \
+               : [ya0] "v"(yA0), [ya1] "v"(yA1), [ta] "v"(sA), "v"(kf_))
 template <class F, int G = 0>
 __device__ __forceinline__ void q64_unroll16(F&& f) {
   if constexpr (G < 16) {
@@ -869,47 +922,48 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       constexpr int T = G >> 3, E0 = (2 * G) & 15;
       // reads issued in step s (in order): K(s+2) if s+2 <= 15; V(s+2) if 4 <= s+2 <= 15; the 4 trailing fragments in steps 14 / 15
       constexpr int prev = G - 1;
+      // the step's wait: K(G) (and V(G)) landed; step G-1's reads stay in flight
       constexpr int younger = prev < 0 ? 0 : ((prev + 2 <= 15) + (prev + 2 >= 4 && prev + 2 <= 15) + (prev >= 14 ? 2 : 0));
-      // K(G) (and V(G)) landed; step G-1's reads stay in flight
-      if constexpr (G >= 4) q64_landed<younger>(kfr[G % 3], vfr[G % 3]); else if constexpr (G > 0) q64_landed<younger>(kfr[G % 3]);
-      float yA0, yA1, yB0, yB1, eA0, eA1, eB0, eB1, sA, sB;
+      float yA0, yA1, yB0, yB1, sA, sB;
       uint32_t wA, wB;
-      auto readK = [&]() { if constexpr (G + 2 <= 15) q64_lds_read<KN + ((G + 2) >> 3) * (32 * 256)>(kfr[(G + 2) % 3], akl[(G + 2) & 7]); };
-      auto readV = [&]() {
-        if constexpr (G + 2 >= 4 && G + 2 <= 15) q64_lds_read<VB + ((G + 2) & 3) * (32 * 128)>(vfr[(G + 2) % 3], avl[((G + 2) >> 2) - 1]);
-        if constexpr (G == 14) { q64_lds_read<VB + 0 * (32 * 128)>(vtr[0], avl[3]); q64_lds_read<VB + 1 * (32 * 128)>(vtr[1], avl[3]); }
-        if constexpr (G == 15) { q64_lds_read<VB + 2 * (32 * 128)>(vtr[2], avl[3]); q64_lds_read<VB + 3 * (32 * 128)>(vtr[3], avl[3]); }
-      };
       auto dma = [&]() { if constexpr (G < CPW) stage_k1(PAR, kv0 + 128, G); else if constexpr (G < 2 * CPW) stage_v1((PAR + 1) & 1, kv0 + 64, G - CPW); };
-      // the softmax slice of this step in issue order V1..V14 (A = query group 0, B = group 1)
-      auto V1 = [&]() { q64_fma(yA0, sc[0][T][E0], p.c, nmc[0]); };
-      auto V2 = [&]() { q64_fma(yA1, sc[0][T][E0 + 1], p.c, nmc[0]); };
-      auto V3 = [&]() { q64_exp(eA0, yA0); };
-      auto V4 = [&]() { q64_fma(yB0, sc[1][T][E0], p.c, nmc[1]); };
-      auto V5 = [&]() { q64_exp(eA1, yA1); };
-      auto V6 = [&]() { q64_fma(yB1, sc[1][T][E0 + 1], p.c, nmc[1]); };
-      auto V7 = [&]() { q64_add(sA, eA0, eA1); };
-      auto V8 = [&]() { q64_exp(eB0, yB0); };
-      auto V9 = [&]() { q64_add(ps[0], ps[0], sA); };
-      auto V10 = [&]() { q64_exp(eB1, yB1); };
-      auto V11 = [&]() { q64_cvt(wA, eA0, eA1); };
-      auto V12 = [&]() { q64_add(sB, eB0, eB1); };
-      auto V13 = [&]() { q64_add(ps[1], ps[1], sB); };
-      auto V14 = [&]() { q64_cvt(wB, eB0, eB1); };
-      if constexpr (G >= 4) {
-        Q64P_MFMA_O(oacc[0][G & 3], vfr[G % 3], pk[0][(G >> 2) - 1]);
-        readK(); V1(); V2(); V3();
-        Q64P_MFMA_O(oacc[1][G & 3], vfr[G % 3], pk[1][(G >> 2) - 1]);
-        readV(); V4(); V5(); V6();
-        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[0][T], kfr[G % 3], qa[0][G & 7]); else Q64_MFMA_S(sn[0][T], kfr[G % 3], qa[0][G & 7]);
-        dma(); V7(); V8(); V9(); V10();
-        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[1][T], kfr[G % 3], qa[1][G & 7]); else Q64_MFMA_S(sn[1][T], kfr[G % 3], qa[1][G & 7]);
-        V11(); V12(); V13(); V14();
-      } else {
-        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[0][T], kfr[G % 3], qa[0][G & 7]); else Q64_MFMA_S(sn[0][T], kfr[G % 3], qa[0][G & 7]);
-        readK(); readV(); V1(); V2(); V3(); V4(); V5(); V6(); V7();
-        if constexpr ((G & 7) == 0) Q64_MFMA_S0(sn[1][T], kfr[G % 3], qa[1][G & 7]); else Q64_MFMA_S(sn[1][T], kfr[G % 3], qa[1][G & 7]);
-        dma(); V8(); V9(); V10(); V11(); V12(); V13(); V14();
+      constexpr int KOFF = KN + ((G + 2) >> 3) * (32 * 256), VOFF = VB + ((G + 2) & 3) * (32 * 128);
+      if constexpr (G >= 14) {            // P V + S; the reads are the trailing V^T fragments (two per step)
+        constexpr int F1 = VB + (2 * (G - 14)) * (32 * 128), F2 = F1 + 32 * 128;
+        Q64_STEP_HI_A("%[s0]", "+v", younger, oacc[0][G & 3], oacc[1][G & 3], vfr[G % 3], pk[0][(G >> 2) - 1], pk[1][(G >> 2) - 1], sn[0][T],
+                      kfr[G % 3], qa[0][G & 7], vtr[2 * (G - 14)], avl[3], F1, vtr[2 * (G - 14) + 1], avl[3], F2, sc, T, E0, p.c, nmc[0], nmc[1]);
+        dma();
+        Q64_STEP_HI_B("%[s1]", "+v", sn[1][T], kfr[G % 3], qa[1][G & 7]);
+      } else if constexpr (G == 8) {      // opens the second key half of S: C = 0
+        Q64_STEP_HI_A("0", "=&v", younger, oacc[0][G & 3], oacc[1][G & 3], vfr[G % 3], pk[0][(G >> 2) - 1], pk[1][(G >> 2) - 1], sn[0][T],
+                      kfr[G % 3], qa[0][G & 7], kfr[(G + 2) % 3], akl[(G + 2) & 7], KOFF, vfr[(G + 2) % 3], avl[((G + 2) >> 2) - 1], VOFF, sc, T, E0,
+                      p.c, nmc[0], nmc[1]);
+        dma();
+        Q64_STEP_HI_B("0", "=&v", sn[1][T], kfr[G % 3], qa[1][G & 7]);
+      } else if constexpr (G >= 4) {
+        Q64_STEP_HI_A("%[s0]", "+v", younger, oacc[0][G & 3], oacc[1][G & 3], vfr[G % 3], pk[0][(G >> 2) - 1], pk[1][(G >> 2) - 1], sn[0][T],
+                      kfr[G % 3], qa[0][G & 7], kfr[(G + 2) % 3], akl[(G + 2) & 7], KOFF, vfr[(G + 2) % 3], avl[((G + 2) >> 2) - 1], VOFF, sc, T, E0,
+                      p.c, nmc[0], nmc[1]);
+        dma();
+        Q64_STEP_HI_B("%[s1]", "+v", sn[1][T], kfr[G % 3], qa[1][G & 7]);
+      } else if constexpr (G == 0) {      // K(0) landed at the top of the body; opens the first key half: C = 0; one read (K(2))
+        bf16x8_t none;
+        Q64_STEP_LO_A("", "", "0", "0", "=&v", 0, sn[0][T], sn[1][T], kfr[0], qa[0][0], qa[1][0], kfr[2], akl[2], KOFF, none, akl[2], 0, sc, T, E0,
+                      p.c, nmc[0], nmc[1]);
+        dma();
+        Q64_STEP_LO_B(kfr[0]);
+      } else if constexpr (G == 1) {      // one read (K(3))
+        bf16x8_t none;
+        Q64_STEP_LO_A("s_waitcnt lgkmcnt(%[n])\n\t", "", "%[s0]", "%[s1]", "+v", younger, sn[0][T], sn[1][T], kfr[G % 3], qa[0][G], qa[1][G],
+                      kfr[(G + 2) % 3], akl[G + 2], KOFF, none, akl[2], 0, sc, T, E0, p.c, nmc[0], nmc[1]);
+        dma();
+        Q64_STEP_LO_B(kfr[G % 3]);
+      } else {                            // G = 2, 3: K(G+2) and V(G+2)
+        Q64_STEP_LO_A("s_waitcnt lgkmcnt(%[n])\n\t", "ds_read_b128 %[d2], %[a2] offset:%[f2]\n\t", "%[s0]", "%[s1]", "+v", younger, sn[0][T],
+                      sn[1][T], kfr[G % 3], qa[0][G], qa[1][G], kfr[(G + 2) % 3], akl[G + 2], KOFF, vfr[(G + 2) % 3], avl[((G + 2) >> 2) - 1], VOFF,
+                      sc, T, E0, p.c, nmc[0], nmc[1]);
+        dma();
+        Q64_STEP_LO_B(kfr[G % 3]);
       }
       pk[0][G >> 2][G & 3] = wA;
       pk[1][G >> 2][G & 3] = wB;

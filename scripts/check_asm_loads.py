@@ -6,7 +6,8 @@ hipcc treats the destination of an `asm volatile("ds_read_b128 %0, ...")` as def
 statement (a register copy for a live-range split, a v_accvgpr_write to park the value across a branch) may read registers the LDS has not
 written yet.  Round 4 hit exactly that in attention_q64_kernel (a K fragment requested above the rescale branch was parked in AGPRs one
 instruction later: NaNs that came and went with register allocation).  The kernels are written so that only asm statements sit between a read
-and its wait; this script checks the compiler's output instead of trusting the source.
+and its wait; this script checks the compiler's output instead of trusting the source.  Second rule (same origin: code hipcc puts next to an asm statement):
+no VALU instruction writes an A / B operand of an asm MFMA less than two wait states before it (check_mfma_operands).
 
     python scripts/check_asm_loads.py [source.hip [kernel-name-substring ...]]      default: csrc/attention.hip attention_q64, then csrc/gemm_bf16.hip gemm_bf16_deep
 
@@ -96,6 +97,36 @@ def check(name, body):
     return n_reads, bad
 
 
+def check_mfma_operands(name, body):
+    """second rule: an MFMA reads a VALU-written A / B operand correctly only two wait states after the write.  hipcc pads that for its own
+    MFMAs; for one inside an asm statement it does not, and it may well restore a parked fragment (v_accvgpr_read) in the instruction right
+    before the statement.  Every instruction counts one wait state, s_nop N counts N + 1."""
+    ins = []
+    for ln, raw in enumerate(body):
+        text = raw.split(";")[0].strip()
+        if text and not text.startswith(".") and not text.endswith(":"):
+            ins.append((ln, text))
+    bad, n_mfma = [], 0
+    for k, (ln, text) in enumerate(ins):
+        if not text.startswith("v_mfma"):
+            continue
+        n_mfma += 1
+        ops = [o.strip() for o in text[len(text.split()[0]):].split(",")]
+        src = regs(ops[1]) | regs(ops[2])
+        waited, j = 0, k - 1
+        while j >= 0 and waited < 2:
+            pln, prev = ins[j]
+            op = prev.split()[0]
+            if op.startswith("v_") and not op.startswith("v_mfma"):
+                hit = regs(prev[len(op):].split(",")[0]) & src
+                if hit:
+                    bad.append((ln, text, pln, prev, sorted(hit)))
+            m = re.match(r"s_nop\s+(\d+)", prev)
+            waited += int(m.group(1)) + 1 if m else 1
+            j -= 1
+    return n_mfma, bad
+
+
 def run(src, wanted):
     asm = compile_asm(src)
     status, seen = 0, 0
@@ -107,6 +138,11 @@ def run(src, wanted):
         print(f"{name[:110]}: {n_reads} LDS reads, {len(bad)} violation(s)")
         for ln, text, qln, qtext, hit in bad[:12]:
             print(f"    +{ln}: `{text}` touches {hit} of the outstanding `{qtext}` (+{qln})")
+        status |= bool(bad)
+        n_mfma, bad = check_mfma_operands(name, body)
+        print(f"{' ' * min(len(name), 110)}  {n_mfma} MFMAs, {len(bad)} operand(s) written less than two wait states before")
+        for ln, text, pln, prev, hit in bad[:12]:
+            print(f"    +{ln}: `{text[:80]}` reads {hit} written by `{prev}` (+{pln})")
         status |= bool(bad)
     if not seen:
         print(f"no kernel matching {wanted} in {src}")

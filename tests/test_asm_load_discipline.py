@@ -31,3 +31,18 @@ def test_the_checker_sees_a_copy_of_an_outstanding_read():
             "\tv_mov_b32_e32 v10, v0", "\tv_mov_b32_e32 v11, v4"]
     n, bad = chk.check("k", body)
     assert n == 2 and [b[1] for b in bad] == ["v_mov_b32_e32 v11, v4"]
+
+
+def test_the_checker_sees_an_operand_restored_right_before_an_mfma():
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_asm_loads as chk
+    mfma = "\tv_mfma_f32_32x32x16_bf16 v[82:97], v[124:127], a[132:135], v[82:97]"
+    # round 4: hipcc restored a parked K fragment in the instruction before the statement; one s_waitcnt between is one wait state, not two
+    n, bad = chk.check_mfma_operands("k", ["\tv_accvgpr_read_b32 v124, a80", "\ts_waitcnt lgkmcnt(1)", mfma])
+    assert n == 1 and len(bad) == 1 and bad[0][3].startswith("v_accvgpr_read_b32 v124")
+    n, bad = chk.check_mfma_operands("k", ["\tv_accvgpr_read_b32 v124, a80", "\ts_waitcnt lgkmcnt(1)", "\tv_fma_f32 v1, v2, s3, v4", mfma])
+    assert n == 1 and not bad
+    n, bad = chk.check_mfma_operands("k", ["\tv_accvgpr_write_b32 a133, v1", "\ts_nop 1", mfma])
+    assert n == 1 and not bad
+    n, bad = chk.check_mfma_operands("k", ["\tv_accvgpr_write_b32 a133, v1", "\ts_nop 0", mfma])
+    assert n == 1 and len(bad) == 1
