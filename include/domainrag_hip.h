@@ -26,8 +26,8 @@ int drag_version(void);
 const char* drag_last_error(void);
 /* Measurement switches (A/B of kernel variants inside one process; every setting computes the same function):
  *   "attn_sched" 0 | 1 | 2 (schedule of the attention kernel's KV-tile loop), "attn_w4" 0 | 1 (128-query blocks at any
- *   length), "attn_tune" bit 0: static wave priority, bit 1: 16-byte epilogue stores, "attn_q64" 0 | 1 (the 4-wave x 64-query
- *   experiment kernel for S >= 1024), "attn_persist" 0 | 1 | n >= 3 (persistent attention experiment: off, one workgroup per
+ *   length), "attn_tune" bit 0: static wave priority, bit 1: 16-byte epilogue stores, "attn_q64" 0 | 1 | 2 (the 4-wave x 64-query
+ *   kernel: by policy — joint sequences of 4096 keys and more that fill the chip | whenever S >= 1024 | never), "attn_persist" 0 | 1 | n >= 3 (persistent attention experiment: off, one workgroup per
  *   CU, n per XCD), "gemm_kernel", "gemm_group_m", "ln_generic", "topk_grid" (workgroups at most of the top-k scan, 0 = 512),
  *   "topk_depth" 0 | 3 (LDS-DMA ring depth of the scan), "topk_qt" 0 | 2 | 4 (query tiles per scan workgroup), "topk_select" 0 | 256 | 1024,
  *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima), "gemm_pair" 0 | 1 | 2

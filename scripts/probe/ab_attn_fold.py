@@ -1,3 +1,4 @@
+# needs scripts/probe/attention_fold_scale_max.patch applied (attn_tune bit 2 then selects the UNfolded 64-query kernel); the product build has no fold
 """the DiT's attention call (fused q preparation, B = 8, S = 5337): the 64-query kernel with the folded scale / maximum (attn_tune 2) against the
 unfolded one (attn_tune 6 = 2 | 4) and the 8-wave kernel (attn_q64 2), interleaved in one process; output distances"""
 import math, os, sys, statistics

@@ -1,3 +1,4 @@
+# needs scripts/probe/attention_fold_scale_max.patch applied (attn_tune bit 2 then selects the UNfolded 64-query kernel); the product build has no fold
 import math, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
