@@ -76,6 +76,53 @@ def test_attention_random_lengths(gpu):
         assert _rel(o, ref) < 1.5e-2, (case, B, S, H)
 
 
+def test_attention_q64_equals_the_8_wave_kernel_on_ragged_shapes(gpu):
+    """the hand-placed 64-query kernel (forced from S = 1024 on: "attn_q64" 1) against the 8-wave kernel, bit for bit: ragged last key tiles and
+    query blocks, (batch, head) counts that do not fill an XCD group, score scales that keep the deferred rescale quiet (0.5) and that fire it
+    on most tiles (6.0), odd and even tile counts, with and without the fused q preparation; oracle distance for the first case of each scale"""
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    rng = np.random.default_rng(11)
+    g = torch.Generator().manual_seed(5)
+    cases = [(1, 1024, 1), (1, 1025, 3), (2, 1087, 5), (1, 1100, 2), (3, 4096, 2), (1, 4097, 9), (1, 5337, 3), (2, 2111, 8), (1, 8191, 1)]
+    try:
+        for ci, (B, S, H) in enumerate(cases):
+            D = H * 128
+            scale_in = float(rng.choice([0.5, 1.0, 6.0])) if ci >= 3 else (0.5, 1.0, 6.0)[ci]
+            qkv = (torch.randn(B, S, 3 * D, generator=g) * scale_in).bfloat16().to(gpu)
+            s_txt = int(rng.integers(0, min(S, 600)))
+            w = [(1 + 0.1 * torch.randn(128, generator=g)).bfloat16().to(gpu) for _ in range(4)]
+            ang = torch.rand(S, 64, generator=g) * 6.28
+            cos, sin = torch.cos(ang).contiguous().to(gpu), torch.sin(ang).contiguous().to(gpu)
+            vt = torch.empty(B, H, 128, (S + 63) // 64 * 64, device=gpu, dtype=torch.bfloat16)
+            # two-pass route: q, k prepared in place
+            q2 = qkv.clone()
+            ops.qk_norm_rope_vt(q2, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
+            outs = {}
+            for q64 in (2, 1):
+                ops.set_option("attn_q64", q64)
+                o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
+                ops.attention(q2, q2.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+                outs[q64] = o.cpu()
+            assert torch.isfinite(outs[2].float()).all(), (B, S, H)
+            assert torch.equal(outs[1], outs[2]), ("two-pass", B, S, H, scale_in)
+            if ci < 3:
+                q, k, v = (qkv.cpu()[..., i * D:(i + 1) * D].view(B, S, H, 128).transpose(1, 2).float() for i in range(3))
+                assert _rel(outs[1], ops_ref.attention_ref(q, k, v, 1 / math.sqrt(128))) < 1.5e-2, (B, S, H, scale_in)
+            # fused route: k / v prepared by the pass, q inside the attention kernel
+            q3 = qkv.clone()
+            ops.k_norm_rope_vt(q3, vt, w[1], w[3], cos, sin, B, S, H, 3 * D, s_txt)
+            for q64 in (2, 1):
+                ops.set_option("attn_q64", q64)
+                o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
+                ops.attention_qprep(q3, q3.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128), w[0], w[2], cos, sin, s_txt)
+                outs[q64] = o.cpu()
+            assert torch.isfinite(outs[2].float()).all(), (B, S, H)
+            assert torch.equal(outs[1], outs[2]), ("fused q preparation", B, S, H, scale_in, s_txt)
+    finally:
+        ops.set_option("attn_q64", 0)
+
+
 def test_resample_random_sizes(gpu):
     from PIL import Image
     from domain_rag_amd import resample
