@@ -888,11 +888,17 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
       // the other 32 keys of a query live in lane ^ 32: v_permlane32_swap pairs the halves of both groups (no LDS round trip: a
       // ds_bpermute here waits out the K fragment reads already in flight).  swap(ra, rb) = ((ra.lo | rb.lo), (ra.hi | rb.hi)):
       // lanes < 32 then hold group A's two halves of query l, lanes >= 32 group B's of query l - 32
-      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ra), __builtin_bit_cast(unsigned, rb), false, false);
-      const float mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-      const auto sw2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
-      mt_carry[0] = __builtin_bit_cast(float, sw2[0]);      // (mx.lo | mx.lo): group A's maximum in both lane halves
-      mt_carry[1] = __builtin_bit_cast(float, sw2[1]);      // (mx.hi | mx.hi): group B's
+      // As asm: hipcc (ROCm 7.2) folds fmaxf(sw[0], sw[1]) of __builtin_amdgcn_permlane32_swap's two results to sw[0], and the two results
+      // of swap(x, x) to one value (the optimised IR holds a single extractvalue): the maxima then covered the keys of ONE lane half — every
+      // parity test passed (any reference value below the true maximum gives the same softmax until 2^(max - reference) overflows) and a key 128
+      // octaves above its row's running maximum gave NaN.  scripts/probe/dbg_attn_rescale*.py; test_attention_hot_key_in_every_lane_half.
+      // (v_permlane32_swap needs two wait states after the VALU write of its operands: the s_nop; its results need none.)
+      float mxa = ra, mxb = rb;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mxa), "+v"(mxb));        // (ra.lo | rb.lo), (ra.hi | rb.hi)
+      float mx = fmaxf(mxa, mxb), my = mx;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mx), "+v"(my));          // (mx.lo | mx.lo), (mx.hi | mx.hi)
+      mt_carry[0] = mx;                                     // group A's maximum in both lane halves
+      mt_carry[1] = my;                                     // group B's
       if (kv0 + 64 > p.S) {       // the ragged last tile: keys >= S do not exist (the trees above saw them) — once per (batch, head, query block)
 #pragma unroll
         for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(sc[qg], kv0);

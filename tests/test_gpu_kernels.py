@@ -285,6 +285,46 @@ def test_attention_q64_with_fused_q_prep_equals_the_8_wave_kernel(gpu, B, S, H, 
         ops.set_option("attn_q64", 0)
 
 
+@pytest.mark.parametrize("S", [1024, 4160])
+def test_attention_hot_key_in_every_lane_half(gpu, S):
+    """round 4: one key per run whose score sits 150 octaves above every row's running maximum, at each of the 64 positions of a KV tile
+    (tile 5; the two lane halves of a wave hold keys (0-3, 8-11, ...) and (4-7, 12-15, ...)): the row maximum must see it, or exp2 overflows.
+    The 64-query kernel's maxima once covered one lane half only (hipcc folds the two results of __builtin_amdgcn_permlane32_swap into
+    one): NaN for half of the positions, and no parity test noticed, because ANY reference value gives the same softmax until it
+    overflows.  Both kernel families, against each other bit for bit and against the exact answer (all mass on the hot key)"""
+    from domain_rag_amd import ops
+    B, H, D = 1, 1, 128
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(B, S, 3 * D, generator=g) * 0.3
+    qdir = torch.randn(D, generator=g); qdir /= qdir.norm()
+    base[0, :, :D] += qdir * 4.0
+    j = torch.arange(S)
+    v = torch.zeros(S, 128); v[j, j % 128] = 1.0
+    base[0, :, 2 * D:] = v
+    try:
+        for pos in list(range(0, 64, 3)) + [4, 5, 7, 13, 37, 63]:
+            x = base.clone()
+            hot = 5 * 64 + pos
+            x[0, hot, D:2 * D] = qdir * 300.0
+            qkv = x.bfloat16().to(gpu)
+            vt = torch.empty(B, H, 128, (S + 63) // 64 * 64, device=gpu, dtype=torch.bfloat16)
+            ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
+            outs = {}
+            for q64 in (2, 1):
+                ops.set_option("attn_q64", q64)
+                o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
+                ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+                outs[q64] = o.float().cpu()[0]
+            for q64, o in outs.items():
+                assert torch.isfinite(o).all(), (pos, q64, int(torch.isnan(o).any(1).sum()))
+                # rows with a usual q component along qdir put all their mass on the hot key: column hot % 128 of the one-hot V
+                mass = o[:, hot % 128]
+                assert (mass > 0.99).float().mean().item() > 0.95, (pos, q64, mass.min().item())
+            assert torch.equal(outs[1], outs[2]), pos
+    finally:
+        ops.set_option("attn_q64", 0)
+
+
 @pytest.mark.parametrize("B,S,H,s_txt", [(1, 4300, 8, 1241), (2, 4224, 8, 0), (3, 4161, 8, 512), (1, 5337, 24, 1241)])
 def test_persistent_attention_equals_the_one_item_kernel(gpu, B, S, H, s_txt):
     """round 3 experiment (off the product path: measured 1 % slower): the persistent attention kernel (one workgroup walks many
