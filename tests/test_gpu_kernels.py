@@ -285,10 +285,10 @@ def test_attention_q64_with_fused_q_prep_equals_the_8_wave_kernel(gpu, B, S, H, 
         ops.set_option("attn_q64", 0)
 
 
-@pytest.mark.parametrize("S", [1024, 4160])
+@pytest.mark.parametrize("S", [1087, 4160])
 def test_attention_hot_key_in_every_lane_half(gpu, S):
-    """round 4: one key per run whose score sits 150 octaves above every row's running maximum, at each of the 64 positions of a KV tile
-    (tile 5; the two lane halves of a wave hold keys (0-3, 8-11, ...) and (4-7, 12-15, ...)): the row maximum must see it, or exp2 overflows.
+    """round 4: one key per run whose score sits 150 octaves above every row's running maximum, at positions of a KV tile in both lane halves
+    (tile 5 densely, the first, second and last tile sparsely; the two lane halves of a wave hold keys (0-3, 8-11, ...) and (4-7, 12-15, ...)): the row maximum must see it, or exp2 overflows.
     The 64-query kernel's maxima once covered one lane half only (hipcc folds the two results of __builtin_amdgcn_permlane32_swap into
     one): NaN for half of the positions, and no parity test noticed, because ANY reference value gives the same softmax until it
     overflows.  Both kernel families, against each other bit for bit and against the exact answer (all mass on the hot key)"""
@@ -301,10 +301,13 @@ def test_attention_hot_key_in_every_lane_half(gpu, S):
     j = torch.arange(S)
     v = torch.zeros(S, 128); v[j, j % 128] = 1.0
     base[0, :, 2 * D:] = v
+    last = (S - 1) // 64
+    # tile 5 at many positions; the first tile (maxima from the prologue) and the last one (ragged for S = 1087: 63 keys) at a few
+    where = [(5, pos) for pos in list(range(0, 64, 3)) + [4, 5, 7, 13, 37, 63]] + [(t, pos) for t in (0, 1, last) for pos in (0, 6, 33, 44, (S - 1) % 64)]
     try:
-        for pos in list(range(0, 64, 3)) + [4, 5, 7, 13, 37, 63]:
+        for tile, pos in where:
             x = base.clone()
-            hot = 5 * 64 + pos
+            hot = tile * 64 + pos
             x[0, hot, D:2 * D] = qdir * 300.0
             qkv = x.bfloat16().to(gpu)
             vt = torch.empty(B, H, 128, (S + 63) // 64 * 64, device=gpu, dtype=torch.bfloat16)
@@ -316,11 +319,31 @@ def test_attention_hot_key_in_every_lane_half(gpu, S):
                 ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
                 outs[q64] = o.float().cpu()[0]
             for q64, o in outs.items():
-                assert torch.isfinite(o).all(), (pos, q64, int(torch.isnan(o).any(1).sum()))
+                assert torch.isfinite(o).all(), (tile, pos, q64, int(torch.isnan(o).any(1).sum()))
                 # rows with a usual q component along qdir put all their mass on the hot key: column hot % 128 of the one-hot V
                 mass = o[:, hot % 128]
-                assert (mass > 0.99).float().mean().item() > 0.95, (pos, q64, mass.min().item())
-            assert torch.equal(outs[1], outs[2]), pos
+                assert (mass > 0.99).float().mean().item() > 0.95, (tile, pos, q64, mass.min().item())
+            assert torch.equal(outs[1], outs[2]), (tile, pos)
+        # the fused q preparation: q and k are RMS-normalised, so a key parallel to every query sits 16 octaves up — the deferred rescale
+        # (threshold 8) fires at its tile, in whichever lane half it lives
+        ones = torch.ones(128).bfloat16().to(gpu)
+        cos, sin = torch.ones(S, 64, device=gpu), torch.zeros(S, 64, device=gpu)
+        for tile, pos in [(5, 2), (5, 5), (5, 36), (5, 47), (1, 4), (last, 6)]:
+            x = base.clone()
+            x[0, :, :D] = qdir * 4.0 + torch.randn(S, D, generator=g) * 0.05
+            hot = tile * 64 + pos
+            x[0, hot, D:2 * D] = qdir * 4.0
+            qkv = x.bfloat16().to(gpu)
+            vt = torch.empty(B, H, 128, (S + 63) // 64 * 64, device=gpu, dtype=torch.bfloat16)
+            ops.k_norm_rope_vt(qkv, vt, ones, ones, cos, sin, B, S, H, 3 * D, 0)
+            for q64 in (2, 1):
+                ops.set_option("attn_q64", q64)
+                o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
+                ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128), ones, ones, cos, sin, 0)
+                outs[q64] = o.float().cpu()[0]
+            assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[2]).all(), (tile, pos)
+            assert (outs[1][:, hot % 128] > 0.9).float().mean().item() > 0.95, (tile, pos, outs[1][:, hot % 128].min().item())
+            assert torch.equal(outs[1], outs[2]), ("fused q preparation", tile, pos)
     finally:
         ops.set_option("attn_q64", 0)
 
