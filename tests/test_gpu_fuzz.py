@@ -275,6 +275,41 @@ def test_topk_fuzz_with_ties_nonfinite_rows_and_every_measurement_option(gpu):
             ops.set_option(n_, 0)
 
 
+def test_topk_adversarial_score_layouts(gpu):
+    """score layouts chosen against the top-k's shortcuts (a threshold from a strided sample, a filtered scan into bounded per-wave regions):
+    every row equal; scores rising / falling with the row index; the top k inside one 16-row group; large scores ONLY on rows a strided
+    sample of stride 2 / 4 / 8 / 16 / 32 / 64 never visits (the sample's threshold is then far too low and nearly every row is a candidate);
+    two score levels with far more than k rows on the upper one.  (D, I) are the oracle's bit for bit, for Q = 1, 16 and 64"""
+    import numpy as np
+    import torch
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(5)
+    N, d, k = 40000, 64, 100
+    u = rng.standard_normal(d).astype(np.float32); u /= np.linalg.norm(u)
+    idx = np.arange(N)
+    layouts = {
+        "all rows equal": np.ones(N),
+        "rising": 1.0 + idx / N,
+        "falling": 2.0 - idx / N,
+        "top k in one group": np.where((idx >= 16 * 777) & (idx < 16 * 777 + 16), 5.0 + idx % 16, 1.0 + 1e-3 * (idx % 7)),
+        "two levels": np.where(idx % 3 == 0, 2.0, 1.0),
+    }
+    for stride in (2, 4, 8, 16, 32, 64):
+        layouts[f"large off the stride-{stride} sample"] = np.where(idx % stride == stride - 1, 3.0 + 1e-4 * (idx % 1000), 1e-3 * (1 + idx % 5))
+    for name, w in layouts.items():
+        # rows are multiples of one direction (cosine similarity would make them all equal), plus a small orthogonal part that sets the norm:
+        # score_i = w_i / sqrt(w_i^2 + c^2) is monotone in w_i
+        v = rng.standard_normal(d).astype(np.float32); v -= u * (v @ u); v /= np.linalg.norm(v)
+        corpus = (w[:, None].astype(np.float32) * u[None, :] + 1.5 * v[None, :]).astype(np.float32)
+        for Q in (1, 16, 64):
+            q = (u[None, :] * (1 + np.arange(Q)[:, None] / 8) + 0.01 * rng.standard_normal((Q, d))).astype(np.float32)
+            D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(q).to(gpu), k)
+            Dr, Ir = oret.cosine_topk(corpus, q, k)
+            assert np.array_equal(I.cpu().numpy(), Ir), (name, Q)
+            assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), (name, Q)
+
+
 def test_gemm_pair_random_configs(gpu):
     """round 3: seeded random two-segment launches (row counts from 1 to a few thousand per segment, batched row maps, every epilogue
     form, the policy's kernel and forced ones) against the same two problems as separate launches: equal bits, nothing written

@@ -324,6 +324,24 @@ def test_attention_hot_key_in_every_lane_half(gpu, S):
                 mass = o[:, hot % 128]
                 assert (mass > 0.99).float().mean().item() > 0.95, (tile, pos, q64, mass.min().item())
             assert torch.equal(outs[1], outs[2]), (tile, pos)
+        # every schedule / block shape of the 8-wave family on two hot positions (one per lane half)
+        for tile, pos in [(5, 5), (5, 36)]:
+            x = base.clone()
+            hot = tile * 64 + pos
+            x[0, hot, D:2 * D] = qdir * 300.0
+            qkv = x.bfloat16().to(gpu)
+            vt = torch.empty(B, H, 128, (S + 63) // 64 * 64, device=gpu, dtype=torch.bfloat16)
+            ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
+            ops.set_option("attn_q64", 2)
+            got = {}
+            for sched, w4, tune in [(2, 0, 2), (0, 0, 0), (1, 0, 0), (2, 0, 3), (1, 1, 2), (2, 1, 0)]:
+                ops.set_option("attn_sched", sched); ops.set_option("attn_w4", w4); ops.set_option("attn_tune", tune)
+                o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
+                ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+                got[(sched, w4, tune)] = o.float().cpu()[0]
+            for key, o in got.items():
+                assert torch.isfinite(o).all() and torch.equal(o, got[(2, 0, 2)]), (tile, pos, key)
+        ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2)
         # the fused q preparation: q and k are RMS-normalised, so a key parallel to every query sits 16 octaves up — the deferred rescale
         # (threshold 8) fires at its tile, in whichever lane half it lives
         ones = torch.ones(128).bfloat16().to(gpu)
@@ -345,7 +363,7 @@ def test_attention_hot_key_in_every_lane_half(gpu, S):
             assert (outs[1][:, hot % 128] > 0.9).float().mean().item() > 0.95, (tile, pos, outs[1][:, hot % 128].min().item())
             assert torch.equal(outs[1], outs[2]), ("fused q preparation", tile, pos)
     finally:
-        ops.set_option("attn_q64", 0)
+        ops.set_option("attn_q64", 0); ops.set_option("attn_sched", 2); ops.set_option("attn_w4", 0); ops.set_option("attn_tune", 2)
 
 
 @pytest.mark.parametrize("B,S,H,s_txt", [(1, 4300, 8, 1241), (2, 4224, 8, 0), (3, 4161, 8, 512), (1, 5337, 24, 1241)])
