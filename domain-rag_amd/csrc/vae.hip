@@ -16,7 +16,10 @@
 namespace {
 
 // ------------------------------------------------------------------ GroupNorm
-// pass 1: per (image, pixel chunk) partial sums for every unit of 4 channels
+// pass 1: per (image, pixel chunk) partial sums for every unit of 4 channels.  Sums are taken of x − c and (x − c)² with c = the group's
+// first element (pixel 0, first channel): E[x²] − E[x]² in float32 partials loses the variance of a group whose mean is large against its
+// spread (mean 100, spread 0.3: 1e4 · 1e-6 of rounding against a variance of 0.1), torch's GroupNorm (Welford) does not; any c near the
+// mean removes the cancellation and costs two subtractions per element of an HBM-bound pass.
 struct GnPartArgs {
   const bf16_t* x;   // [B, HW, C]
   float* part;       // [B, nchunks, C/4, 2]
@@ -31,13 +34,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnPartArgs p) {
   const int b = blockIdx.y, ch = blockIdx.x;
   const int p0 = ch * p.chunk, p1 = min(p0 + p.chunk, p.HW);
   const bf16_t* xb = p.x + (long long)b * p.HW * p.C;
+  const int cpg = p.C / 32;                  // channels per group (4, 8 or 16): a unit of 4 channels lies inside one group
+  const float sh0 = bf2f(xb[((slot * 8) / cpg) * cpg]), sh1 = bf2f(xb[((slot * 8 + 4) / cpg) * cpg]);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   for (int px = p0 + prow; px < p1; px += pstep) {
     const u32x4_t raw = *(const u32x4_t*)(xb + (long long)px * p.C + slot * 8);
-    const float a0 = bf2f((bf16_t)(raw[0] & 0xffff)), a1 = bf2f((bf16_t)(raw[0] >> 16));
-    const float a2 = bf2f((bf16_t)(raw[1] & 0xffff)), a3 = bf2f((bf16_t)(raw[1] >> 16));
-    const float c0 = bf2f((bf16_t)(raw[2] & 0xffff)), c1 = bf2f((bf16_t)(raw[2] >> 16));
-    const float c2 = bf2f((bf16_t)(raw[3] & 0xffff)), c3 = bf2f((bf16_t)(raw[3] >> 16));
+    const float a0 = bf2f((bf16_t)(raw[0] & 0xffff)) - sh0, a1 = bf2f((bf16_t)(raw[0] >> 16)) - sh0;
+    const float a2 = bf2f((bf16_t)(raw[1] & 0xffff)) - sh0, a3 = bf2f((bf16_t)(raw[1] >> 16)) - sh0;
+    const float c0 = bf2f((bf16_t)(raw[2] & 0xffff)) - sh1, c1 = bf2f((bf16_t)(raw[2] >> 16)) - sh1;
+    const float c2 = bf2f((bf16_t)(raw[3] & 0xffff)) - sh1, c3 = bf2f((bf16_t)(raw[3] >> 16)) - sh1;
     s0 += (a0 + a1) + (a2 + a3);
     q0 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     s1 += (c0 + c1) + (c2 + c3);
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnPartArgs p) {
 }
 
 // pass 2: per (image, group) mean / rstd, accumulated in double in a fixed order
-__global__ void gn_finalize_kernel(const float* part, float* stats, int nchunks, int C, int G, int HW, float eps) {
+__global__ void gn_finalize_kernel(const bf16_t* x, const float* part, float* stats, int nchunks, int C, int G, int HW, float eps) {
   const int b = blockIdx.x, g = threadIdx.x;
   if (g >= G) return;
   const int upg = (C / G) / 4;  // units of 4 channels per group
@@ -68,9 +73,10 @@ __global__ void gn_finalize_kernel(const float* part, float* stats, int nchunks,
       s += o[0]; q += o[1];
     }
   const double n = (double)HW * (C / G);
-  const double mean = s / n;
-  double var = q / n - mean * mean;
+  const double dm = s / n;                   // mean of x − c
+  double var = q / n - dm * dm;
   if (var < 0) var = 0;
+  const double mean = (double)bf2f(x[(long long)b * HW * C + g * (C / G)]) + dm;
   stats[(b * G + g) * 2] = (float)mean;
   stats[(b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
@@ -327,7 +333,7 @@ extern "C" int drag_groupnorm_silu_bf16(const void* x, void* y, const void* gamm
   GnPartArgs pa{(const bf16_t*)x, part, HW, C, 1024};
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, B), dim3(256), 0, st, pa);
   DRAG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, (const float*)part, stats, nchunks, C, groups, HW, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, (const bf16_t*)x, (const float*)part, stats, nchunks, C, groups, HW, eps);
   DRAG_LAUNCH_CHECK();
   GnApplyArgs aa{(const bf16_t*)x, (bf16_t*)y, (const bf16_t*)gamma, (const bf16_t*)beta, stats, B, H, W, C, groups, out_pad, silu};
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long long)B * HW * (C / 8))), dim3(256), 0, st, aa);
