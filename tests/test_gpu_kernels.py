@@ -788,6 +788,47 @@ def test_specialised_epilogue_equals_the_general_one(gpu, M, N, K, rpb):
         ops.set_option("gemm_kernel", 0); ops.set_option("gemm_epilogue", 0)
 
 
+@pytest.mark.parametrize("M,N,K,rpb", [(1024, 768, 512, 256), (600, 520, 1024, 300), (2560, 512, 256, 1280)])
+def test_gemm_epilogue_rounding_order_is_torchs_bit_for_bit(gpu, M, N, K, rpb):
+    """the epilogues' sequence of bf16 roundings against torch's own (oracle/ops_ref.gemm_ref: Linear -> round, gate * y -> round,
+    x + . -> round), bit for bit, on operands whose dot products are EXACT in float32 (small integers times halves: sums below 2^11), with
+    magnitudes at which every rounding step moves the result (sums of several hundred: bf16 steps of 2-4; biases, gates and residuals with
+    full bf16 mantissas).  Random N(0, 1) operands only ever meet this with a 1.5 % tolerance.  Every kernel family, specialised and
+    general epilogue"""
+    from domain_rag_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randint(-3, 4, (M, K), generator=g).float().bfloat16()
+    w = (torch.randint(-2, 3, (N, K), generator=g).float() * 0.5).bfloat16()
+    bias = (torch.randn(N, generator=g) * 40).bfloat16()
+    nb = M // rpb
+    gate = (torch.randn(nb, N, generator=g) * 1.7).bfloat16()
+    resid = (torch.randn(M, N, generator=g) * 90).bfloat16()
+    want = {"bias": ops_ref.gemm_ref(a, w, bias), "plain": ops_ref.gemm_ref(a, w, None),
+            "resid": ops_ref.gemm_ref(a, w, bias, resid=resid), "gate": ops_ref.gemm_ref(a, w, bias, gate=gate, resid=resid, rows_per_batch=rpb)}
+    exact = a.double() @ w.double().T
+    assert exact.abs().max() < 2048 and (exact.float().double() == exact).all()
+    ad, wd, bd, gd = a.to(gpu), w.to(gpu), bias.to(gpu), gate.to(gpu)
+    codes = [0, 1, 43, 23, 14] + ([2] if N >= 256 and K >= 256 else [])
+    try:
+        for code in codes:
+            for epi in (0, 1):
+                ops.set_option("gemm_kernel", code); ops.set_option("gemm_epilogue", epi)
+                got = {"bias": ops.gemm(ad, wd, bias=bd), "plain": ops.gemm(ad, wd)}
+                x = resid.to(gpu).clone()
+                ops.gemm(ad, wd, out=x, bias=bd, M=M, lda=K, ldc=N, resid=x)
+                got["resid"] = x
+                y = resid.to(gpu).clone()
+                ops.gemm(ad, wd, out=y, bias=bd, M=M, lda=K, ldc=N, c_rows_per_batch=rpb, c_batch_stride=rpb * N, gate=gd, resid=y, ldg=N)
+                got["gate"] = y
+                for name, t in got.items():
+                    t = t.cpu()
+                    same = (t == want[name]).float().mean().item()
+                    assert torch.equal(t, want[name]), (code, epi, name, same, (t.float() - want[name].float()).abs().max().item())
+    finally:
+        ops.set_option("gemm_kernel", 0); ops.set_option("gemm_epilogue", 0)
+
+
 @pytest.mark.parametrize("M1,M2,N,K", [(1024, 512, 768, 256), (1000, 77, 520, 192), (300, 1300, 1536, 320), (40, 24, 384, 128), (2304, 1100, 1024, 256)])
 def test_gemm_pair_equals_two_gemms(gpu, M1, M2, N, K):
     """round 3: drag_gemm_bf16_pair — a double block's image-stream and text-stream Linears (own A, W, bias, gate, residual, output
