@@ -874,31 +874,31 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
         else q64_max3(u[3], t[9], el(qg, 30), el(qg, 31));
       };
 #define Q64P_T(dt, qg) Q64P_MFMA_O(oacc[qg][dt], vtr[dt], pk[qg][3])
-      Q64P_T(0, 0); L1(ta, 0, 0); L1(ta, 0, 1); L1(ta, 0, 2); L1(ta, 0, 3);
-      Q64P_T(0, 1); L1(ta, 0, 4); L1(ta, 0, 5); L1(ta, 0, 6); L1(ta, 0, 7);
-      Q64P_T(1, 0); L1(ta, 0, 8); L1(ta, 0, 9); L1(tb, 1, 0); L1(tb, 1, 1);
-      Q64P_T(1, 1); L1(tb, 1, 2); L1(tb, 1, 3); L1(tb, 1, 4); L1(tb, 1, 5);
-      Q64P_T(2, 0); L1(tb, 1, 6); L1(tb, 1, 7); L1(tb, 1, 8); L1(tb, 1, 9);
-      Q64P_T(2, 1); L2(ua, ta, 0, 0); L2(ua, ta, 0, 1); L2(ua, ta, 0, 2); L2(ua, ta, 0, 3);
-      Q64P_T(3, 0); L2(ub, tb, 1, 0); L2(ub, tb, 1, 1); L2(ub, tb, 1, 2); L2(ub, tb, 1, 3);
-      Q64P_T(3, 1); q64_max3(ra, ua[0], ua[1], ua[2]); q64_max3(rb, ub[0], ub[1], ub[2]);
-#undef Q64P_T
-      q64_landed<0>(kfr[0], kfr[1]);
-      ra = fmaxf(ra, ua[3]); rb = fmaxf(rb, ub[3]);
-      // the other 32 keys of a query live in lane ^ 32: v_permlane32_swap pairs the halves of both groups (no LDS round trip: a
-      // ds_bpermute here waits out the K fragment reads already in flight).  swap(ra, rb) = ((ra.lo | rb.lo), (ra.hi | rb.hi)):
-      // lanes < 32 then hold group A's two halves of query l, lanes >= 32 group B's of query l - 32
+      // six v_max3 behind each of the first five MFMAs (what a lone wave hides behind 32 cycles); the joining of the lane halves behind the
+      // last three: the other 32 keys of a query live in lane ^ 32, v_permlane32_swap pairs the halves of both groups (no LDS round trip: a
+      // ds_bpermute here waits out the K fragment reads already in flight).  swap(ra, rb) = ((ra.lo | rb.lo), (ra.hi | rb.hi)): lanes < 32 then
+      // hold group A's two halves of query l, lanes >= 32 group B's of query l - 32; their maximum, swapped with itself, is group A's value in
+      // both halves of the first result and group B's in the second.  (The swap needs two wait states after the VALU write of its operands:
+      // the MFMA between and one s_nop.)
       // As asm: hipcc (ROCm 7.2) folds fmaxf(sw[0], sw[1]) of __builtin_amdgcn_permlane32_swap's two results to sw[0], and the two results
       // of swap(x, x) to one value (the optimised IR holds a single extractvalue): the maxima then covered the keys of ONE lane half — every
       // parity test passed (any reference value below the true maximum gives the same softmax until 2^(max - reference) overflows) and a key 128
       // octaves above its row's running maximum gave NaN.  scripts/probe/dbg_attn_rescale*.py; test_attention_hot_key_in_every_lane_half.
-      // (v_permlane32_swap needs two wait states after the VALU write of its operands: the s_nop; its results need none.)
-      float mxa = ra, mxb = rb;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mxa), "+v"(mxb));        // (ra.lo | rb.lo), (ra.hi | rb.hi)
-      float mx = fmaxf(mxa, mxb), my = mx;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mx), "+v"(my));          // (mx.lo | mx.lo), (mx.hi | mx.hi)
-      mt_carry[0] = mx;                                     // group A's maximum in both lane halves
-      mt_carry[1] = my;                                     // group B's
+      Q64P_T(0, 0); L1(ta, 0, 0); L1(ta, 0, 1); L1(ta, 0, 2); L1(ta, 0, 3); L1(ta, 0, 4); L1(ta, 0, 5);
+      Q64P_T(0, 1); L1(ta, 0, 6); L1(ta, 0, 7); L1(ta, 0, 8); L1(ta, 0, 9); L1(tb, 1, 0); L1(tb, 1, 1);
+      Q64P_T(1, 0); L1(tb, 1, 2); L1(tb, 1, 3); L1(tb, 1, 4); L1(tb, 1, 5); L1(tb, 1, 6); L1(tb, 1, 7);
+      Q64P_T(1, 1); L1(tb, 1, 8); L1(tb, 1, 9); L2(ua, ta, 0, 0); L2(ua, ta, 0, 1); L2(ua, ta, 0, 2); L2(ua, ta, 0, 3);
+      Q64P_T(2, 0); L2(ub, tb, 1, 0); L2(ub, tb, 1, 1); L2(ub, tb, 1, 2); L2(ub, tb, 1, 3); q64_max3(ra, ua[0], ua[1], ua[2]); q64_max3(rb, ub[0], ub[1], ub[2]);
+      asm volatile("v_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3" : "+v"(ra), "+v"(rb) : "v"(ua[3]), "v"(ub[3]));
+      Q64P_T(2, 1);
+      asm volatile("s_nop 0\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0" : "+v"(ra), "+v"(rb));
+      Q64P_T(3, 0);
+      asm volatile("s_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ra), "+v"(rb));
+      Q64P_T(3, 1);
+#undef Q64P_T
+      q64_landed<0>(kfr[0], kfr[1]);
+      mt_carry[0] = ra;                                     // group A's maximum in both lane halves
+      mt_carry[1] = rb;                                     // group B's
       if (kv0 + 64 > p.S) {       // the ragged last tile: keys >= S do not exist (the trees above saw them) — once per (batch, head, query block)
 #pragma unroll
         for (int qg = 0; qg < 2; ++qg) mt_carry[qg] = mask_and_max(sc[qg], kv0);
