@@ -681,21 +681,23 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   const bf16_t* vbase = p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
   __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.vt_bytes, 0x00020000);
-  int krow[4];
-  unsigned kslot[4], voff[4];
+  // K staging offsets: lane's row of piece i inside a tile and its swizzled 16-byte slot as ONE loop-invariant byte offset; a piece's address is
+  // that plus the tile's (uniform) byte offset — one v_add_u32 per piece (the clamp min(row, S - 1) and its 64-bit multiply-add cost three
+  // VALU instructions per piece in a loop bound by its issue slots).  Rows past S fall outside the (batch, head) descriptor: the LDS-DMA
+  // writes zeros for them, and their scores are masked by the ragged-tile path like the clamped copies of row S - 1 were.
+  unsigned koff[4], voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = w * CPW + i;
-    krow[i] = c * 4 + (l >> 4);
-    kslot[i] = (unsigned)(((l & 15) ^ (krow[i] & 15)) * 16);
+    const int krow = c * 4 + (l >> 4);
+    koff[i] = (unsigned)krow * (unsigned)(p.ld_qk * 2) + (unsigned)(((l & 15) ^ (krow & 15)) * 16);
     const int vrow = c * 8 + (l >> 3);
     const int vslot = (l & 7) ^ ((vrow >> 1) & 7);
     voff[i] = (unsigned)(((long long)vrow * p.s_pad + vslot * 8) * 2);
   }
   auto stage_k1 = [&](int buf, int kv0, int i) {
     const int c = w * CPW + i;
-    const int kr = min(kv0 + krow[i], p.S - 1);
-    const unsigned ko = (unsigned)((long long)kr * p.ld_qk * 2) + kslot[i];
+    const unsigned ko = koff[i] + (unsigned)kv0 * (unsigned)(p.ld_qk * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024), 16, ko, 0, 0, 0);
   };
   auto stage_v1 = [&](int buf, int kv0, int i) {
