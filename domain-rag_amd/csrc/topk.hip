@@ -59,7 +59,7 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src) {
 }
 
 // ------------------------------------------------------------------ scan
-enum { SCAN_SCORES = 0, SCAN_KEYS_DENSE = 1, SCAN_KEYS_FILTER = 2, SCAN_GROUP_MAX = 3 };
+enum { SCAN_SCORES = 0, SCAN_KEYS_DENSE = 1, SCAN_KEYS_FILTER = 2, SCAN_GROUP_MAX = 3, SCAN_SCORES_GMAX = 4 };
 struct ScanArgs {
   const float* corpus;
   const float* queries;  // [Q, d], Q <= 64 in one launch
@@ -73,6 +73,7 @@ struct ScanArgs {
   long long npad;
   // SCAN_KEYS_DENSE: keys[q * kstride + 16 * i + r] = composite(score, row), 0 for rows >= N
   // SCAN_GROUP_MAX: keys[q * kstride + i] = the best composite among the 16 rows of group(i) (0 if the group has no row)
+  // SCAN_SCORES_GMAX: both of SCAN_SCORES and SCAN_GROUP_MAX in one pass (the two-launch top-k call)
   // SCAN_KEYS_FILTER: wave v = worker * 4 + w appends the composites >= thresh[q] it finds to its own region
   //   keys[q * kstride + v * region_cap + n], n = 0, 1, ...; counts[q * nregions + v] = how many
   u64* keys;
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(256, 2) void ip_scan_kernel(ScanArgs p) {
             ncand[t] += (unsigned)__popcll(m);
           }
         }
-      } else if (p.mode == SCAN_GROUP_MAX) {
+      } else if (p.mode == SCAN_GROUP_MAX || p.mode == SCAN_SCORES_GMAX) {
+        if (p.mode == SCAN_SCORES_GMAX && qq < p.Q) *(f32x4_t*)(p.scores + (long long)qq * p.npad + row0 + 4 * g) = acc[t];
         u64 m = 0ull;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -485,6 +487,181 @@ __global__ __launch_bounds__(NT) void select_kernel(SelArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ selection through the row groups' maxima (two-launch call)
+// The scan left every score [Q, npad] and the best composite of every group of 16 rows [Q, gstride] (ngroups <= LMAX, k <= 128).
+// The k-th best GROUP maximum T is a lower bound of the answer's k-th best composite (k different rows reach it), and — keys
+// being unique — exactly k groups have a maximum >= T: every row of the answer lives in one of those k groups.  So the
+// selection reads ngroups keys, then 16 k scores, and never more: no sample launch, no threshold launch, no candidate regions,
+// and the worst case is the common case (a corpus that defeats a strided sample does not exist for this form).
+struct GroupSelArgs {
+  const u64* gmax;        // [Q, gstride]
+  long long gstride;
+  int ngroups;
+  const float* scores;    // [Q, npad]
+  long long npad, N;
+  int k;
+  float* out_d;
+  long long* out_i;
+};
+
+struct KthScratch {
+  unsigned hist[256];
+  unsigned need, done;
+  u64 prefix;
+  u64 red_or[16], red_and[16];
+};
+
+// the k-th largest of more than k unique keys spread over the workgroup's threads: T with exactly k keys >= T (the radix select of
+// select_kernel: bits common to all keys skipped, 8 bits per pass, early exit when the bin that holds the k-th key holds exactly what
+// is still needed).  each(f) calls f(x) for every key the thread holds (registers or LDS); vor / vand = OR / AND over those keys.
+// Called by all NT threads; ends behind a barrier.
+template <int NT, class Each>
+__device__ __forceinline__ u64 kth_largest(Each each, int k, KthScratch& s, u64 vor, u64 vand) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { vor |= shfl64(vor, lane ^ m); vand &= shfl64(vand, lane ^ m); }
+  if (lane == 0) { s.red_or[wv] = vor; s.red_and[wv] = vand; }
+  if (tid == 0) { s.need = (unsigned)k; s.done = 0u; }
+  __syncthreads();
+  u64 aor = 0ull, aand = ~0ull;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) { aor |= s.red_or[i]; aand &= s.red_and[i]; }
+  const u64 diff = aor ^ aand;
+  if (diff == 0ull) { __syncthreads(); return aand; }
+  const int hb = 63 - __builtin_clzll(diff);
+  u64 mask = hb == 63 ? 0ull : ~((2ull << hb) - 1ull);
+  if (tid == 0) s.prefix = aand & mask;
+  int sh = max(hb - 7, 0), width = hb - sh + 1;
+  while (true) {
+    if (tid < 256) s.hist[tid] = 0u;
+    __syncthreads();
+    if (s.done) break;
+    const u64 prefix = s.prefix;
+    const unsigned need = s.need;
+    const unsigned dm = (1u << width) - 1u;
+    each([&](u64 x) {
+      if ((x & mask) == prefix) atomicAdd(&s.hist[(unsigned)(x >> sh) & dm], 1u);
+    });
+    __syncthreads();
+    if (tid < 64) {                       // wave 0 scans the 256 bins from the top: lane i owns bins 255-4i .. 252-4i
+      unsigned h[4], s4 = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h[j] = s.hist[255 - 4 * tid - j]; s4 += h[j]; }
+      unsigned incl = s4;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if (tid >= off) incl += v;
+      }
+      unsigned run = incl - s4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (run < need && need <= run + h[j]) {
+          s.need = need - run;
+          s.prefix = prefix | ((u64)(255 - 4 * tid - j) << sh);
+          if (h[j] == need - run) s.done = 1u;
+        }
+        run += h[j];
+      }
+    }
+    mask |= ((u64)dm << sh);
+    __syncthreads();
+    if (sh == 0) break;
+    const int nsh = max(sh - 8, 0);
+    width = sh - nsh;
+    sh = nsh;
+  }
+  const u64 T = s.prefix;
+  __syncthreads();                        // the scratch may be reused
+  return T;
+}
+
+constexpr int GSEL_NT = 1024;
+constexpr int GSEL_KMAX = 128;
+constexpr int GSEL_R = LMAX / GSEL_NT;    // group maxima per thread, in registers
+constexpr int GSEL_RANK_MAX = 512;        // candidates up to which ranks are counted directly (no second radix select)
+__global__ __launch_bounds__(GSEL_NT) void select_groups_kernel(GroupSelArgs p) {
+  __shared__ u64 cand[16 * GSEL_KMAX];    // the rows of the k best groups that reach T
+  __shared__ u64 srt[GSEL_KMAX];
+  __shared__ unsigned grp[GSEL_KMAX];
+  __shared__ KthScratch ks;
+  __shared__ unsigned n_grp, n_cand, n_sel;
+  const int tid = threadIdx.x, q = blockIdx.x;
+  const int L = p.ngroups, k = p.k;
+  const u64* src = p.gmax + (long long)q * p.gstride;
+  // every load of the thread in flight at once (a loop of load -> use would pay the memory latency GSEL_R times)
+  u64 r[GSEL_R];
+#pragma unroll
+  for (int j = 0; j < GSEL_R; ++j) {
+    const int i = tid + j * GSEL_NT;
+    r[j] = i < L ? src[i] : 0ull;         // 0 = no key (a real composite is never 0)
+  }
+  if (tid == 0) { n_grp = 0u; n_cand = 0u; n_sel = 0u; }
+  u64 vor = 0ull, vand = ~0ull;
+#pragma unroll
+  for (int j = 0; j < GSEL_R; ++j)
+    if (r[j]) { vor |= r[j]; vand &= r[j]; }
+  const u64 T = kth_largest<GSEL_NT>([&](auto f) {
+#pragma unroll
+    for (int j = 0; j < GSEL_R; ++j)
+      if (r[j]) f(r[j]);
+  }, k, ks, vor, vand);                   // more than SAMPLE_GROUPS >= k keys
+#pragma unroll
+  for (int j = 0; j < GSEL_R; ++j)
+    if (r[j] >= T && r[j]) grp[atomicAdd(&n_grp, 1u)] = (~(unsigned)(r[j] & 0xffffffffull)) >> 4;   // the group of the key's row: exactly k of them
+  __syncthreads();
+  const float* sc = p.scores + (long long)q * p.npad;
+  float v[2];
+  long long row[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {           // 16 k <= 2048 scores: both loads of the thread in flight
+    const int i = tid + j * GSEL_NT;
+    row[j] = i < 16 * k ? (long long)grp[i >> 4] * 16 + (i & 15) : p.N;
+    v[j] = row[j] < p.N ? sc[row[j]] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (row[j] < p.N) {
+      const u64 x = composite(v[j], (unsigned)row[j]);
+      if (x >= T) cand[atomicAdd(&n_cand, 1u)] = x;
+    }
+  __syncthreads();
+  const int C = (int)n_cand;              // >= k: the k group maxima are among them
+  if (C <= GSEL_RANK_MAX) {
+    // a candidate's rank = the number of larger candidates (keys are unique): ranks below k are the answer, already in order
+    if (tid < C) {
+      const u64 x = cand[tid];
+      int rank = 0;
+      for (int j = 0; j < C; ++j) rank += cand[j] > x;
+      if (rank < k) {
+        const long long o = (long long)q * k + rank;
+        p.out_d[o] = okey_inv((unsigned)(x >> 32));
+        p.out_i[o] = (long long)(~(unsigned)(x & 0xffffffffull));
+      }
+    }
+    return;
+  }
+  // many candidates (the answer's groups are full of high scorers): a second radix select, then the rank sort over k keys
+  u64 cor = 0ull, cand_and = ~0ull;
+  for (int i = tid; i < C; i += GSEL_NT) { cor |= cand[i]; cand_and &= cand[i]; }
+  const u64 T2 = kth_largest<GSEL_NT>([&](auto f) {
+    for (int i = tid; i < C; i += GSEL_NT) f(cand[i]);
+  }, k, ks, cor, cand_and);
+  for (int i = tid; i < C; i += GSEL_NT) {
+    const u64 x = cand[i];
+    if (x >= T2) srt[atomicAdd(&n_sel, 1u)] = x;
+  }
+  __syncthreads();
+  for (int i = tid; i < k; i += GSEL_NT) {
+    const u64 x = srt[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) rank += srt[j] > x;
+    const long long o = (long long)q * k + rank;
+    p.out_d[o] = okey_inv((unsigned)(x >> 32));
+    p.out_i[o] = (long long)(~(unsigned)(x & 0xffffffffull));
+  }
+}
+
 struct L2Args { float* x; long long rows; int d; };
 __global__ __launch_bounds__(256) void l2norm_kernel(L2Args p) {
   const int w = wave_id(), l = lane_id();
@@ -611,6 +788,21 @@ extern "C" int drag_cosine_topk_f32(const float* corpus, const float* queries, i
     sa.corpus = corpus; sa.queries = queries + (long long)q0 * d; sa.N = N; sa.d = d; sa.Q = qn; sa.ntile = (qn + 15) / 16;
     SelArgs se{};
     se.k = k; se.kpad = kpad;
+    // two launches through the group maxima (select_groups_kernel): every group maximum fits one workgroup's LDS and k groups
+    // of 16 rows bound the candidates; "topk_path" = 1 forces the sampled-threshold form below (A/B, tests)
+    const bool group_path = ngroups > SAMPLE_GROUPS && ngroups <= LMAX && k <= GSEL_KMAX && drag_opt(DRAG_OPT_TOPK_PATH) != 1;
+    if (group_path) {
+      // workspace reuse: the sample area [64][8192] u64 holds the group maxima, the candidate area (8 bytes per row and query) the scores
+      sa.mode = SCAN_SCORES_GMAX; sa.gstride = 1; sa.niter = ngroups; sa.keys = sample; sa.kstride = LMAX;
+      sa.scores = (float*)cand; sa.npad = 2 * cstride;
+      if (int rc = launch_scan(sa, st)) return rc;
+      GroupSelArgs ga{};
+      ga.gmax = sample; ga.gstride = LMAX; ga.ngroups = (int)ngroups; ga.scores = sa.scores; ga.npad = sa.npad; ga.N = N; ga.k = k;
+      ga.out_d = out_d + (long long)q0 * k; ga.out_i = (long long*)out_i + (long long)q0 * k;
+      hipLaunchKernelGGL(select_groups_kernel, dim3(qn), dim3(GSEL_NT), 0, st, ga);
+      DRAG_LAUNCH_CHECK();
+      continue;
+    }
     if (ngroups <= SAMPLE_GROUPS) {
       // small corpus: every composite goes to the candidate list at its own slot (no sample, no atomics)
       sa.mode = SCAN_KEYS_DENSE; sa.gstride = 1; sa.niter = ngroups; sa.keys = cand; sa.kstride = cstride;

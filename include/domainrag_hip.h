@@ -30,10 +30,11 @@ const char* drag_last_error(void);
  *   kernel: by policy — joint sequences of 4096 keys and more that fill the chip | whenever S >= 1024 | never), "attn_persist" 0 | 1 | n >= 3 (persistent attention experiment: off, one workgroup per
  *   CU, n per XCD), "gemm_kernel", "gemm_group_m", "ln_generic", "topk_grid" (workgroups at most of the top-k scan, 0 = 512),
  *   "topk_depth" 0 | 3 (LDS-DMA ring depth of the scan), "topk_qt" 0 | 2 | 4 (query tiles per scan workgroup), "topk_select" 0 | 256 | 1024,
- *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima), "gemm_pair" 0 | 1 | 2
+ *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima), "topk_path" 0 | 1 (top-k call: two launches
+ *   through the row groups' maxima where that form applies — k <= 128, 8 192 < N <= 131 072 | always the sampled-threshold form), "gemm_pair" 0 | 1 | 2
  *   (drag_gemm_bf16_pair: merge unless both problems fill the chip alone | never | always).
  * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
- * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_GEMM_PAIR.  Returns 0, or -1 for an unknown name. */
+ * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_TOPK_PATH, $DRAG_GEMM_PAIR.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 
 /* activation codes used by epilogues */

@@ -264,6 +264,7 @@ def test_topk_fuzz_with_ties_nonfinite_rows_and_every_measurement_option(gpu):
                                     int(rng.integers(0, 2)), int(rng.choice([0, 256, 1024])))))
             if not ops.experiments_built():
                 opts["topk_qt"] = 0                 # several query tiles per workgroup: DRAG_EXPERIMENTS builds only
+            opts["topk_path"] = c % 2               # odd cases: the sampled-threshold form even where the two-launch form applies
             for n_, v in opts.items():
                 ops.set_option(n_, v)
             D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(q).to(gpu), k)
@@ -271,7 +272,7 @@ def test_topk_fuzz_with_ties_nonfinite_rows_and_every_measurement_option(gpu):
             assert np.array_equal(I.cpu().numpy(), Ir), (c, N, d, Q, k, opts)
             assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), (c, N, d, Q, k, opts)
     finally:
-        for n_ in names:
+        for n_ in names + ("topk_path",):
             ops.set_option(n_, 0)
 
 
@@ -304,10 +305,15 @@ def test_topk_adversarial_score_layouts(gpu):
         corpus = (w[:, None].astype(np.float32) * u[None, :] + 1.5 * v[None, :]).astype(np.float32)
         for Q in (1, 16, 64):
             q = (u[None, :] * (1 + np.arange(Q)[:, None] / 8) + 0.01 * rng.standard_normal((Q, d))).astype(np.float32)
-            D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(q).to(gpu), k)
             Dr, Ir = oret.cosine_topk(corpus, q, k)
-            assert np.array_equal(I.cpu().numpy(), Ir), (name, Q)
-            assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), (name, Q)
+            try:
+                for path in (0, 1):                  # two launches through the group maxima | sampled threshold + filtered scan
+                    ops.set_option("topk_path", path)
+                    D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(q).to(gpu), k)
+                    assert np.array_equal(I.cpu().numpy(), Ir), (name, Q, path)
+                    assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), (name, Q, path)
+            finally:
+                ops.set_option("topk_path", 0)
 
 
 def test_gemm_pair_random_configs(gpu):

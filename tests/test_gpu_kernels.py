@@ -498,10 +498,49 @@ def test_topk_bit_exact(gpu, N, Q, k):
     corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
     qs = rng.standard_normal((Q, 512)).astype(np.float32)
     qs /= np.linalg.norm(qs, axis=1, keepdims=True)
-    D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu), k)
     Dr, Ir = oret.cosine_topk(corpus, qs, k)
-    assert np.array_equal(I.cpu().numpy(), Ir)
-    assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+    try:
+        for path in (0, 1):          # 0: by policy (two launches through the group maxima where k <= 128 and 8192 < N <= 131072), 1: sampled threshold
+            ops.set_option("topk_path", path)
+            D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu), k)
+            assert np.array_equal(I.cpu().numpy(), Ir), path
+            assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), path
+    finally:
+        ops.set_option("topk_path", 0)
+
+
+@pytest.mark.parametrize("N,Q,k", [(8193, 1, 128), (8193, 3, 100), (8208, 1, 1), (131072, 1, 100), (131072, 17, 128), (131067, 64, 100),
+                                   (131073, 2, 100), (131072, 2, 129), (118287, 1, 100), (118287, 70, 16)])
+def test_topk_two_launch_path_at_its_limits(gpu, N, Q, k):
+    """the two-launch call (scores + group maxima in the scan, select_groups_kernel) applies for 513 .. 8192 groups of 16 rows and
+    k <= 128; just inside, on and just outside those limits, with the answer's rows packed into few groups (the k best groups then
+    hold far more than k candidates), spread one per group, duplicated (ties -> index order) and NaN / inf rows: the oracle's
+    (D, I) bit for bit, and the same arrays as the sampled-threshold form"""
+    from domain_rag_amd import ops
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(N * 7 + Q + k)
+    d = 64
+    u = rng.standard_normal(d).astype(np.float32); u /= np.linalg.norm(u)
+    corpus = rng.standard_normal((N, d)).astype(np.float32)
+    hot = 16 * int(rng.integers(0, N // 16 - 12))
+    corpus[hot:hot + 160] += 6.0 * u                                      # ten whole groups full of high scorers
+    corpus[rng.integers(0, N, 300)] += 7.0 * u                            # and 300 scattered ones
+    corpus[N - 1] += 9.0 * u                                              # the last row of a (possibly ragged) last group
+    dup = rng.integers(0, N, 64)
+    corpus[dup] = corpus[hot + 3]                                         # exact ties across groups
+    corpus[rng.integers(0, N)] = np.nan
+    corpus[rng.integers(0, N), 1] = np.inf
+    qs = (u[None] * (1 + 0.1 * np.arange(Q)[:, None]) + 0.05 * rng.standard_normal((Q, d))).astype(np.float32)
+    Dr, Ir = oret.cosine_topk(corpus, qs, k)
+    cd, qd = torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu)
+    try:
+        for path in (0, 1):
+            ops.set_option("topk_path", path)
+            D, I = ops.cosine_topk(cd, qd, k)
+            assert np.array_equal(I.cpu().numpy(), Ir), path
+            assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), path
+    finally:
+        ops.set_option("topk_path", 0)
 
 
 def test_topk_ties_and_padding(gpu):
@@ -539,9 +578,14 @@ def test_topk_when_the_sample_misrepresents_the_corpus(gpu):
     for i in range(512):
         sampled[i * stride * 16: i * stride * 16 + 16] = True
     corpus[sampled] = -10.0 * qs.sum(0)                        # the sampled rows: strongly anti-aligned with every query
-    D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu), k)
     Dr, Ir = oret.cosine_topk(corpus, qs, k)
-    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+    try:
+        for path in (1, 0):                                    # the sampled-threshold form this corpus is built against, then the policy's
+            ops.set_option("topk_path", path)
+            D, I = ops.cosine_topk(torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu), k)
+            assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32)), path
+    finally:
+        ops.set_option("topk_path", 0)
     same = np.tile(rng.standard_normal((1, 512)).astype(np.float32), (20000, 1))
     D, I = ops.cosine_topk(torch.from_numpy(same).to(gpu), torch.from_numpy(qs).to(gpu), k)
     assert (I.cpu().numpy() == np.arange(k)[None]).all() and (D.cpu().numpy() == D.cpu().numpy()[:, :1]).all()
@@ -583,7 +627,9 @@ def test_topk_threshold_and_selection_variants_give_the_same_answer(gpu):
         ref = {k: ops.cosine_topk(corpus, q, k) for k in (1, 100, 128, 129)}
         sc0 = ops.cosine_scores(corpus, q)
         variants = [{"topk_dense_sample": 1}, {"topk_select": 256}, {"topk_select": 1024}, {"topk_grid": 1024, "topk_depth": 3},
-                    {"topk_dense_sample": 1, "topk_select": 1024, "topk_grid": 2048}, {"topk_grid": 16}]      # (a grid below one unit of workgroups is clamped)
+                    {"topk_dense_sample": 1, "topk_select": 1024, "topk_grid": 2048}, {"topk_grid": 16},     # (a grid below one unit of workgroups is clamped)
+                    {"topk_path": 1}, {"topk_path": 1, "topk_dense_sample": 1}, {"topk_path": 1, "topk_select": 256, "topk_grid": 1024},
+                    {"topk_grid": 2048, "topk_depth": 3}]
         if ops.experiments_built():
             variants += [{"topk_qt": 2}, {"topk_qt": 4}, {"topk_qt": 4, "topk_grid": 1024}]
         for opts in variants:
@@ -596,7 +642,7 @@ def test_topk_threshold_and_selection_variants_give_the_same_answer(gpu):
             for name in opts:
                 ops.set_option(name, 0)
     finally:
-        for name in ("topk_dense_sample", "topk_select", "topk_grid", "topk_depth", "topk_qt"):
+        for name in ("topk_dense_sample", "topk_select", "topk_grid", "topk_depth", "topk_qt", "topk_path"):
             ops.set_option(name, 0)
 
 
