@@ -208,7 +208,10 @@ int drag_scale_sum_bf16(const void* x, const float* scales, void* out, int32_t G
  *   out_i int64 [Q, k].  Score = fp32 fma chain in the fixed order documented in oracle/topk.c;
  *   ties -> lower index first; k <= 2048; if k > N the tail is (-FLT_MAX, -1) like faiss.
  *   Up to 64 queries share ONE pass over the corpus (more: ceil(Q / 64) passes; 32 or 16 per pass when N is so large that 64
- *   candidate regions would pass 1 GiB); the call is four launches: a strided
+ *   candidate regions would pass 1 GiB).  For k <= 128 and 8 192 < N <= 131 072 the call is TWO launches: the corpus pass writes
+ *   the scores and the best (score, index) of every group of 16 rows; one workgroup per query takes the k-th best group maximum as
+ *   the bound (exactly k groups reach it and hold the whole answer), reads those groups' 16 k scores and ranks them.  Otherwise four
+ *   launches: a strided
  *   8192-row sample -> its k-th best per query (a valid lower bound of the answer's k-th best) -> the corpus pass keeping only
  *   scores above it (per-wave candidate regions, no atomics, no [Q, N] score matrix) -> select + sort + decode on the candidates.
  *   Deterministic; results do not depend on Q or on how queries are grouped into calls.
