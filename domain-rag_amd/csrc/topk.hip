@@ -799,13 +799,11 @@ extern "C" int drag_cosine_topk_f32(const float* corpus, const float* queries, i
     const bool group_path = ngroups > SAMPLE_GROUPS && ngroups <= LMAX && k <= GSEL_KMAX && drag_opt(DRAG_OPT_TOPK_PATH) != 1;
     if (group_path) {
       // workspace reuse: the sample area [64][8192] u64 holds the group maxima, the candidate area (8 bytes per row and query) the scores
-      const bool dense = drag_opt(DRAG_OPT_TOPK_SELECT) != 7;
-      const long long gms = dense ? (ngroups + 15) / 16 * 16 : LMAX;
-      sa.mode = SCAN_SCORES_GMAX; sa.gstride = 1; sa.niter = ngroups; sa.keys = sample; sa.kstride = gms;
-      sa.scores = (float*)cand; sa.npad = dense ? (N + 63) / 64 * 64 : 2 * cstride;
+      sa.mode = SCAN_SCORES_GMAX; sa.gstride = 1; sa.niter = ngroups; sa.keys = sample; sa.kstride = LMAX;
+      sa.scores = (float*)cand; sa.npad = 2 * cstride;
       if (int rc = launch_scan(sa, st)) return rc;
       GroupSelArgs ga{};
-      ga.gmax = sample; ga.gstride = gms; ga.ngroups = (int)ngroups; ga.scores = sa.scores; ga.npad = sa.npad; ga.N = N; ga.k = k;
+      ga.gmax = sample; ga.gstride = LMAX; ga.ngroups = (int)ngroups; ga.scores = sa.scores; ga.npad = sa.npad; ga.N = N; ga.k = k;
       ga.out_d = out_d + (long long)q0 * k; ga.out_i = (long long*)out_i + (long long)q0 * k;
       hipLaunchKernelGGL(select_groups_kernel, dim3(qn), dim3(GSEL_NT), 0, st, ga);
       DRAG_LAUNCH_CHECK();
