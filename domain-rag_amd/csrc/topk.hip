@@ -514,7 +514,7 @@ struct KthScratch {
   unsigned hist[256];
   unsigned need, done;
   u64 prefix;
-  u64 red_or[16], red_and[16];
+  u64 red_or[16], red_and[16], red_min[16];
 };
 
 // the k-th largest of more than k unique keys spread over the workgroup's threads: T with exactly k keys >= T (the radix select of
@@ -545,8 +545,22 @@ __device__ __forceinline__ u64 kth_largest(Each each, int k, KthScratch& s, u64 
     const u64 prefix = s.prefix;
     const unsigned need = s.need;
     const unsigned dm = (1u << width) - 1u;
+    // wave-aggregated: when all of a wave's keys under the prefix fall into ONE bin (a query with a near-duplicate in the corpus puts
+    // one key far above the rest: the digits between them hold every other key in a single bin — 7 000 atomics on one LDS address,
+    // 3-4 us per pass), one lane adds their count
     each([&](u64 x) {
-      if ((x & mask) == prefix) atomicAdd(&s.hist[(unsigned)(x >> sh) & dm], 1u);
+      const bool in = (x & mask) == prefix;
+      const unsigned bin = (unsigned)(x >> sh) & dm;
+      const u64 act = __ballot(in);
+      if (act != 0ull) {
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned b0 = (unsigned)__shfl((int)bin, leader, 64);
+        if (__ballot(in && bin == b0) == act) {
+          if (lane == leader) atomicAdd(&s.hist[b0], (unsigned)__popcll(act));
+        } else if (in) {
+          atomicAdd(&s.hist[bin], 1u);
+        }
+      }
     });
     __syncthreads();
     if (tid < 64) {                       // wave 0 scans the 256 bins from the top: lane i owns bins 255-4i .. 252-4i
@@ -603,6 +617,26 @@ __global__ __launch_bounds__(GSEL_NT) void select_groups_kernel(GroupSelArgs p) 
     r[j] = i < L ? src[i] : 0ull;         // 0 = no key (a real composite is never 0)
   }
   if (tid == 0) { n_grp = 0u; n_cand = 0u; n_sel = 0u; }
+  // Keys that cannot be among the k best leave the selection here: every thread that holds keys holds its own maximum, at least
+  // SAMPLE_GROUPS + 1 > k threads do, so the SMALLEST of the threads' maxima is a lower bound of the k-th best key.  What this buys
+  // is the radix select's first digit: it starts at the highest bit in which two keys differ, and ONE group of 16 all-negative scores
+  // (one query in five at N = 118 287) or a NaN row puts that at the sign bit — 7 000 keys in two or three bins, 3 passes and
+  // thousands of LDS atomics per address (+6.5 us on the call).  With the low outliers gone the digit starts inside the exponent.
+  {
+    u64 tmax = 0ull;
+#pragma unroll
+    for (int j = 0; j < GSEL_R; ++j) tmax = r[j] > tmax ? r[j] : tmax;
+    u64 m = tmax ? tmax : ~0ull;          // threads without keys do not vote
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const u64 v = shfl64(m, (tid & 63) ^ o); m = v < m ? v : m; }
+    if ((tid & 63) == 0) ks.red_min[tid >> 6] = m;
+    __syncthreads();
+    u64 lb = ~0ull;
+#pragma unroll
+    for (int i = 0; i < GSEL_NT / 64; ++i) { const u64 v = ks.red_min[i]; lb = v < lb ? v : lb; }
+#pragma unroll
+    for (int j = 0; j < GSEL_R; ++j) r[j] = r[j] < lb ? 0ull : r[j];
+  }
   u64 vor = 0ull, vand = ~0ull;
 #pragma unroll
   for (int j = 0; j < GSEL_R; ++j)

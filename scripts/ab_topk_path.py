@@ -17,6 +17,8 @@ for N in [int(x) for x in os.environ.get("NS", "118287,50000,131072,20000").spli
     g = torch.Generator(device=dev).manual_seed(0)
     corpus = torch.randn(N, 512, device=dev, generator=g); corpus /= corpus.norm(dim=-1, keepdim=True)
     qs = torch.randn(64, 512, device=dev, generator=g); qs /= qs.norm(dim=-1, keepdim=True)
+    if os.environ.get("PLANTED"):        # queries with a near-duplicate in the corpus (bench.py's side field): one key far above the rest
+        qs = (corpus[torch.randint(0, N, (64,), generator=g, device=dev)] + 0.02 * torch.randn(64, 512, generator=g, device=dev)).contiguous()
     for Q in (1, 4, 16, 32, 64):
         q = qs[:Q].contiguous()
         t = {0: [], 1: []}
