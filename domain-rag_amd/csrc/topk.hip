@@ -620,7 +620,7 @@ __global__ __launch_bounds__(GSEL_NT) void select_groups_kernel(GroupSelArgs p) 
   // Keys that cannot be among the k best leave the selection here: every thread that holds keys holds its own maximum, at least
   // SAMPLE_GROUPS + 1 > k threads do, so the SMALLEST of the threads' maxima is a lower bound of the k-th best key.  What this buys
   // is the radix select's first digit: it starts at the highest bit in which two keys differ, and ONE group of 16 all-negative scores
-  // (one query in five at N = 118 287) or a NaN row puts that at the sign bit — 7 000 keys in two or three bins, 3 passes and
+  // (2^-16 per group: one query in nine at N = 118 287) or a NaN row puts that at the sign bit — 7 000 keys in two or three bins, 3 passes and
   // thousands of LDS atomics per address (+6.5 us on the call).  With the low outliers gone the digit starts inside the exponent.
   {
     u64 tmax = 0ull;
