@@ -530,6 +530,12 @@ def test_topk_two_launch_path_at_its_limits(gpu, N, Q, k):
     corpus[dup] = corpus[hot + 3]                                         # exact ties across groups
     corpus[rng.integers(0, N)] = np.nan
     corpus[rng.integers(0, N), 1] = np.inf
+    # whole groups below everything else: all 16 scores negative (the group maximum then lacks the sign bit every other key has — the
+    # radix select's first digit used to start there), all NaN, all -inf: the lower bound of the selection drops them, the answer stays
+    lows = 16 * rng.choice(N // 16 - 1, 3, replace=False)
+    corpus[lows[0]:lows[0] + 16] = (-3.0 * u[None] + 0.01 * rng.standard_normal((16, d))).astype(np.float32)
+    corpus[lows[1]:lows[1] + 16] = np.nan
+    corpus[lows[2]:lows[2] + 16] = -np.inf
     qs = (u[None] * (1 + 0.1 * np.arange(Q)[:, None]) + 0.05 * rng.standard_normal((Q, d))).astype(np.float32)
     Dr, Ir = oret.cosine_topk(corpus, qs, k)
     cd, qd = torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu)
