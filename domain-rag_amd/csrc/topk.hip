@@ -600,8 +600,12 @@ constexpr int GSEL_NT = 1024;
 constexpr int GSEL_KMAX = 128;
 constexpr int GSEL_R = LMAX / GSEL_NT;    // group maxima per thread, in registers
 constexpr int GSEL_RANK_MAX = 512;        // candidates up to which ranks are counted directly (no second radix select)
+// M: row groups per key ("super-group", a power of two <= 8): a thread folds M consecutive group maxima into each of its registers, so
+// 8192 keys cover 8192 M groups = 131 072 M rows; exactly k super-groups reach the bound and their 16 M k rows are the candidates
+// (LDS for all of them: 128 KiB at M = 8, N <= 1 048 576).
+template <int M>
 __global__ __launch_bounds__(GSEL_NT) void select_groups_kernel(GroupSelArgs p) {
-  __shared__ u64 cand[16 * GSEL_KMAX];    // the rows of the k best groups that reach T
+  __shared__ u64 cand[16 * M * GSEL_KMAX];   // the rows of the k best super-groups that reach T
   __shared__ u64 srt[GSEL_KMAX];
   __shared__ unsigned grp[GSEL_KMAX];
   __shared__ KthScratch ks;
@@ -613,8 +617,14 @@ __global__ __launch_bounds__(GSEL_NT) void select_groups_kernel(GroupSelArgs p) 
   u64 r[GSEL_R];
 #pragma unroll
   for (int j = 0; j < GSEL_R; ++j) {
-    const int i = tid + j * GSEL_NT;
-    r[j] = i < L ? src[i] : 0ull;         // 0 = no key (a real composite is never 0)
+    u64 best = 0ull;                      // 0 = no key (a real composite is never 0)
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const int gi = (tid + j * GSEL_NT) * M + i;
+      const u64 x = gi < L ? src[gi] : 0ull;
+      best = x > best ? x : best;
+    }
+    r[j] = best;
   }
   if (tid == 0) { n_grp = 0u; n_cand = 0u; n_sel = 0u; }
   // Keys that cannot be among the k best leave the selection here: every thread that holds keys holds its own maximum, at least
@@ -648,23 +658,27 @@ __global__ __launch_bounds__(GSEL_NT) void select_groups_kernel(GroupSelArgs p) 
   }, k, ks, vor, vand);                   // more than SAMPLE_GROUPS >= k keys
 #pragma unroll
   for (int j = 0; j < GSEL_R; ++j)
-    if (r[j] >= T && r[j]) grp[atomicAdd(&n_grp, 1u)] = (~(unsigned)(r[j] & 0xffffffffull)) >> 4;   // the group of the key's row: exactly k of them
+    if (r[j] >= T && r[j]) grp[atomicAdd(&n_grp, 1u)] = ((~(unsigned)(r[j] & 0xffffffffull)) >> 4) / M;   // the super-group of the key's row: exactly k of them
   __syncthreads();
   const float* sc = p.scores + (long long)q * p.npad;
-  float v[2];
-  long long row[2];
+  constexpr int RPS = 16 * M;             // rows per super-group
+  constexpr int GB = M == 1 ? 2 : 4;      // loads of a thread in flight (16 k <= 2048 scores at M = 1: both)
+  for (int i0 = 0; i0 < RPS * k; i0 += GB * GSEL_NT) {
+    float v[GB];
+    long long row[GB];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {           // 16 k <= 2048 scores: both loads of the thread in flight
-    const int i = tid + j * GSEL_NT;
-    row[j] = i < 16 * k ? (long long)grp[i >> 4] * 16 + (i & 15) : p.N;
-    v[j] = row[j] < p.N ? sc[row[j]] : 0.f;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-    if (row[j] < p.N) {
-      const u64 x = composite(v[j], (unsigned)row[j]);
-      if (x >= T) cand[atomicAdd(&n_cand, 1u)] = x;
+    for (int j = 0; j < GB; ++j) {
+      const int i = i0 + tid + j * GSEL_NT;
+      row[j] = i < RPS * k ? (long long)grp[i / RPS] * RPS + (i % RPS) : p.N;
+      v[j] = row[j] < p.N ? sc[row[j]] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < GB; ++j)
+      if (row[j] < p.N) {
+        const u64 x = composite(v[j], (unsigned)row[j]);
+        if (x >= T) cand[atomicAdd(&n_cand, 1u)] = x;
+      }
+  }
   __syncthreads();
   const int C = (int)n_cand;              // >= k: the k group maxima are among them
   if (C <= GSEL_RANK_MAX) {
@@ -830,16 +844,28 @@ extern "C" int drag_cosine_topk_f32(const float* corpus, const float* queries, i
     se.k = k; se.kpad = kpad;
     // two launches through the group maxima (select_groups_kernel): every group maximum fits one workgroup's LDS and k groups
     // of 16 rows bound the candidates; "topk_path" = 1 forces the sampled-threshold form below (A/B, tests)
-    const bool group_path = ngroups > SAMPLE_GROUPS && ngroups <= LMAX && k <= GSEL_KMAX && drag_opt(DRAG_OPT_TOPK_PATH) != 1;
+    // Beyond 131 072 rows (more than one row group per key) the [Q, N] scores the scan has to write start to cost what the saved launches
+    // gave: measured (profiles/r04_topk_two_launch_ab.log) N = 300 000: Q = 1 -9 %, Q = 4 -5 %, Q = 16 -1 %, Q = 32 +1 %; N = 1 000 000:
+    // Q = 1 -0.5 %, Q = 4 +2 %, Q = 16 +6 % — so by policy only up to 524 288 rows and 4 queries per pass; "topk_path" = 2 takes
+    // it wherever it applies (tests, measurements)
+    const int path_opt = drag_opt(DRAG_OPT_TOPK_PATH);
+    const bool group_ok = ngroups > SAMPLE_GROUPS && ngroups <= 8 * LMAX && k <= GSEL_KMAX;
+    const bool group_path = group_ok && path_opt != 1 && (path_opt == 2 || ngroups <= LMAX || (ngroups <= 4 * LMAX && qn <= 4));
     if (group_path) {
-      // workspace reuse: the sample area [64][8192] u64 holds the group maxima, the candidate area (8 bytes per row and query) the scores
-      sa.mode = SCAN_SCORES_GMAX; sa.gstride = 1; sa.niter = ngroups; sa.keys = sample; sa.kstride = LMAX;
+      // workspace reuse: a query's candidate region (8 bytes per row + 1 MiB) holds its scores (4 bytes per row) and, behind them, its
+      // group maxima (half a byte per row)
+      u64* gm = (u64*)((char*)cand + 4 * ceil16(N));
+      sa.mode = SCAN_SCORES_GMAX; sa.gstride = 1; sa.niter = ngroups; sa.keys = gm; sa.kstride = cstride;
       sa.scores = (float*)cand; sa.npad = 2 * cstride;
       if (int rc = launch_scan(sa, st)) return rc;
       GroupSelArgs ga{};
-      ga.gmax = sample; ga.gstride = LMAX; ga.ngroups = (int)ngroups; ga.scores = sa.scores; ga.npad = sa.npad; ga.N = N; ga.k = k;
+      ga.gmax = gm; ga.gstride = cstride; ga.ngroups = (int)ngroups; ga.scores = sa.scores; ga.npad = sa.npad; ga.N = N; ga.k = k;
       ga.out_d = out_d + (long long)q0 * k; ga.out_i = (long long*)out_i + (long long)q0 * k;
-      hipLaunchKernelGGL(select_groups_kernel, dim3(qn), dim3(GSEL_NT), 0, st, ga);
+      const long long per_key = (ngroups + LMAX - 1) / LMAX;             // row groups per key: 1 up to 131 072 rows, 8 up to 1 048 576
+      if (per_key <= 1) hipLaunchKernelGGL(select_groups_kernel<1>, dim3(qn), dim3(GSEL_NT), 0, st, ga);
+      else if (per_key <= 2) hipLaunchKernelGGL(select_groups_kernel<2>, dim3(qn), dim3(GSEL_NT), 0, st, ga);
+      else if (per_key <= 4) hipLaunchKernelGGL(select_groups_kernel<4>, dim3(qn), dim3(GSEL_NT), 0, st, ga);
+      else hipLaunchKernelGGL(select_groups_kernel<8>, dim3(qn), dim3(GSEL_NT), 0, st, ga);
       DRAG_LAUNCH_CHECK();
       continue;
     }

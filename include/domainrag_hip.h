@@ -30,8 +30,9 @@ const char* drag_last_error(void);
  *   kernel: by policy — joint sequences of 4096 keys and more that fill the chip | whenever S >= 1024 | never), "attn_persist" 0 | 1 | n >= 3 (persistent attention experiment: off, one workgroup per
  *   CU, n per XCD), "gemm_kernel", "gemm_group_m", "ln_generic", "topk_grid" (workgroups at most of the top-k scan, 0 = 512),
  *   "topk_depth" 0 | 3 (LDS-DMA ring depth of the scan), "topk_qt" 0 | 2 | 4 (query tiles per scan workgroup), "topk_select" 0 | 256 | 1024,
- *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima), "topk_path" 0 | 1 (top-k call: two launches
- *   through the row groups' maxima where that form applies — k <= 128, 8 192 < N <= 131 072 | always the sampled-threshold form), "gemm_pair" 0 | 1 | 2
+ *   "topk_dense_sample" 0 | 1 (threshold from every sampled row instead of the group maxima), "topk_path" 0 | 1 | 2 (top-k call: two launches
+ *   through the row groups' maxima by policy — k <= 128 and 8 192 < N <= 131 072, or N <= 524 288 with at most 4 queries | always the
+ *   sampled-threshold form | the two-launch form wherever it applies: k <= 128, 8 192 < N <= 1 048 576), "gemm_pair" 0 | 1 | 2
  *   (drag_gemm_bf16_pair: merge unless both problems fill the chip alone | never | always).
  * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
  * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_TOPK_PATH, $DRAG_GEMM_PAIR.  Returns 0, or -1 for an unknown name. */
@@ -208,7 +209,7 @@ int drag_scale_sum_bf16(const void* x, const float* scales, void* out, int32_t G
  *   out_i int64 [Q, k].  Score = fp32 fma chain in the fixed order documented in oracle/topk.c;
  *   ties -> lower index first; k <= 2048; if k > N the tail is (-FLT_MAX, -1) like faiss.
  *   Up to 64 queries share ONE pass over the corpus (more: ceil(Q / 64) passes; 32 or 16 per pass when N is so large that 64
- *   candidate regions would pass 1 GiB).  For k <= 128 and 8 192 < N <= 131 072 the call is TWO launches: the corpus pass writes
+ *   candidate regions would pass 1 GiB).  For k <= 128 and 8 192 < N <= 131 072 (up to 524 288 rows for at most 4 queries) the call is TWO launches: the corpus pass writes
  *   the scores and the best (score, index) of every group of 16 rows; one workgroup per query takes the k-th best group maximum as
  *   the bound (exactly k groups reach it and hold the whole answer), reads those groups' 16 k scores and ranks them.  Otherwise four
  *   launches: a strided

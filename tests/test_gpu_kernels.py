@@ -510,10 +510,12 @@ def test_topk_bit_exact(gpu, N, Q, k):
 
 
 @pytest.mark.parametrize("N,Q,k", [(8193, 1, 128), (8193, 3, 100), (8208, 1, 1), (131072, 1, 100), (131072, 17, 128), (131067, 64, 100),
-                                   (131073, 2, 100), (131072, 2, 129), (118287, 1, 100), (118287, 70, 16)])
+                                   (131073, 2, 100), (131072, 2, 129), (118287, 1, 100), (118287, 70, 16),
+                                   (262144, 3, 100), (262147, 1, 128), (600000, 2, 100), (1048576, 1, 100), (1048570, 17, 7), (1048577, 1, 100)])
 def test_topk_two_launch_path_at_its_limits(gpu, N, Q, k):
-    """the two-launch call (scores + group maxima in the scan, select_groups_kernel) applies for 513 .. 8192 groups of 16 rows and
-    k <= 128; just inside, on and just outside those limits, with the answer's rows packed into few groups (the k best groups then
+    """the two-launch call (scores + group maxima in the scan, select_groups_kernel<M>) applies for 513 .. 65 536 groups of 16 rows
+    (1, 2, 4 or 8 groups per key: the steps at 131 072, 262 144 and 524 288 rows, the end at 1 048 576) and k <= 128; just inside, on and
+    just outside those limits, with the answer's rows packed into few groups (the k best groups then
     hold far more than k candidates), spread one per group, duplicated (ties -> index order) and NaN / inf rows: the oracle's
     (D, I) bit for bit, and the same arrays as the sampled-threshold form"""
     from domain_rag_amd import ops
@@ -540,7 +542,7 @@ def test_topk_two_launch_path_at_its_limits(gpu, N, Q, k):
     Dr, Ir = oret.cosine_topk(corpus, qs, k)
     cd, qd = torch.from_numpy(corpus).to(gpu), torch.from_numpy(qs).to(gpu)
     try:
-        for path in (0, 1):
+        for path in (0, 1, 2):          # policy | sampled threshold | group maxima wherever the form applies (1, 2, 4, 8 groups per key)
             ops.set_option("topk_path", path)
             D, I = ops.cosine_topk(cd, qd, k)
             assert np.array_equal(I.cpu().numpy(), Ir), path
