@@ -52,6 +52,7 @@ SIGNATURES = {
     "drag_version": (c_int, []),
     "drag_last_error": (ctypes.c_char_p, []),
     "drag_set_option": (c_int, [ctypes.c_char_p, c_int]),
+    "drag_experiments_built": (c_int, []),
     "drag_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     "drag_gemm_bf16_pair": (c_int, [ctypes.POINTER(GemmArgs), ctypes.POINTER(GemmArgs), c_void_p]),
     "drag_gemm_bf16_pair_merges": (c_int, [c_int, c_int, c_int, c_int]),

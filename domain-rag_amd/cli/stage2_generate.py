@@ -221,16 +221,24 @@ def run_timestamp(world: int) -> str:
         return env
     if world > 1:
         import torch.distributed as dist
+        created = False
         if not dist.is_initialized():
             try:
                 if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
                     raise RuntimeError("MASTER_ADDR / MASTER_PORT are not set")
-                dist.init_process_group("gloo")
+                # a rank that never arrives must not hold the others for gloo's 30-minute default ($DRAG_RENDEZVOUS_TIMEOUT_S to change)
+                from datetime import timedelta
+                dist.init_process_group("gloo", timeout=timedelta(seconds=int(os.environ.get("DRAG_RENDEZVOUS_TIMEOUT_S", "300"))))
+                created = True
             except Exception as e:
                 print(f"警告：无法建立进程组来广播时间戳 ({e})；退回到父进程启动时间（仅限同一节点、同一父进程）")
         if dist.is_initialized():
             box = [datetime.now().strftime("%Y%m%d_%H%M%S")]
-            dist.broadcast_object_list(box, src=0)
+            try:
+                dist.broadcast_object_list(box, src=0)
+            finally:
+                if created:           # the group existed for this one string: the data path needs no collective
+                    dist.destroy_process_group()
             return box[0]
         try:
             with open(f"/proc/{os.getppid()}/stat") as f:

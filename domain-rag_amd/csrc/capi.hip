@@ -12,6 +12,7 @@ void drag_set_error(const char* msg) {
 
 extern "C" const char* drag_last_error(void) { return g_err; }
 extern "C" int drag_version(void) { return 100; }  // 0.1.0
+extern "C" int drag_experiments_built(void) { return DRAG_EXP; }
 
 // ---- tuning switches (measurement only: every setting computes the same values unless its comment says otherwise).  Initial
 // values come from the environment ONCE; drag_set_option changes them at run time so one process can A/B kernels.

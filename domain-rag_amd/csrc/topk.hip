@@ -548,6 +548,8 @@ __device__ __forceinline__ u64 kth_largest(Each each, int k, KthScratch& s, u64 
     // wave-aggregated: when all of a wave's keys under the prefix fall into ONE bin (a query with a near-duplicate in the corpus puts
     // one key far above the rest: the digits between them hold every other key in a single bin — 7 000 atomics on one LDS address,
     // 3-4 us per pass), one lane adds their count
+    // each() may call this from divergent code (`if (r[j]) f(r[j])`, a ragged `for i < C`): __ballot then covers the ACTIVE lanes only,
+    // `leader` is the first lane of that ballot and therefore active — the one constraint __shfl has on its source lane
     each([&](u64 x) {
       const bool in = (x & mask) == prefix;
       const unsigned bin = (unsigned)(x >> sh) & dm;
@@ -605,6 +607,11 @@ constexpr int GSEL_RANK_MAX = 512;        // candidates up to which ranks are co
 // (LDS for all of them: 128 KiB at M = 8, N <= 1 048 576).
 template <int M>
 __global__ __launch_bounds__(GSEL_NT) void select_groups_kernel(GroupSelArgs p) {
+  // gfx950 only (160 KiB of LDS per workgroup): M = 8 takes 128 KiB for the candidates alone — checked here because the four instantiations
+  // are compiled unconditionally
+  static_assert(M == 1 || M == 2 || M == 4 || M == 8, "row groups per key: a power of two <= 8");
+  static_assert(sizeof(u64) * (16 * M * GSEL_KMAX + GSEL_KMAX) + sizeof(unsigned) * (GSEL_KMAX + 3) + sizeof(KthScratch) <= 160 * 1024,
+                "select_groups_kernel: LDS budget of gfx950 exceeded");
   __shared__ u64 cand[16 * M * GSEL_KMAX];   // the rows of the k best super-groups that reach T
   __shared__ u64 srt[GSEL_KMAX];
   __shared__ unsigned grp[GSEL_KMAX];

@@ -16,15 +16,29 @@
 namespace {
 
 // ------------------------------------------------------------------ GroupNorm
-// pass 1: per (image, pixel chunk) partial sums for every unit of 4 channels.  Sums are taken of x − c and (x − c)² with c = the group's
-// first element (pixel 0, first channel): E[x²] − E[x]² in float32 partials loses the variance of a group whose mean is large against its
-// spread (mean 100, spread 0.3: 1e4 · 1e-6 of rounding against a variance of 0.1), torch's GroupNorm (Welford) does not; any c near the
-// mean removes the cancellation and costs two subtractions per element of an HBM-bound pass.
+// pass 1: per (image, pixel chunk) partial sums for every unit of 4 channels.  Sums are taken of x − c and (x − c)² with a shift c per
+// group: E[x²] − E[x]² in float32 partials loses the variance of a group whose mean is large against its spread (mean 100, spread 0.3:
+// 1e4 · 1e-6 of rounding against a variance of 0.1), torch's GroupNorm (Welford) does not; any c near the mean removes the cancellation
+// and costs two subtractions per element of an HBM-bound pass.  c = the mean of the group's channels at four pixels spread over the image
+// (gn_shift: round 4 took the single element (pixel 0, first channel) — one outlier there brought the cancellation back, one Inf there
+// turned every statistic of the group into NaN where plain sums would have stayed finite for the other groups).  A
+// non-finite shift counts as 0.  Both passes call the same function on the same data: the same float.
 struct GnPartArgs {
   const bf16_t* x;   // [B, HW, C]
   float* part;       // [B, nchunks, C/4, 2]
-  int HW, C, chunk;  // pixels per block
+  int HW, C, G, chunk;  // pixels per block
 };
+
+__device__ __forceinline__ float gn_shift(const bf16_t* xb, int HW, int C, int cpg, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long px = (long long)k * (HW - 1) / 3;
+    for (int c = 0; c < cpg; ++c) s += bf2f(xb[px * C + g * cpg + c]);
+  }
+  s *= 1.0f / (4.0f * (float)cpg);
+  return (s - s == 0.f) ? s : 0.f;          // Inf / NaN -> 0
+}
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnPartArgs p) {
   __shared__ float red[256 * 4];
@@ -34,8 +48,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnPartArgs p) {
   const int b = blockIdx.y, ch = blockIdx.x;
   const int p0 = ch * p.chunk, p1 = min(p0 + p.chunk, p.HW);
   const bf16_t* xb = p.x + (long long)b * p.HW * p.C;
-  const int cpg = p.C / 32;                  // channels per group (4, 8 or 16): a unit of 4 channels lies inside one group
-  const float sh0 = bf2f(xb[((slot * 8) / cpg) * cpg]), sh1 = bf2f(xb[((slot * 8 + 4) / cpg) * cpg]);
+  const int cpg = p.C / p.G;                 // channels per group (4, 8 or 16): a unit of 4 channels lies inside one group
+  const float sh0 = gn_shift(xb, p.HW, p.C, cpg, (slot * 8) / cpg), sh1 = gn_shift(xb, p.HW, p.C, cpg, (slot * 8 + 4) / cpg);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   for (int px = p0 + prow; px < p1; px += pstep) {
     const u32x4_t raw = *(const u32x4_t*)(xb + (long long)px * p.C + slot * 8);
@@ -76,7 +90,7 @@ __global__ void gn_finalize_kernel(const bf16_t* x, const float* part, float* st
   const double dm = s / n;                   // mean of x − c
   double var = q / n - dm * dm;
   if (var < 0) var = 0;
-  const double mean = (double)bf2f(x[(long long)b * HW * C + g * (C / G)]) + dm;
+  const double mean = (double)gn_shift(x + (long long)b * HW * C, HW, C, C / G, g) + dm;
   stats[(b * G + g) * 2] = (float)mean;
   stats[(b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
@@ -330,7 +344,7 @@ extern "C" int drag_groupnorm_silu_bf16(const void* x, void* y, const void* gamm
   const int nchunks = (HW + 1023) / 1024;
   float* part = (float*)workspace;
   float* stats = part + (long long)B * nchunks * (C / 4) * 2;
-  GnPartArgs pa{(const bf16_t*)x, part, HW, C, 1024};
+  GnPartArgs pa{(const bf16_t*)x, part, HW, C, groups, 1024};
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, B), dim3(256), 0, st, pa);
   DRAG_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, (const bf16_t*)x, (const float*)part, stats, nchunks, C, groups, HW, eps);

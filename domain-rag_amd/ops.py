@@ -89,11 +89,7 @@ def set_option(name: str, value: int) -> None:
 def experiments_built() -> bool:
     """True when libdomainrag_hip.so was built with DRAG_EXPERIMENTS=1 (csrc/drag_common.h): only then does it carry the kernels behind
     "attn_persist", "attn_sched" = 3 and "topk_qt" — measured non-improvements kept for their A/B records, not product code"""
-    lib = _lib.load()
-    if lib.drag_set_option(b"attn_persist", 1) != 0:
-        return False
-    lib.drag_set_option(b"attn_persist", 0)
-    return True
+    return bool(_lib.load().drag_experiments_built())        # a pure query: no option is read or written (ADVICE round 4)
 
 
 def _stream() -> int:
@@ -130,7 +126,18 @@ def _gemm_args(a, w, out, bias, act, act_n0, gate, resid, out_f32, M, a_rows_per
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
     if ldc is None:
-        ldc = N
+        # a 2-D destination carries its own row stride (a two-destination launch writes n_split columns into `out`, not N: defaulting to N
+        # there wrote past the tensor — round 5, found as a GPU memory fault by a test that forgot ldc)
+        ldc = out.stride(-2) if out.dim() >= 2 and out.stride(-1) == 1 else N
+    if c_rows_per_batch == 0 and (out2 is None or (0 < n_split < N and n_split % 256 == 0)):     # (an invalid n_split is the library's to report)
+        # last element written into each destination must lie inside its storage: a wrong ldc is an error here, not a memory fault there
+        def _room(t):
+            return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+        cols = n_split if out2 is not None else N
+        if (M - 1) * ldc + cols > _room(out):
+            raise ValueError(f"gemm.out: {M} rows of stride {ldc} x {cols} columns do not fit the destination ({_room(out)} elements from its start)")
+        if out2 is not None and (M - 1) * ldc2 + (N - n_split) > _room(out2):
+            raise ValueError(f"gemm.out2: {M} rows of stride {ldc2} x {N - n_split} columns do not fit the destination ({_room(out2)} elements from its start)")
     args = GemmArgs()
     args.A, args.W, args.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     args.bias = bias.data_ptr() if bias is not None else None

@@ -37,6 +37,9 @@ const char* drag_last_error(void);
  * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
  * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_TOPK_PATH, $DRAG_GEMM_PAIR.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
+/* 1 when the library was built with DRAG_EXPERIMENTS=1 and carries the kernels behind "attn_persist", "attn_sched" = 3 and "topk_qt"
+ * (measured non-improvements kept for their A/B records), else 0.  A pure query: no option is touched. */
+int drag_experiments_built(void);
 
 /* activation codes used by epilogues */
 #define DRAG_ACT_NONE 0

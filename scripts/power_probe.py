@@ -1,0 +1,66 @@
+"""Socket power and clocks while ONE kernel family runs back to back (rocm-smi sampled from a side thread): is the GEMM / attention
+ended by the chip's power cap?     python scripts/power_probe.py [gemm|gemm_zero|attention|idle] [seconds]
+gemm: (32768, 3072, 12288) + (42696, 21504, 3072) on N(0, 1) operands; gemm_zero: the same launches on zero-filled operands (no toggling in
+the multipliers: the guide's +19 % case); attention: B = 8, S = 5337, 24 heads."""
+import math, os, re, subprocess, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from domain_rag_amd import ops
+what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
+dev = torch.device("cuda:0")
+samples, stop = [], False
+
+def sampler():
+    while not stop:
+        r = subprocess.run(["/opt/rocm/bin/rocm-smi", "-d", "0", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True)
+        t = r.stdout
+        pw = re.search(r"(?:Average|Current Socket) Graphics Package Power \(W\):\s*([\d.]+)", t)
+        cap = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", t)
+        sclk = re.search(r"sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)", t)
+        samples.append((time.time(), float(pw.group(1)) if pw else None, float(cap.group(1)) if cap else None, int(sclk.group(1)) if sclk else None))
+        if len(samples) == 1:
+            print(t[:1500], flush=True)
+        time.sleep(0.25)
+
+if what.startswith("gemm"):
+    ops_list = []
+    for (M, N, K) in [(32768, 3072, 12288), (42696, 21504, 3072)]:
+        g = torch.Generator(device=dev).manual_seed(K)
+        if what == "gemm_zero":
+            A = torch.zeros(M, K, device=dev, dtype=torch.bfloat16); W = torch.zeros(N, K, device=dev, dtype=torch.bfloat16)
+        else:
+            A = torch.randn(M, K, device=dev, generator=g).bfloat16(); W = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16()
+        C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops_list.append((A, W, C, 2.0 * M * N * K))
+    def work():
+        fl = 0.0
+        for A, W, C, f in ops_list:
+            ops.gemm(A, W, out=C); fl += f
+        return fl
+elif what == "attention":
+    B, S, H = 8, 5337, 24
+    D = H * 128
+    qkv = torch.randn(B, S, 3 * D, device=dev).bfloat16()
+    s_pad = (S + 63) // 64 * 64
+    vt = torch.empty(B, H, 128, s_pad, dtype=torch.bfloat16, device=dev)
+    ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
+    out = torch.empty(B, S, D, dtype=torch.bfloat16, device=dev)
+    def work():
+        ops.attention(qkv, qkv.view(-1)[D:], vt, out, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+        return 4.0 * S * S * 128 * H * B
+else:
+    def work():
+        time.sleep(0.05); return 0.0
+for _ in range(3): work()
+torch.cuda.synchronize()
+th = threading.Thread(target=sampler); th.start()
+t0 = time.time(); fl = 0.0; n = 0
+while time.time() - t0 < secs:
+    for _ in range(10): fl += work()
+    torch.cuda.synchronize(); n += 10
+el = time.time() - t0
+stop = True; th.join()
+pw = [s[1] for s in samples[2:] if s[1] is not None]; ck = [s[3] for s in samples[2:] if s[3] is not None]; cap = [s[2] for s in samples if s[2] is not None]
+print(f"{what}: {fl / el / 1e12:.0f} TFLOP/s over {el:.1f} s; socket power samples {len(pw)}: mean {sum(pw) / max(len(pw), 1):.0f} W, max {max(pw) if pw else 0:.0f} W; "
+      f"cap {cap[0] if cap else None} W; sclk mean {sum(ck) / max(len(ck), 1):.0f} MHz min {min(ck) if ck else 0} max {max(ck) if ck else 0}", flush=True)
