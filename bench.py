@@ -387,6 +387,54 @@ def _pmc_mfma_util():
     return None
 
 
+class PowerSampler:
+    """socket power and shader clock of one GPU, sampled with rocm-smi from a side thread while the timed region runs.  The dominant
+    kernels of this workload are ended by the socket's power cap (scripts/power_probe.py, profiles/r05_power_probe_socket_power_cap.log:
+    the GEMM draws 1379 W of 1400 W at 1.81 GHz on N(0, 1) operands and runs 1633 TFLOP/s at 2.39 GHz and 1023 W on zeros), so a
+    throughput figure only compares across boxes next to the clock and the power it was measured at."""
+
+    def __init__(self, device_index: int, period_s: float = 0.5, enabled: bool = True):
+        self.smi = "/opt/rocm/bin/rocm-smi" if enabled and os.path.exists("/opt/rocm/bin/rocm-smi") else None
+        self.idx, self.period, self.samples, self._stop, self._th = device_index, period_s, [], False, None
+
+    def _loop(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                t = subprocess.run([self.smi, "-d", str(self.idx), "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True,
+                                   timeout=10).stdout
+                pw = re.search(r"Graphics Package Power \(W\):\s*([\d.]+)", t.split("Power Consumption")[-1])
+                cap = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", t)
+                ck = re.search(r"sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)", t)
+                self.samples.append((float(pw.group(1)) if pw else None, float(cap.group(1)) if cap else None, int(ck.group(1)) if ck else None))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.smi:
+            import threading
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=15)
+
+    def summary(self):
+        pw = [x[0] for x in self.samples if x[0] is not None]
+        ck = [x[2] for x in self.samples if x[2] is not None]
+        cap = [x[1] for x in self.samples if x[1] is not None]
+        if not pw:
+            return None
+        return {"socket_w_mean": sum(pw) / len(pw), "socket_w_max": max(pw), "cap_w": cap[0] if cap else None,
+                "sclk_mhz_mean": sum(ck) / len(ck) if ck else None, "sclk_mhz_min": min(ck) if ck else None, "samples": len(pw),
+                "source": "rocm-smi --showpower --showclocks every 0.5 s over the timed region (whole pipeline, rank 0's GPU)"}
+
+
 # ----------------------------------------------------------------------------------------------- workloads
 def run_generate(args, d: Dist):
     from domain_rag_amd import ops
@@ -400,11 +448,13 @@ def run_generate(args, d: Dist):
     # the prior, the VAE encodes and the decode, and of every 5th denoise step (all 30 launch the same shapes) of the
     # first timed batch; everything else runs exactly as the product path does (hipGraph replay of the DiT forward)
     rec = ops.GemmRecorder(every=args.roofline_every)
+    power = PowerSampler(d.local if not d.shared else 0, enabled=d.rank == 0)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        job.run_batch(recorder=rec if i == 0 else None)
-    torch.cuda.synchronize()
-    own = time.perf_counter() - t0                  # this rank's own clock, before the closing barrier
+    with power:
+        for i in range(args.steps):
+            job.run_batch(recorder=rec if i == 0 else None)
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0                  # this rank's own clock, before the closing barrier
     d.barrier()
     dt = d.max_over_ranks(time.perf_counter() - t0)
     per_rank = d.all_ranks(own)
@@ -441,7 +491,7 @@ def run_generate(args, d: Dist):
                                                                   "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0}
                                                               for k, v in bk.items()}},
                      "e2e_mfma_frac": job.flops_per_image() * images / d.world / dt / (MFMA_BF16_PEAK_TF * 1e12),
-                     "mfma_util_pmc": _pmc_mfma_util()},
+                     "mfma_util_pmc": _pmc_mfma_util(), "power": power.summary()},
     }
     if not args.no_side_configs and d.world == 1:
         del job

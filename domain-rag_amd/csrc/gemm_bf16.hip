@@ -1117,7 +1117,11 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   // the K = 3072 shapes (8 ahead by 1-3 % at N = 3072), 4 is 2-3 % ahead at K >= 12288; 16 / 32 (towards W-stationary) lose 5-10 %
   // everywhere (scripts/bench_gemm_group_m.py, two boxes).  Order only: the bits do not depend on it.
   k.epi_generic = drag_opt(DRAG_OPT_GEMM_EPILOGUE) == 1;
-  k.group_m = drag_opt(DRAG_OPT_GEMM_GROUP_M) > 0 ? drag_opt(DRAG_OPT_GEMM_GROUP_M) : (K >= 8192 ? 4 : 8);
+  // Round 5 (profiles/r05_gemm_tile_walk_fetch_clock.txt: bytes the L2s pull per launch and the clock the launch gets, per setting): the
+  // fabric traffic of a launch is A x tiles_n / (32 / g) + W x tiles_m / g and the chip — at its 1400 W socket cap in this kernel — pays for
+  // it in clock (g = 1 on (42696, 21504, 3072): 23.4 GB and 1.48 GHz; g = 4: 11.5 GB and 1.77 GHz).  4 | 8 are the two minima; the wide
+  // launches (N >= 16384: the single blocks' q|k|v|mlp Linear) run 1.5 % faster on 4.
+  k.group_m = drag_opt(DRAG_OPT_GEMM_GROUP_M) > 0 ? drag_opt(DRAG_OPT_GEMM_GROUP_M) : (K >= 8192 || N >= 16384 ? 4 : 8);
   static const bool narrow = env_flag("DRAG_GEMM_NARROW");
   k.wide = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (k.cm.rpb >= M || c_bs % 8 == 0) &&
            (!resid || ((uintptr_t)resid & 15) == 0) && (!gate || (((uintptr_t)gate & 15) == 0 && ldg % 8 == 0)) &&

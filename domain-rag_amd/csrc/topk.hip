@@ -278,6 +278,157 @@ __global__ __launch_bounds__(256, 2) void ip_scan_kernel(ScanArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ scan, d = 512: the queries in REGISTERS (round 5)
+// ip_scan_kernel reads every query fragment from the workgroup's LDS image again for every corpus chunk: 4 KiB of query reads next to the
+// 4 KiB of corpus reads and the 4 KiB the LDS-DMA writes, per wave and chunk — 8 waves of a CU keep the LDS ~75 % busy, and at 64 queries
+// per pass (four sibling workgroups per row range, the exact-f32 matrix core the bound) the scan reached only half of the matrix peak.
+// A tile of 16 queries x 512 dimensions is 128 floats per lane in the MFMA's own operand layout (lane (g, r16): query q0 + r16, the four
+// floats at d = 64 c + 16 cc + 4 g of every chunk c and quarter cc): with two waves per SIMD there are 256 registers per lane, so the
+// tile lives in registers for the whole launch, loaded once straight from global memory (L2 after the first workgroup).  No query image,
+// no start-up barrier, half the LDS reads, 32 KiB of LDS per workgroup instead of 64.  The chunk index has to be a compile-time constant
+// for that (register arrays cannot be indexed at run time), so a group's eight chunks are unrolled; the LDS-DMA stream is the same one
+// (chunk by chunk, one ahead, across group boundaries), the MFMA order per output is the same: same bits (every top-k / score test runs
+// on this kernel by default; "topk_qreg" = 1 switches back to ip_scan_kernel for the A/B).  Same grid, same row -> wave assignment, same
+// output modes.
+__global__ __launch_bounds__(256, 2) void ip_scan_q512_kernel(ScanArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 4096];     // per wave: two 4 KiB chunk buffers
+  constexpr int nch = 8;
+  const int w = wave_id(), l = lane_id();
+  char* sA = smem + w * (2 * 4096);
+  const int grp8 = (int)blockIdx.x >> 3;
+  const int tile = grp8 % p.ntile;
+  const long long worker = (long long)(grp8 / p.ntile) * 8 + ((int)blockIdx.x & 7);
+  const long long nworkers = (long long)(gridDim.x / (8 * p.ntile)) * 8;
+  const int q0 = tile * 16;
+  const int g = l >> 4, r16 = l & 15;
+  const int rd_base = r16 * 256;
+  unsigned lane_off[4];
+  int lane_row[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lane_row[i] = 4 * i + (l >> 4);
+    lane_off[i] = (unsigned)((((l & 15) ^ (lane_row[i] & 15)) & 15) * 16);
+  }
+  const int qq = q0 + r16;
+  u64 T = ~0ull;
+  unsigned ncand = 0;
+  u64* region = nullptr;
+  const long long step = nworkers * 4;
+  const long long first = worker * 4 + w;
+  if (p.mode == SCAN_KEYS_FILTER && qq < p.Q) {
+    T = p.thresh[qq];
+    region = p.keys + (long long)qq * p.kstride + (worker * 4 + w) * p.region_cap;
+  }
+  if (first >= p.niter) {                // a wave without rows still owns a region per query: say that it is empty
+    if (p.mode == SCAN_KEYS_FILTER && l < 16 && q0 + l < p.Q) p.counts[(long long)(q0 + l) * p.nregions + worker * 4 + w] = 0u;
+    return;
+  }
+  // ---- the first chunk's DMA goes out before the query tile is fetched (both latencies overlap)
+  const long long nmine = (p.niter - first + step - 1) / step;
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff[4];
+  auto descriptor = [&](long long it_) {     // base of a group's 16 rows, clamped row offsets for a ragged last group
+    const long long row0 = it_ * p.gstride * 16;
+    const int nvalid = (int)min((long long)16, p.N - row0);
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.corpus + row0 * 512), 0, (unsigned)(nvalid * 512 * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) voff[i] = (unsigned)(min(lane_row[i], nvalid - 1) * 512 * 4) + lane_off[i];
+  };
+  auto issue = [&](int buf, int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (DRAG_LDS void*)((DRAG_LDS char*)sA + buf * 4096 + i * 1024), 16, voff[i], c * 256, 0, 0);
+  };
+  descriptor(first);
+  issue(0, 0);
+  f32x4_t qv[nch][4];
+  {
+    const float* qp = p.queries + (long long)min(qq, p.Q - 1) * 512 + 4 * g;
+#pragma unroll
+    for (int c = 0; c < nch; ++c)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        qv[c][cc] = *(const f32x4_t*)(qp + 64 * c + 16 * cc);
+        if (qq >= p.Q) qv[c][cc] = (f32x4_t){0.f, 0.f, 0.f, 0.f};          // rows past Q are zero (as in the LDS image)
+      }
+  }
+  long long it = first;
+  for (long long j = 0; j < nmine; ++j, it += step) {
+    const bool more = j + 1 < nmine;
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < nch; ++c) {
+      // chunk c sits (or lands) in buffer c & 1; the next chunk of the stream goes to the other buffer, whose reads the MFMAs of the
+      // previous chunk consumed (lgkmcnt(0) below)
+      if (c + 1 < nch) {
+        issue((c + 1) & 1, c + 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else if (more) {
+        descriptor(it + step);
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const char* a = sA + (c & 1) * 4096 + rd_base;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const f32x4_t av = *(const f32x4_t*)(a + ((((4 * cc + g) ^ r16) & 15) * 16));
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ss], qv[c][cc][ss], acc, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- a group is complete: acc[r] = score[row0 + 4g + r][query q0 + r16]
+    const long long row0 = it * p.gstride * 16;
+    if (p.mode == SCAN_KEYS_FILTER) {
+      u64 key[4];
+      bool pass[4], any = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = row0 + 4 * g + r;
+        key[r] = composite(acc[r], (unsigned)row);
+        pass[r] = row < p.N && key[r] >= T;        // T = ~0 in lanes without a query
+        any = any || pass[r];
+      }
+      if (__ballot(any) != 0ull) {
+        const u64 mine = 0x0001000100010001ull << r16;
+        const u64 below = (1ull << l) - 1ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u64 m = __ballot(pass[r]) & mine;
+          if (pass[r]) region[ncand + __popcll(m & below)] = key[r];
+          ncand += (unsigned)__popcll(m);
+        }
+      }
+    } else if (p.mode == SCAN_GROUP_MAX || p.mode == SCAN_SCORES_GMAX) {
+      if (p.mode == SCAN_SCORES_GMAX && qq < p.Q) *(f32x4_t*)(p.scores + (long long)qq * p.npad + row0 + 4 * g) = acc;
+      u64 m = 0ull;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = row0 + 4 * g + r;
+        const u64 key = row < p.N ? composite(acc[r], (unsigned)row) : 0ull;
+        m = key > m ? key : m;
+      }
+      { const u64 o = shfl64(m, l ^ 16); m = o > m ? o : m; }
+      { const u64 o = shfl64(m, l ^ 32); m = o > m ? o : m; }
+      if (l < 16 && qq < p.Q) p.keys[(long long)qq * p.kstride + it] = m;
+    } else if (qq < p.Q) {
+      if (p.mode == SCAN_SCORES) {
+        *(f32x4_t*)(p.scores + (long long)qq * p.npad + row0 + 4 * g) = acc;
+      } else {
+        u64* dst = p.keys + (long long)qq * p.kstride + it * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long row = row0 + 4 * g + r;
+          dst[r] = row < p.N ? composite(acc[r], (unsigned)row) : 0ull;
+        }
+      }
+    }
+  }
+  if (p.mode == SCAN_KEYS_FILTER && l < 16 && q0 + l < p.Q) p.counts[(long long)(q0 + l) * p.nregions + worker * 4 + w] = ncand;
+}
+
 // ------------------------------------------------------------------ selection
 constexpr int LMAX = 8192;   // elements a selection workgroup holds in LDS
 constexpr int KMAX = 2048;
@@ -786,6 +937,11 @@ int launch_scan(ScanArgs& sa, hipStream_t st) {
   if (qt == 2) return launch_scan_n<2, 2>(sa, st);
 #endif
   if (drag_opt(DRAG_OPT_TOPK_DEPTH) == 3) return launch_scan_n<3, 1>(sa, st);
+  if (sa.d == 512 && drag_opt(DRAG_OPT_TOPK_QREG) != 1) {      // CLIP's width: the query tile in registers (ip_scan_q512_kernel)
+    hipLaunchKernelGGL(ip_scan_q512_kernel, dim3(scan_grid(sa.niter, sa.ntile)), dim3(256), 0, st, sa);
+    DRAG_LAUNCH_CHECK();
+    return 0;
+  }
   return launch_scan_n<2, 1>(sa, st);
 }
 

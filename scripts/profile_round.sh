@@ -14,6 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 run() { echo "== $*" >&2; "$@"; }
 run rocprofv3 --kernel-trace -d "$OUT" -o bench -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-side-configs > "$OUT/bench_under_rocprof.log" 2>&1
 python "$R/scripts/rocpd_stats.py" "$OUT/bench_results.db" > "$OUT/kernel_stats_bench_default.txt" 2>&1
+# the timed region alone (after the warm-up batch's last kernel): what runs PER BATCH, without model construction
+python "$R/scripts/rocpd_stats.py" "$OUT/bench_results.db" image_postprocess 1 > "$OUT/kernel_stats_bench_default_timed_region.txt" 2>&1
 run rocprofv3 --kernel-trace -d "$OUT" -o retr -- python "$R/bench.py" --workload retrieval --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/retrieval_under_rocprof.log" 2>&1
 python "$R/scripts/rocpd_stats.py" "$OUT/retr_results.db" > "$OUT/kernel_stats_bench_retrieval.txt" 2>&1
 run rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT" -o fetch -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-side-configs > "$OUT/pmc_fetch.log" 2>&1
