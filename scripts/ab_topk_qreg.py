@@ -28,7 +28,7 @@ for N in [int(x) for x in os.environ.get("NS", "118287,1000000").split(",")]:
             ops.set_option("topk_qreg", v)
             ops.cosine_scores(corpus, q, out=sc)
             D, I = ops.cosine_topk(corpus, q, 100)
-            ref[v] = (sc.clone(), D, I)
+            ref[v] = (sc[:, :N].clone(), D, I)          # (columns past N: the ragged last group and the row padding, written by nobody)
         same = torch.equal(ref[0][0], ref[1][0]) and torch.equal(ref[0][1], ref[1][1]) and torch.equal(ref[0][2], ref[1][2])
         for rep in range(3):
             for v in (0, 1):
