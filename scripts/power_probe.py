@@ -49,6 +49,14 @@ elif what == "attention":
     def work():
         ops.attention(qkv, qkv.view(-1)[D:], vt, out, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
         return 4.0 * S * S * 128 * H * B
+elif what.startswith("scan"):       # scan<Q>: the top-k corpus pass at N = 1 000 000, d = 512 (HBM-bound): bytes instead of flops
+    N, Q = 1000000, int(what[4:] or 16)
+    corpus = torch.randn(N, 512, device=dev); corpus /= corpus.norm(dim=-1, keepdim=True)
+    qs = torch.randn(Q, 512, device=dev); qs /= qs.norm(dim=-1, keepdim=True)
+    sc = ops.cosine_scores(corpus, qs)
+    def work():
+        ops.cosine_scores(corpus, qs, out=sc)
+        return float(N * 512 * 4)
 else:
     def work():
         time.sleep(0.05); return 0.0
@@ -62,5 +70,5 @@ while time.time() - t0 < secs:
 el = time.time() - t0
 stop = True; th.join()
 pw = [s[1] for s in samples[2:] if s[1] is not None]; ck = [s[3] for s in samples[2:] if s[3] is not None]; cap = [s[2] for s in samples if s[2] is not None]
-print(f"{what}: {fl / el / 1e12:.0f} TFLOP/s over {el:.1f} s; socket power samples {len(pw)}: mean {sum(pw) / max(len(pw), 1):.0f} W, max {max(pw) if pw else 0:.0f} W; "
+print(f"{what}: {fl / el / 1e12:.2f} T{'B' if what.startswith('scan') else 'FLOP'}/s over {el:.1f} s; socket power samples {len(pw)}: mean {sum(pw) / max(len(pw), 1):.0f} W, max {max(pw) if pw else 0:.0f} W; "
       f"cap {cap[0] if cap else None} W; sclk mean {sum(ck) / max(len(ck), 1):.0f} MHz min {min(ck) if ck else 0} max {max(ck) if ck else 0}", flush=True)

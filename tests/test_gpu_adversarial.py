@@ -505,3 +505,85 @@ def test_fill_30_chained_steps_on_student_t_weights(gpu):
                                                "seconds": time.time() - t_start})
     chained._check(rows, "Fill x30, Student-t weights")
     assert e <= max(1e-2 + 0.5 / 255, 1.3 * e_or), f"pixels: HIP vs f32 {e:.4f}, bf16 oracle vs f32 {e_or:.4f}"
+
+
+# ------------------------------------------------------------------ GroupNorm's shift, the VAE on extreme images and latents
+def test_groupnorm_outlier_or_inf_at_the_pixels_the_shift_is_taken_from(gpu):
+    """the statistics are sums of x - c and (x - c)^2 (round 4); c was the group's element at (pixel 0, first channel): ONE outlier there
+    brought E[x^2] - E[x]^2 back for a large-mean group, ONE Inf there made every statistic of the group NaN.  c is now the
+    mean of the group's channels at four pixels; a non-finite c counts as 0.  Against torch's float64 GroupNorm (the reference's is torch's)."""
+    import torch.nn.functional as F
+    from domain_rag_amd import ops
+    g_ = _g(11)
+    for C, H, W in [(128, 64, 64), (512, 24, 24)]:
+        B, cpg = 2, C // 32
+        x = torch.randn(B, C, H, W, generator=g_)
+        for grp, (mean, spread) in {3: (100.0, 0.5), 7: (-300.0, 2.0)}.items():
+            x[:, grp * cpg:(grp + 1) * cpg] = mean + spread * torch.randint(-1, 2, (B, cpg, H, W), generator=g_).float()
+        x[0, 3 * cpg, 0, 0] = 3e4          # the old shift element of group 3: an outlier 300 x the group's mean
+        x[1, 7 * cpg, 0, 0] = -2e5         # and of group 7 in the other image
+        x[:, 5 * cpg:(5 + 1) * cpg, 0, 0] = 1e3      # every channel of group 5 at pixel 0 (one of the four shift pixels) is an outlier
+        x = _bf(x).float()
+        gam, bet = _bf(torch.randn(C, generator=g_)), _bf(torch.randn(C, generator=g_))
+        ref = F.group_norm(x.double(), 32, gam.double(), bet.double(), 1e-6)
+        y = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device=gpu)
+        ops.groupnorm_silu(_bf(x.permute(0, 2, 3, 1).contiguous()).to(gpu), y, gam.to(gpu), bet.to(gpu), B, H, W, C, out_pad=0, silu=False)
+        got = y.cpu().double().permute(0, 3, 1, 2)
+        for grp in (3, 7, 5, 0, 20):
+            sl = slice(grp * cpg, (grp + 1) * cpg)
+            e = ((got[:, sl] - ref[:, sl]).abs().max() / ref[:, sl].abs().max()).item()
+            assert e < 1.5e-2, (C, grp, e)
+        # one Inf: that group's output is non-finite in torch too; every OTHER group stays exact
+        xi = x.clone(); xi[0, 9 * cpg, 0, 0] = float("inf")
+        y2 = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device=gpu)
+        ops.groupnorm_silu(_bf(xi.permute(0, 2, 3, 1).contiguous()).to(gpu), y2, gam.to(gpu), bet.to(gpu), B, H, W, C, out_pad=0, silu=False)
+        got2 = y2.cpu().double().permute(0, 3, 1, 2)
+        keep = torch.ones(C, dtype=torch.bool); keep[9 * cpg:10 * cpg] = False
+        assert torch.equal(got2[:, keep], got[:, keep]) and torch.equal(got2[1], got[1])
+        assert not torch.isfinite(got2[0, 9 * cpg:10 * cpg]).all()
+
+
+def test_vae_on_extreme_images_and_latents(gpu):
+    """the Fill pipeline's two encodes on saturated / flat / checkerboard pictures (uint8 0 and 255 everywhere, a 1-pixel checkerboard: the
+    largest high-frequency content an image can hold) and its decode on latents with a massive channel and a flat region — against the bf16
+    and float32 oracles on the same weights, bar 1.3 x the reference dtype's own distance from float32"""
+    from domain_rag_amd import vae
+    from oracle import vae as ov
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    cfg = vae.VaeConfig()
+    p = vae.init_params(cfg, seed=5)
+    p32 = {k: v.float() for k, v in p.items()}
+    model = vae.FluxVaeHIP(cfg, p, gpu)
+    res, h, w = 256, 16, 16
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    imgs = torch.stack([torch.full((res, res, 3), 255, dtype=torch.uint8), torch.zeros((res, res, 3), dtype=torch.uint8),
+                        (((yy + xx) % 2) * 255).to(torch.uint8)[..., None].expand(res, res, 3).contiguous(),
+                        torch.where(xx[..., None] < res // 2, torch.tensor(255), torch.tensor(0)).to(torch.uint8).expand(res, res, 3).contiguous()])
+    B = imgs.shape[0]
+    toks = torch.empty((B, h * w, 64), dtype=torch.bfloat16, device=gpu)
+    model.encode_to_tokens(imgs.to(gpu), None, None, toks, 64)
+    toks = toks.cpu()
+    assert torch.isfinite(toks.float()).all()
+    with torch.no_grad():
+        for b in range(B):
+            x = ov.preprocess_image(imgs[b:b + 1])
+            ref = ov.pack_latents(ov.sample_latents(ov.encode_moments(p32, x), None))
+            refb = ov.pack_latents(ov.sample_latents(ov.encode_moments(p, x.bfloat16()), None))
+            e, e_or = _rel(toks[b:b + 1], ref), _rel(refb, ref)
+            print(f"[adversarial] vae encode image {b}: HIP-f32 {e:.3e} | bf16 oracle-f32 {e_or:.3e} | ratio {e / max(e_or, 1e-30):.2f}", flush=True)
+            assert e < max(1.5e-2, 1.3 * e_or), (b, e, e_or)
+    g = _g(6)
+    lat = torch.randn(2, h * w, 64, generator=g)
+    lat[0, :, 7] *= 40.0                    # a massive latent channel
+    lat[1, : h * w // 2] = 0.25             # a flat half
+    lat[1, 5, :] = 60.0                     # one hot token
+    lat = _bf(lat)
+    img_u8, rows = model.decode_tokens(lat.to(gpu), 2, h, w, return_rows=True)
+    got = (rows.view(2, res, res, -1)[..., :3].float().cpu() / 2 + 0.5).clamp(0, 1).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        for b in range(2):
+            _, ref32 = ov.decode_tokens_to_u8(p32, lat[b:b + 1].float(), h, w)
+            _, refbf = ov.decode_tokens_to_u8(p, lat[b:b + 1], h, w)
+            e, e_or = _rel(got[b:b + 1], ref32), _rel(refbf, ref32)
+            print(f"[adversarial] vae decode latents {b}: HIP-f32 {e:.3e} | bf16 oracle-f32 {e_or:.3e} | ratio {e / max(e_or, 1e-30):.2f}", flush=True)
+            assert e < max(1e-2, 1.3 * e_or), (b, e, e_or)
