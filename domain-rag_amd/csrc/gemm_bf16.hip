@@ -761,6 +761,109 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep(GemmKArgs p) {
   }
 }
 
+#if DRAG_EXP
+// --------------------------------------------------------------------------------------------
+// gemm_bf16_w4 (round 5; EXPERIMENT, DRAG_EXPERIMENTS builds only: "gemm_kernel" = 400 + V) — the 256x256x64 tile as FOUR waves x (128 x 128),
+// one wave per SIMD with the whole register file (256 accumulators in AGPRs): a third less LDS -> register traffic per flop than the
+// 8-wave kernel below, the shape of the vendor library's kernel on this chip.  hipcc cannot schedule a 512-register wave
+// (gemm_bf16_deep<8, 2, 8>: waterfall loops around every LDS-DMA, 168 v_accvgpr moves per K-step), so the K loop is ONE asm statement whose
+// text scripts/gen/gemm4w_kloop.py generates (register map and schedule there); the kernel binds its operands to the physical registers
+// the text names.  Plain tiles (not persistent), K a multiple of 128.  Bit-identical to every other GEMM kernel here.
+// MEASURED (profiles/r05_gemm_w4_*.log; us per K-step and tile round, the 8-wave kernel 1.45-1.49 on the same boxes): V1 = refill by
+// LDS-DMA 1.50-1.53, V0 = refill through registers (every chunk a full K-step in flight) 1.58; ablations: no refill 1.12-1.15 (= 2048
+// MFMA cycles at 96 %: the MFMA + fragment-read skeleton is fine), no barrier -0.07...-0.16, every chunk from an L2-resident K-step 1.26.
+// So 0.3 us of a K-step is the operand stream pushing back on the ISSUE of a lone wave's loads (not latency: a K-step of flight per chunk
+// does not help) — exactly what the 8-wave kernel's second wave group hides.  Not the product kernel.
+// --------------------------------------------------------------------------------------------
+#include "gemm4w_kloop.h"
+typedef __attribute__((ext_vector_type(32))) float f32x32_t;
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
+
+template <int V>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4(GemmKArgs p) {
+  constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * STAGE = 128 KiB
+  const int w = wave_id();
+  const int l = lane_id();
+  const int wr = w >> 1, wc = w & 1;
+  int tm, tn;
+  pick_tile(p, (int)blockIdx.x, tm, tn);
+  pick_segment(p, tm);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const long long a0 = p.am.off(m0);
+  const int wrows = min(256, p.N - n0);
+  // descriptors as four dwords each (base, base_hi, num_records, flags): operands of the asm statement
+  const unsigned long long pa = (unsigned long long)(uintptr_t)(p.A + a0), pw = (unsigned long long)(uintptr_t)(p.W + (long long)n0 * p.K);
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };      // wave-uniform by construction: say so
+  // bounded: the register form requests up to one K-step past K in its last iterations (zeros / the next row's start, never used)
+  const long long a_span = (p.am.off(min(m0 + 255, p.M - 1)) - a0 + p.K) * 2;
+  const u32x4_t rsA = {uni((uint32_t)pa), uni((uint32_t)(pa >> 32) & 0xffffu), uni((uint32_t)a_span), 0x00020000u};
+  const u32x4_t rsW = {uni((uint32_t)pw), uni((uint32_t)(pw >> 32) & 0xffffu), uni((uint32_t)((long long)wrows * p.K * 2)), 0x00020000u};
+  u32x8_t voA, voW;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (w * 8 + i) * 8 + (l >> 3);
+    const int slot = (l & 7) ^ ((row >> 1) & 7);
+    const int ra = min(m0 + row, p.M - 1);                 // clamp: rows past the edge are never stored
+    voA[i] = (unsigned)((p.am.off(ra) - a0 + slot * 8) * 2);
+    const int rw = min(row, wrows - 1);
+    voW[i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
+  const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)w * 8192u));
+  const int p0 = (l >> 4) ^ ((l & 15) >> 1);
+  const int fa = (wr * 128 + (l & 15)) * 128;
+  const int fb = A_BYTES + (wc * 128 + (l & 15)) * 128;
+  u32x8_t rd;      // [buffer][X k-half 0, X k-half 1, W k-half 0, W k-half 1]
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      rd[4 * b + ks] = lds0 + (unsigned)(b * STAGE + fa + ((p0 ^ (ks * 4)) << 4));
+      rd[4 * b + 2 + ks] = lds0 + (unsigned)(b * STAGE + fb + ((p0 ^ (ks * 4)) << 4));
+    }
+  f32x32_t accrow[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 32; ++r) accrow[i][r] = 0.f;
+  unsigned n2 = (unsigned)(p.K / 128 - 1);       // pairs of K-steps in the steady loop; the last pair is the tail
+  unsigned soff = 0;
+  // prologue: K-steps 0 and 1 into the two stage buffers, then K-step 0 visible to every wave
+  const u32x2_t wrv = {lds0 + (unsigned)(w * 8192 + l * 16), lds0 + (unsigned)(STAGE + w * 8192 + l * 16)};
+#define G4W_OUTS                                                                                                                              \
+  "+{a[0:31]}"(accrow[0]), "+{a[32:63]}"(accrow[1]), "+{a[64:95]}"(accrow[2]), "+{a[96:127]}"(accrow[3]), "+{a[128:159]}"(accrow[4]),        \
+      "+{a[160:191]}"(accrow[5]), "+{a[192:223]}"(accrow[6]), "+{a[224:255]}"(accrow[7]), [n2] "+s"(n2), [soff] "+s"(soff)
+#define G4W_INS "{v[128:135]}"(voA), "{v[136:143]}"(voW), "{v[144:151]}"(rd), [rsa] "s"(rsA), [rsw] "s"(rsW), [ldsw] "s"(ldsw)
+  if constexpr (V == 1) {          // form D: refill by LDS-DMA
+    asm volatile(G4W_D_STAGE0 G4W_FIRST_READS G4W_D_LOOP G4W_D_TAIL : G4W_OUTS : G4W_INS : G4W_CLOBBERS, "scc", "memory");
+  } else if constexpr (V == 2) {   // timing ablations of form R
+    asm volatile(G4W_R_STAGE0 G4W_FIRST_READS G4W_R_LOOP_NOBAR G4W_R_TAIL : G4W_OUTS : G4W_INS, "{v[152:153]}"(wrv) : G4W_CLOBBERS_R, "scc", "memory");
+  } else if constexpr (V == 3) {
+    asm volatile(G4W_R_STAGE0 G4W_FIRST_READS G4W_R_LOOP_NOREFILL G4W_R_TAIL : G4W_OUTS : G4W_INS, "{v[152:153]}"(wrv) : G4W_CLOBBERS_R, "scc", "memory");
+  } else {                         // form R: refill through registers
+    asm volatile(G4W_R_STAGE0 G4W_FIRST_READS G4W_R_LOOP G4W_R_TAIL : G4W_OUTS : G4W_INS, "{v[152:153]}"(wrv) : G4W_CLOBBERS_R, "scc", "memory");
+  }
+#undef G4W_OUTS
+#undef G4W_INS
+  f32x4_t acc[8][8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = accrow[mi][4 * ni + r];
+  const GemmKArgs pd = dest_of(p, n0);
+  if (p.wide) {
+    __syncthreads();                              // the slabs alias the stage buffers
+    staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, l, acc, smem + w * 2048);
+  } else {
+    wave_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 128 + (l >> 4) * 4, acc);
+  }
+}
+
+#endif
+
 // --------------------------------------------------------------------------------------------
 // gemm_bf16_t256 — 256x256x64 tile, 8 waves (2 along M x 4 along N), wave tile 128x64 as 8x4
 // v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  LDS: 2 K-tile buffers x {A0,A1,B0,B1}
@@ -1203,8 +1306,8 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
   } else if (choice) {
     const int deep = choice;
     const int ni = deep >= 100 ? 6 : 4, mi = (deep % 100) / 10, st = deep % 10;
-    DRAG_CHECK((mi >= 1 && mi <= 4) && st >= 2 && st <= 4, "drag_gemm_bf16: gemm_kernel must be 0, 1, 2, 10 * MI + ST or 100 + 10 * MI + ST of a gemm_bf16_deep<MI, ST, NI> that is built");
-    tiles_of(32 * mi); k.tiles_n = (a->N + 32 * ni - 1) / (32 * ni);
+    DRAG_CHECK((deep >= 400 && deep <= 405) || ((mi >= 1 && mi <= 4) && st >= 2 && st <= 4), "drag_gemm_bf16: gemm_kernel must be 0, 1, 2, 10 * MI + ST or 100 + 10 * MI + ST of a gemm_bf16_deep<MI, ST, NI> that is built");
+    tiles_of(deep >= 400 ? 256 : 32 * mi); k.tiles_n = (a->N + 32 * ni - 1) / (32 * ni);
     const dim3 g(k.tiles_m * k.tiles_n);
 #define DRAG_DEEP_LAUNCH(MI_, ST_, NI_)                                                                                    \
   {                                                                                                                        \
@@ -1223,6 +1326,19 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
   break
 #define DRAG_DEEP(MI_, ST_) case 10 * MI_ + ST_: DRAG_DEEP_LAUNCH(MI_, ST_, 4)
 #define DRAG_DEEP6(MI_, ST_) case 100 + 10 * MI_ + ST_: DRAG_DEEP_LAUNCH(MI_, ST_, 6)
+#if DRAG_EXP
+    if (deep >= 400 && deep <= 405) {            // round-5 experiment: gemm_bf16_w4<variant>
+      DRAG_CHECK(a->K % 128 == 0 && a->K >= 256 && b == nullptr, "drag_gemm_bf16: gemm_kernel 400 (gemm_bf16_w4) needs K % 128 == 0, K >= 256, one segment");
+      k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
+      const dim3 g4(k.tiles_m * k.tiles_n);
+#define DRAG_W4(V_) case 400 + V_: DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4<V_>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess, "hipFuncSetAttribute"); \
+      hipLaunchKernelGGL((gemm_bf16_w4<V_>), g4, dim3(256), 131072, st_, k); break
+      switch (deep) { DRAG_W4(0); DRAG_W4(1); DRAG_W4(2); DRAG_W4(3); default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel 400..403"); }
+#undef DRAG_W4
+      DRAG_LAUNCH_CHECK();
+      return 0;
+    }
+#endif
     switch (deep) {
       DRAG_DEEP(4, 2); DRAG_DEEP(4, 3);
       DRAG_DEEP(3, 2); DRAG_DEEP(3, 3);

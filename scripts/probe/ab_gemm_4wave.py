@@ -12,7 +12,7 @@ def bench(fn, iters=8):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-KERNELS = [int(v) for v in os.environ.get("KERNELS", "2,282").split(",")]
+KERNELS = [int(v) for v in os.environ.get("KERNELS", "2,400").split(",")]
 for (M, N) in [(32768, 3072), (16384, 4096)]:
     res = {}
     for K in (3072, 6144, 12288):
