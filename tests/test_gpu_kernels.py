@@ -966,3 +966,24 @@ def test_gemm_two_destinations_equals_two_gemms(gpu, M):
         ops.gemm(a, w, out=o1, bias=b, M=M, lda=K, ldc=ld1, out2=o2, ldc2=ld2, n_split=100)
     with pytest.raises(RuntimeError, match="two-destination"):
         ops.gemm(a, w, out=o1, bias=b, M=M, lda=K, ldc=ld1, out2=o2, ldc2=ld2, n_split=N1, resid=o1)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (2500, 1024, 3072), (300, 260, 128 * 5)])
+def test_gemm_w4_experiment_is_bit_identical(gpu, M, N, K):
+    """round 5's 4-wave x (128 x 128) GEMM with the generated, hand-placed K loop (DRAG_EXPERIMENTS builds only: "gemm_kernel" 400 = refill
+    through registers, 401 = refill by LDS-DMA): same MFMA order per output element as every other GEMM kernel, so the same bits — on full,
+    ragged and odd-pair-count shapes, with a bias / gate / residual epilogue"""
+    from domain_rag_amd import ops
+    if not ops.experiments_built():
+        pytest.skip("gemm_bf16_w4 is compiled with DRAG_EXPERIMENTS=1 only (a measured non-improvement, DESIGN.md round 5)")
+    a, w, b = _randn((M, K), 1).to(gpu), _randn((N, K), 2, 0.05).to(gpu), _randn((N,), 3).to(gpu)
+    g, r = _randn((1, N), 4).to(gpu), _randn((M, N), 5).to(gpu)
+    ref = ops.gemm(a, w, bias=b)
+    ref2 = ops.gemm(a, w, bias=b, gate=g, resid=r, ldg=N)
+    for kern in (400, 401):
+        ops.set_option("gemm_kernel", kern)
+        try:
+            got, got2 = ops.gemm(a, w, bias=b), ops.gemm(a, w, bias=b, gate=g, resid=r, ldg=N)
+        finally:
+            ops.set_option("gemm_kernel", 0)
+        assert torch.equal(got, ref) and torch.equal(got2, ref2), kern
