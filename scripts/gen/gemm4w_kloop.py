@@ -68,7 +68,7 @@ def lwrite(i, buf):
     return f"ds_write_b128 v{152 + buf}, v[{G0 + 4 * i}:{G0 + 4 * i + 3}] offset:{(0 if x else A_BYTES) + (i & 7) * 1024}"
 
 
-def kstep(buf, form, refill=True, request=True, next_reads=True, barrier=True, every=4, start=3):
+def kstep(buf, form, refill=True, request=True, next_reads=True, barrier=True, every=4, start=3, write=True):
     t = []
     order = [(mi, ni) for mi in range(8) for ni in range(8)]
     r1 = reads(1, buf)
@@ -95,7 +95,8 @@ def kstep(buf, form, refill=True, request=True, next_reads=True, barrier=True, e
                 # chunk n of K-step t + 2 has landed when at most 15 younger requests are outstanding (requests return in order); its
                 # registers go to LDS and are requested again at once: LDS instructions read their data registers at issue
                 t.append(f"s_waitcnt vmcnt({15 if request else 15 - n})")
-                t.append(lwrite(n, buf))
+                if write:
+                    t.append(lwrite(n, buf))
                 if request:
                     t.append(gload(n))
             n += 1
@@ -139,5 +140,5 @@ emit("G4W_R_STAGE0", pro)
 emit("G4W_R_LOOP", loop_of("R"))
 emit("G4W_R_TAIL", kstep(0, "R", request=False) + kstep(1, "R", refill=False, next_reads=False))
 # timing ablations of form R (wrong values): no barrier | no refill at all | every chunk from the same, L2-resident K-step
-emit("G4W_R_LOOP_NOBAR", loop_of("R", barrier=False))
+emit("G4W_R_LOOP_NOBAR", loop_of("R", write=False))            # V2: requests and waits, no LDS writes
 emit("G4W_R_LOOP_NOREFILL", loop_of("R", refill=False))
