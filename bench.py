@@ -375,10 +375,10 @@ def _pmc_mfma_util():
             with open(path) as f:
                 pm = json.load(f)
             out = {"source": os.path.relpath(path, ROOT)}
-            for label, subs in (("gemm_bf16_t256<0>", ("gemm_bf16_t256ILi0",)), ("attention", ("attention_q64_kernel", "attention_d128_kernelILi8"))):
+            for label, subs in (("gemm", ("gemm_bf16_w4p", "gemm_bf16_t256ILi0")), ("attention", ("attention_q64_kernel", "attention_d128_kernelILi8"))):
                 key = next(k for sub in subs for k in pm if sub in k)          # (the 64-query kernel since round 4)
                 r = pm[key]
-                out[label] = {"mfma_util": r["mfma_util"], "clock_ghz": r["clock_ghz"], "avg_us_profiled": r["avg_us_profiled"],
+                out[label] = {"kernel": key.split("(")[0][-60:], "mfma_util": r["mfma_util"], "clock_ghz": r["clock_ghz"], "avg_us_profiled": r["avg_us_profiled"],
                               "wave_parked_frac": r.get("sq_wait_any_per_wave_cycle"), "wave_issue_stall_frac": r.get("sq_wait_inst_any_per_wave_cycle"),
                               "lds_bank_conflict_frac": r.get("sq_lds_bank_conflict_per_wave_cycle")}
             return out
@@ -462,10 +462,11 @@ def run_generate(args, d: Dist):
     if d.rank != 0:
         return None
     flops, ms, launches = rec.totals()
-    traffic, traffic_src = _pmc_traffic("gemm_bf16_t256ILi0")
     all_gemm = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    bk = rec.by_kernel()                      # the dominant kernel by time: gemm_bf16_t256<0> (every large Linear)
-    dn, dms, dfl = bk.get("gemm_bf16_t256<0>", (0, 0.0, 0.0))
+    bk = rec.by_kernel()                      # the dominant kernel by time: every large Linear (gemm_bf16_w4p since round 5, gemm_bf16_t256<0> before)
+    dom = max(bk, key=lambda k: bk[k][1]) if bk else "gemm_bf16_w4p"
+    dn, dms, dfl = bk.get(dom, (0, 0.0, 0.0))
+    traffic, traffic_src = _pmc_traffic({"gemm_bf16_w4p": "gemm_bf16_w4p", "gemm_bf16_t256<0>": "gemm_bf16_t256ILi0"}.get(dom, dom))
     achieved = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
     out = {
         "metric": f"composited images/sec @{args.res}^2, {args.denoise_steps} Flux-Redux steps", "value": images / dt, "unit": "images/s",
@@ -479,9 +480,9 @@ def run_generate(args, d: Dist):
                                f"batch={args.batch} per GPU (BASELINE configs[2])",
                    "stages": job.stages(), "global_batch": args.batch * d.world, "parallelism": f"dp{d.world}",
                    "weights": "seeded random init of the FLUX.1-Fill-dev architecture"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_t256<0>", "achieved": achieved, "peak": MFMA_BF16_PEAK_TF,
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_BF16_PEAK_TF,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TF, "traffic": traffic,
-                     "traffic_note": f"bytes/launch of gemm_bf16_t256<0> from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                     "traffic_note": f"bytes/launch of {dom} from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                      f"({traffic_src}); includes Infinity-Cache hits",
                      "launches_timed": dn, "sampled": f"all non-DiT stages + every {rec.every}th denoise step of the first timed batch",
                      "avg_launch_ms": dms / max(dn, 1),

@@ -349,8 +349,8 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
 // the row map's integer division per store when it does): the ablations of round 4 (profiles/r04_gemm_epilogue_ablations.log) put the
 // epilogue at 10 % of a K = 3072 tile with only 1.5-2.6 % of it in the LDS transpose and < 2 % in HBM writes — the rest is its own
 // instruction stream.  FORM: 0 = y, 1 = resid + y, 3 = resid + gate * y;  ACT: the activation applies to every column of the tile.
-template <int MI, int FORM, bool ACT>
-__device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long off0, int bidx, int nw0, int l, f32x4_t (*acc)[4], char* scr) {
+template <int MI, int FORM, bool ACT, int NI = 4, int NI0 = 0>      // NI / NI0: the wave's accumulator row has NI column blocks; this call takes blocks NI0 .. NI0 + 3
+__device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long off0, int bidx, int nw0, int l, f32x4_t (*acc)[NI], char* scr) {
   const int q = l >> 4, r16 = l & 15;
   const int c = l & 7, rl = l >> 3;
   const ActCoef ac = act_coef(p.act);
@@ -393,7 +393,8 @@ __device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long o
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      float v[4] = {acc[mi][ni][0] + bias[ni][0], acc[mi][ni][1] + bias[ni][1], acc[mi][ni][2] + bias[ni][2], acc[mi][ni][3] + bias[ni][3]};
+      float v[4] = {acc[mi][NI0 + ni][0] + bias[ni][0], acc[mi][NI0 + ni][1] + bias[ni][1], acc[mi][NI0 + ni][2] + bias[ni][2],
+                    acc[mi][NI0 + ni][3] + bias[ni][3]};
       if constexpr (ACT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -429,22 +430,134 @@ __device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long o
   }
 }
 
-template <int MI, int TM, int TN = TM, int NI = 4>
-__device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[NI],
+// The same for a wave tile of EIGHT column blocks (the 4-wave kernel's 128 x 128): two column groups through two slabs, software-pipelined by
+// hand — with one wave per SIMD nothing else covers the LDS round trip of a pass, so the slab writes of the next row block are issued
+// between a group's slab reads and its stores.  Operation for operation the arithmetic of staged_rows_fast (same bits).
+template <int MI, int FORM, bool ACT>
+__device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long off0, int bidx, int nw0, int l, f32x4_t (*acc)[8], char* scr) {
+  const int q = l >> 4, r16 = l & 15;
+  const int c = l & 7, rl = l >> 3;
+  const ActCoef ac = act_coef(p.act);
+  float bias[2][4][4];
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      bias[grp][ni][0] = bias[grp][ni][1] = bias[grp][ni][2] = bias[grp][ni][3] = 0.f;
+      if (p.bias) {
+        const u32x2_t bb = *(const u32x2_t*)(p.bias + nw0 + 64 * grp + ni * 16 + q * 4);
+        bias[grp][ni][0] = bf_lo(bb[0]); bias[grp][ni][1] = bf_hi(bb[0]); bias[grp][ni][2] = bf_lo(bb[1]); bias[grp][ni][3] = bf_hi(bb[1]);
+      }
+    }
+  int woff[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+    woff[ni] = r16 * 128 + (((2 * ni + (q >> 1)) ^ (r16 & 7)) << 4) + (((q & 1) ^ (r16 >> 3)) << 3);
+  const int roff = rl * 128 + ((c ^ rl) << 4);
+  const int n = nw0 + c * 8;
+  float g[2][8];
+  if constexpr (FORM == 3) {
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      const u32x4_t gg = *(const u32x4_t*)(p.gate + (long long)bidx * p.ldg + n + 64 * grp);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { g[grp][2 * i] = bf_lo(gg[i]); g[grp][2 * i + 1] = bf_hi(gg[i]); }
+    }
+  }
+  const unsigned lane_off = (unsigned)(rl * p.cm.ld + n);
+  bf16_t* const Cb = (bf16_t*)p.C + off0;
+  const bf16_t* const Rb = FORM ? p.resid + off0 : nullptr;
+  constexpr int RD = 2;
+  u32x4_t rres[RD][2][2];          // [ring][group][j]
+  auto load_resid = [&](int mi2) {
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rres[mi2 % RD][grp][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp);
+  };
+  auto write_slab = [&](int mi, int grp) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float v[4] = {acc[mi][4 * grp + ni][0] + bias[grp][ni][0], acc[mi][4 * grp + ni][1] + bias[grp][ni][1],
+                    acc[mi][4 * grp + ni][2] + bias[grp][ni][2], acc[mi][4 * grp + ni][3] + bias[grp][ni][3]};
+      if constexpr (ACT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = rbf(v[r]);
+          v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
+        }
+      }
+      u32x2_t o;
+      o[0] = pack2bf(v[0], v[1]);
+      o[1] = pack2bf(v[2], v[3]);
+      *(u32x2_t*)(scr + grp * 2048 + woff[ni]) = o;
+    }
+  };
+  if constexpr (FORM != 0) {
+#pragma unroll
+    for (int mi = 0; mi < RD; ++mi) load_resid(mi);
+  }
+  write_slab(0, 0);
+  write_slab(0, 1);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      u32x4_t y[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        y[j] = *(const u32x4_t*)(scr + grp * 2048 + roff + j * 1024);
+        if (j == 1) y[j] = (u32x4_t){y[j][2], y[j][3], y[j][0], y[j][1]};
+      }
+      // the slab is free once its two reads have been issued AND returned: the values above are consumed below, after the next row block's
+      // writes have been issued (the compiler's own lgkmcnt keeps the order: LDS operations of a wave complete in issue order)
+      asm volatile("" : "+v"(y[0]), "+v"(y[1]));
+      if (mi + 1 < MI) write_slab(mi + 1, grp);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (FORM != 0) {
+          const u32x4_t x = rres[mi % RD][grp][j];
+          if constexpr (FORM == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              y[j][i] = pack2bf(bf_lo(x[i]) + rbf(g[grp][2 * i] * bf_lo(y[j][i])), bf_hi(x[i]) + rbf(g[grp][2 * i + 1] * bf_hi(y[j][i])));
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[j][i] = pack2bf(bf_lo(x[i]) + bf_lo(y[j][i]), bf_hi(x[i]) + bf_hi(y[j][i]));
+          }
+        }
+        *(u32x4_t*)(Cb + (long long)(mi * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp) = y[j];
+      }
+    }
+    if constexpr (FORM != 0) {
+      if (mi + RD < MI) load_resid(mi + RD);
+    }
+  }
+}
+
+template <int MI, int TM, int TN = TM, int NI = 4>      // returns true when the tile took the specialised form (a fixed number of stores per wave)
+__device__ __forceinline__ bool staged_epilogue(const GemmKArgs& p, int m0, int mw0, int n0, int nw0, int l, f32x4_t (*acc)[NI],
                                                 char* scr) {
   constexpr int G0 = NI < 4 ? NI : 4;
-  if constexpr (NI == 4) {
+  if constexpr (NI == 4 || NI == 8) {
     const int b_first = m0 / p.cm.rpb;
     const bool fast = m0 + TM <= p.M && n0 + TN <= p.N && b_first == (m0 + TM - 1) / p.cm.rpb && (long long)8 * p.cm.ld + p.N < (1ll << 31);
     const bool act_none = p.act == DRAG_ACT_NONE || p.act_n0 >= n0 + TN, act_all = p.act != DRAG_ACT_NONE && p.act_n0 <= n0;
     if (fast && !p.epi_generic && (act_none || (act_all && !p.resid)) && !(p.gate && !p.resid)) {
       const long long off0 = p.cm.off(mw0);
+      // (NI = 8, the 4-wave kernel's 128-column wave tile: two column groups of four blocks through the same slab, one after the other)
+#define DRAG_FAST(FORM_, ACT_)                                                                              \
+  do {                                                                                                      \
+    if constexpr (NI == 8) staged_rows_fast8<MI, FORM_, ACT_>(p, off0, b_first, nw0, l, acc, scr);          \
+    else staged_rows_fast<MI, FORM_, ACT_, NI, 0>(p, off0, b_first, nw0, l, acc, scr);                      \
+  } while (0)
       if (!p.resid) {
-        if (act_none) staged_rows_fast<MI, 0, false>(p, off0, b_first, nw0, l, acc, scr);
-        else staged_rows_fast<MI, 0, true>(p, off0, b_first, nw0, l, acc, scr);
-      } else if (p.gate) staged_rows_fast<MI, 3, false>(p, off0, b_first, nw0, l, acc, scr);
-      else staged_rows_fast<MI, 1, false>(p, off0, b_first, nw0, l, acc, scr);
-      return;
+        if (act_none) DRAG_FAST(0, false);
+        else DRAG_FAST(0, true);
+      } else if (p.gate) DRAG_FAST(3, false);
+      else DRAG_FAST(1, false);
+#undef DRAG_FAST
+      return true;
     }
   }
   if (m0 + TM <= p.M && n0 + TN <= p.N) {
@@ -454,6 +567,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmKArgs& p, int m0, int 
     staged_rows<MI, TM, true, NI, 0, G0>(p, m0, mw0, n0, nw0, l, acc, scr);
     if constexpr (NI > 4) staged_rows<MI, TM, true, NI, 4, NI - 4>(p, m0, mw0, n0, nw0 + 64, l, acc, scr);
   }
+  return false;
 }
 
 // tile selection shared by both kernels: XCD-contiguous, grouped along M for L2 reuse of the W panel
@@ -761,7 +875,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep(GemmKArgs p) {
   }
 }
 
-#if DRAG_EXP
 // --------------------------------------------------------------------------------------------
 // gemm_bf16_w4 (round 5; EXPERIMENT, DRAG_EXPERIMENTS builds only: "gemm_kernel" = 400 + V) — the 256x256x64 tile as FOUR waves x (128 x 128),
 // one wave per SIMD with the whole register file (256 accumulators in AGPRs): a third less LDS -> register traffic per flop than the
@@ -779,6 +892,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep(GemmKArgs p) {
 typedef __attribute__((ext_vector_type(32))) float f32x32_t;
 typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
 
+#if DRAG_EXP
 template <int V>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4(GemmKArgs p) {
   constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES;
@@ -837,10 +951,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4(GemmKArgs p) {
 #define G4W_INS "{v[128:135]}"(voA), "{v[136:143]}"(voW), "{v[144:151]}"(rd), [rsa] "s"(rsA), [rsw] "s"(rsW), [ldsw] "s"(ldsw)
   if constexpr (V == 1) {          // form D: refill by LDS-DMA
     asm volatile(G4W_D_STAGE0 G4W_FIRST_READS G4W_D_LOOP G4W_D_TAIL : G4W_OUTS : G4W_INS : G4W_CLOBBERS, "scc", "memory");
-  } else if constexpr (V == 2) {   // timing ablations of form R
-    asm volatile(G4W_R_STAGE0 G4W_FIRST_READS G4W_R_LOOP_NOBAR G4W_R_TAIL : G4W_OUTS : G4W_INS, "{v[152:153]}"(wrv) : G4W_CLOBBERS_R, "scc", "memory");
+  } else if constexpr (V == 2) {   // form D2: LDS-DMA, two barriers per K-step, the refill spread from the first barrier on
+    asm volatile(G4W_D_STAGE0 G4W_FIRST_READS G4W_D2_LOOP G4W_D_TAIL : G4W_OUTS : G4W_INS : G4W_CLOBBERS, "scc", "memory");
   } else if constexpr (V == 3) {
-    asm volatile(G4W_R_STAGE0 G4W_FIRST_READS G4W_R_LOOP_NOREFILL G4W_R_TAIL : G4W_OUTS : G4W_INS, "{v[152:153]}"(wrv) : G4W_CLOBBERS_R, "scc", "memory");
+    asm volatile(G4W_D_STAGE0 G4W_FIRST_READS G4W_D2_LOOP_A G4W_D_TAIL : G4W_OUTS : G4W_INS : G4W_CLOBBERS, "scc", "memory");
+  } else if constexpr (V == 4) {
+    asm volatile(G4W_D_STAGE0 G4W_FIRST_READS G4W_D2_LOOP_B G4W_D_TAIL : G4W_OUTS : G4W_INS : G4W_CLOBBERS, "scc", "memory");
+  } else if constexpr (V == 5) {
+    asm volatile(G4W_D_STAGE0 G4W_FIRST_READS G4W_D2_LOOP_C G4W_D_TAIL : G4W_OUTS : G4W_INS : G4W_CLOBBERS, "scc", "memory");
   } else {                         // form R: refill through registers
     asm volatile(G4W_R_STAGE0 G4W_FIRST_READS G4W_R_LOOP G4W_R_TAIL : G4W_OUTS : G4W_INS, "{v[152:153]}"(wrv) : G4W_CLOBBERS_R, "scc", "memory");
   }
@@ -856,13 +974,126 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4(GemmKArgs p) {
   const GemmKArgs pd = dest_of(p, n0);
   if (p.wide) {
     __syncthreads();                              // the slabs alias the stage buffers
-    staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, l, acc, smem + w * 2048);
+    staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, l, acc, smem + w * 4096);
   } else {
     wave_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 128 + (l >> 4) * 4, acc);
   }
 }
 
 #endif
+
+// gemm_bf16_w4p — PRODUCT kernel of the large Linears since round 5: the persistent form of gemm_bf16_w4 (form D2 of the K loop): one workgroup per CU walks tiles b, b + P, ... (all on its
+// XCD); a tile is ONE asm statement (K-steps 0 and 1 already staged, steady loop, a tail whose two K-steps stage K-steps 0 and 1 of the
+// workgroup's next tile), then the C++ epilogue on slabs that do not alias the stage buffers — so the epilogue overlaps the next tile's
+// loads.  K a multiple of 128; batched rows / two destinations / every epilogue form like gemm_bf16_t256<0>; no conv mode, no pair.
+typedef __attribute__((ext_vector_type(16))) uint32_t u32x16_t;
+struct W4Tile {
+  u32x4_t rsA, rsW;
+  u32x16_t vo;      // [0:7] X chunks, [8:15] W chunks
+};
+// vo_in: the offsets of an INTERIOR tile inside one batch of the row map (row * ld, no clamp, no division): the same for every such tile, so
+// only the two descriptors are per-tile work there (scalar); edge tiles and tiles that cross a batch take the general form
+__device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int w, int l, bool valid, const u32x16_t& vo_in, W4Tile& t) {
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  int tm, tn;
+  pick_tile(p, tile, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const long long a0 = p.am.off(m0);
+  const int wrows = min(256, p.N - n0);
+  const unsigned long long pa = (unsigned long long)(uintptr_t)(p.A + a0), pw = (unsigned long long)(uintptr_t)(p.W + (long long)n0 * p.K);
+  const bool interior = m0 + 256 <= p.M && wrows == 256 && m0 / p.am.rpb == (m0 + 255) / p.am.rpb;
+  const long long a_span = interior ? ((long long)255 * p.am.ld + p.K) * 2 : (p.am.off(min(m0 + 255, p.M - 1)) - a0 + p.K) * 2;
+  // no next tile: descriptors with zero records — the tail's loads return zeros without touching memory
+  t.rsA = (u32x4_t){uni((uint32_t)pa), uni((uint32_t)(pa >> 32) & 0xffffu), valid ? uni((uint32_t)a_span) : 0u, 0x00020000u};
+  t.rsW = (u32x4_t){uni((uint32_t)pw), uni((uint32_t)(pw >> 32) & 0xffffu), valid ? uni((uint32_t)((long long)wrows * p.K * 2)) : 0u, 0x00020000u};
+  if (interior) {
+    t.vo = vo_in;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (w * 8 + i) * 8 + (l >> 3);
+    const int slot = (l & 7) ^ ((row >> 1) & 7);
+    const int ra = min(m0 + row, p.M - 1);                 // clamp: rows past the edge are never stored
+    t.vo[i] = (unsigned)((p.am.off(ra) - a0 + slot * 8) * 2);
+    const int rw = min(row, wrows - 1);
+    t.vo[8 + i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
+  constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * STAGE + 4 x 2 epilogue slabs of 2 KiB
+  const int w = wave_id();
+  const int l = lane_id();
+  const int wr = w >> 1, wc = w & 1;
+  const int P = (int)gridDim.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int vb = (int)blockIdx.x;
+  const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
+  const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)w * 8192u));
+  const int p0 = (l >> 4) ^ ((l & 15) >> 1);
+  const int fa = (wr * 128 + (l & 15)) * 128;
+  const int fb = A_BYTES + (wc * 128 + (l & 15)) * 128;
+  u32x8_t rd;      // [buffer][X k-half 0, X k-half 1, W k-half 0, W k-half 1]
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      rd[4 * b + ks] = lds0 + (unsigned)(b * STAGE + fa + ((p0 ^ (ks * 4)) << 4));
+      rd[4 * b + 2 + ks] = lds0 + (unsigned)(b * STAGE + fb + ((p0 ^ (ks * 4)) << 4));
+    }
+  u32x16_t vo_in;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (w * 8 + i) * 8 + (l >> 3);
+    const int slot = (l & 7) ^ ((row >> 1) & 7);
+    vo_in[i] = (unsigned)(((long long)row * p.am.ld + slot * 8) * 2);
+    vo_in[8 + i] = (unsigned)(((long long)row * p.K + slot * 8) * 2);
+  }
+  W4Tile cur, nxt;
+  w4_tile_state(p, vb, w, l, true, vo_in, cur);
+  unsigned soff = 0;
+  // the workgroup's first tile: K-steps 0 and 1 into the two stage buffers (every later tile finds them staged by its predecessor's tail)
+  asm volatile(G4W_D_STAGE0_NOWAIT : [soff] "+s"(soff)
+               : "{v[128:143]}"(cur.vo), [rsa] "s"(cur.rsA), [rsw] "s"(cur.rsW), [ldsw] "s"(ldsw) : "scc", "memory");
+  int stores_behind = 0;
+  for (;;) {
+    const bool have_next = vb + P < nwg;
+    w4_tile_state(p, have_next ? vb + P : vb, w, l, have_next, vo_in, nxt);
+    // K-steps 0 and 1 of this tile landed (this wave's pieces; the statement below opens with the barrier).  Behind an interior tile's fast
+    // epilogue exactly 32 stores are younger than those pieces (VMEM operations of a wave retire in issue order): they may stay in flight
+    if (stores_behind == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x32_t accrow[8];                            // written by the statement (the first K-step's MFMAs start from the constant 0)
+    unsigned n2 = (unsigned)(p.K / 128 - 2);       // pairs of K-steps in the steady loop: all but the first pair and the tail
+    asm volatile(G4W_P_FIRST G4W_P_PAIR0 G4W_P_LOOP G4W_P_TAIL
+                 : "={a[0:31]}"(accrow[0]), "={a[32:63]}"(accrow[1]), "={a[64:95]}"(accrow[2]), "={a[96:127]}"(accrow[3]),
+                   "={a[128:159]}"(accrow[4]), "={a[160:191]}"(accrow[5]), "={a[192:223]}"(accrow[6]), "={a[224:255]}"(accrow[7]),
+                   [n2] "+s"(n2), [soff] "+s"(soff)
+                 : "{v[128:143]}"(cur.vo), "{v[224:239]}"(nxt.vo), "{v[144:151]}"(rd), [rsa] "s"(cur.rsA), [rsw] "s"(cur.rsW),
+                   [rsa2] "s"(nxt.rsA), [rsw2] "s"(nxt.rsW), [ldsw] "s"(ldsw)
+                 : G4W_CLOBBERS, "scc", "memory");
+    f32x4_t acc[8][8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = accrow[mi][4 * ni + r];
+    int tm, tn;
+    pick_tile(p, vb, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const GemmKArgs pd = dest_of(p, n0);
+    bool fast = false;
+    if (pd.wide) fast = staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, l, acc, smem + 2 * STAGE + w * 4096);
+    else wave_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 128 + (l >> 4) * 4, acc);
+    stores_behind = fast ? 32 : 0;
+    if (!have_next) break;
+    cur = nxt;
+    vb += P;
+  }
+}
 
 // --------------------------------------------------------------------------------------------
 // gemm_bf16_t256 — 256x256x64 tile, 8 waves (2 along M x 4 along N), wave tile 128x64 as 8x4
@@ -1272,12 +1503,18 @@ static int gemm_choice(long long M1, long long M2, int N, int K, long long* cost
   const int force = drag_opt(DRAG_OPT_GEMM_KERNEL);
   long long cost = 0;
   int choice;
+  // 3 = gemm_bf16_w4p (round 5): the same 256 x 256 tiles as four waves x (128 x 128) with the hand-placed K loop — same bits, +1...+5 % on
+  // the launches the persistent 8-wave kernel takes (profiles/r05_gemm_w4p_ab*.log) once a launch has at least one tile per CU; one row
+  // segment, K a multiple of 128 ("gemm_w4" = 1: never; "gemm_kernel" = 3 forces it wherever it can run)
+  const bool w4_ok = M2 == 0 && N >= 256 && K >= 256 && K % 128 == 0;
   if (force >= 10) choice = force;
+  else if (force == 3) choice = w4_ok ? 3 : ((N >= 256 && K >= 256) ? 2 : 0);
   else if (force == 2) choice = (N >= 256 && K >= 256) ? 2 : 0;
   else if (force == 1) choice = 0;
   else if (use_t256(M1, M2, N, K)) {
     choice = 2;
     cost = ((tile_rows(M1, M2, 256) * ((N + 255) / 256) + 255) / 256) * (256 + 256);
+    if (w4_ok && drag_opt(DRAG_OPT_GEMM_W4) != 1 && tile_rows(M1, 0, 256) * ((N + 255) / 256) >= 256) choice = 3;
   } else choice = deep_policy(M1, M2, N, K, &cost);
   if (cost_out) *cost_out = cost;
   return choice;
@@ -1298,7 +1535,19 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
     k.tiles_m = (a->M + tm - 1) / tm;
     if (b) { k.seg_tiles_m = k.tiles_m; k.tiles_m += (b->M + tm - 1) / tm; }
   };
-  if (choice == 2) {
+  if (choice == 3) {            // the 4-wave persistent kernel (one segment, K % 128 == 0: gemm_choice)
+    k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
+    constexpr int lds4 = 131072 + 4 * 4096;
+    static unsigned long long ready4 = 0;       // one bit per device: the attribute belongs to the device's copy of the kernel
+    int dev4 = 0;
+    (void)hipGetDevice(&dev4);
+    if (!((ready4 >> (dev4 & 63)) & 1ull)) {
+      DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4p), hipFuncAttributeMaxDynamicSharedMemorySize, lds4) == hipSuccess,
+                 "drag_gemm_bf16: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      ready4 |= 1ull << (dev4 & 63);
+    }
+    hipLaunchKernelGGL(gemm_bf16_w4p, dim3(t256_grid(k.tiles_m * k.tiles_n)), dim3(256), lds4, st_, k);
+  } else if (choice == 2) {
     tiles_of(256); k.tiles_n = (a->N + 255) / 256;
     const dim3 g(t256_grid(k.tiles_m * k.tiles_n));
     if (b) hipLaunchKernelGGL(gemm_bf16_t256_pair, g, dim3(512), 0, st_, k);
@@ -1333,7 +1582,7 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
       const dim3 g4(k.tiles_m * k.tiles_n);
 #define DRAG_W4(V_) case 400 + V_: DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4<V_>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess, "hipFuncSetAttribute"); \
       hipLaunchKernelGGL((gemm_bf16_w4<V_>), g4, dim3(256), 131072, st_, k); break
-      switch (deep) { DRAG_W4(0); DRAG_W4(1); DRAG_W4(2); DRAG_W4(3); default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel 400..403"); }
+      switch (deep) { DRAG_W4(0); DRAG_W4(1); DRAG_W4(2); DRAG_W4(3); DRAG_W4(4); DRAG_W4(5); default: DRAG_CHECK(false, "drag_gemm_bf16: gemm_kernel 400..405"); }
 #undef DRAG_W4
       DRAG_LAUNCH_CHECK();
       return 0;
@@ -1393,7 +1642,8 @@ extern "C" int drag_gemm_bf16_pair_merges(int M1, int M2, int N, int K) {
   const int k2 = gemm_choice(M2, 0, N, K, &c2);
   gemm_choice(M1, M2, N, K, &cm);
   if (cm <= 0) return 0;                           // a forced kernel ("gemm_kernel"): no model
-  return cm < c1 + c2 || (cm == c1 + c2 && (k1 != 2 || k2 != 2));
+  auto persistent = [](int k) { return k == 2 || k == 3; };      // the 8-wave or the 4-wave 256 x 256 kernel
+  return cm < c1 + c2 || (cm == c1 + c2 && (!persistent(k1) || !persistent(k2)));
 }
 
 extern "C" int drag_gemm_bf16_pair(const drag_gemm_args* a, const drag_gemm_args* b, void* stream) {

@@ -22,7 +22,7 @@ import os, re, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # source -> substrings of the kernel names build.py checks in the object it ships
-CHECKED = {"attention.hip": ["attention_q64"], "gemm_bf16.hip": ["gemm_bf16_deep"]}
+CHECKED = {"attention.hip": ["attention_q64"], "gemm_bf16.hip": ["gemm_bf16_deep", "gemm_bf16_w4"]}
 REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
 
 

@@ -47,6 +47,8 @@ class GemmRecorder:
         if conv is True:                                     # the 3x3 convolutions take t256 or t128 only, by their own predicate
             return "gemm_bf16_t256<1>" if _lib.load().drag_conv3x3_bf16_choice(M, N, K // 9) == 2 else "gemm_bf16_t128<1>"
         code = _lib.load().drag_gemm_bf16_choice(M1, M2, N, K)
+        if code == 3:
+            return "gemm_bf16_w4p"
         if code == 2:
             return "gemm_bf16_t256_pair" if M2 > 0 else "gemm_bf16_t256<0>"
         if code == 0:

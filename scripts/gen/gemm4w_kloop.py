@@ -27,11 +27,12 @@ STAGE = 2 * A_BYTES
 G0 = 160
 
 
-def mfma(mi, ni, half):
+def mfma(mi, ni, half, zero=False):
     acc = (8 * mi + ni) * 4
     x = 64 * half + 4 * mi
     w = 64 * half + 32 + 4 * ni
-    return f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{w}:{w + 3}], v[{x}:{x + 3}], a[{acc}:{acc + 3}]"
+    c = "0" if zero else f"a[{acc}:{acc + 3}]"          # the first K-step of a tile starts its accumulators from the inline constant 0
+    return f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{w}:{w + 3}], v[{x}:{x + 3}], {c}"
 
 
 def reads(half, buf):
@@ -47,14 +48,17 @@ def reads(half, buf):
     return out
 
 
-def dmas(buf):
+def dmas(buf, nxt=False):
     """form D: this wave's 16 chunks of one K-step into stage buffer `buf`: m0 = the chunk's LDS address (one instruction between the write
-    of m0 and its use: a wait state the hardware does not interlock), soffset = the K-step's byte offset (%[soff])"""
+    of m0 and its use: a wait state the hardware does not interlock), soffset = the K-step's byte offset (%[soff]).  nxt: the chunks of the
+    NEXT tile of a persistent workgroup (its descriptors %[rsa2] / %[rsw2], its offsets in v[224:239])"""
     out = []
     for i in range(16):
         x = i < 8
+        rs = ('%[rsa2]' if x else '%[rsw2]') if nxt else ('%[rsa]' if x else '%[rsw]')
+        vo = (224 if nxt else 128) + (0 if x else 8) + (i & 7)
         out.append((f"s_add_u32 m0, %[ldsw], {buf * STAGE + (0 if x else A_BYTES) + (i & 7) * 1024}",
-                    f"buffer_load_dwordx4 v{(128 if x else 136) + (i & 7)}, {'%[rsa]' if x else '%[rsw]'}, %[soff] offen lds"))
+                    f"buffer_load_dwordx4 v{vo}, {rs}, %[soff] offen lds"))
     return out
 
 
@@ -106,6 +110,46 @@ def kstep(buf, form, refill=True, request=True, next_reads=True, barrier=True, e
     return t
 
 
+def kstep_d2(buf, refill=True, next_reads=True, b1=36, every=5, reads_every=2, last=None, nxt=False, advance=True, b2=True, zero=False):
+    """form D2: TWO barriers per K-step.  B1 (behind MFMA b1 of k-half 0, once this wave's k-half-1 fragment reads have landed): every wave
+    is done reading this stage buffer, so its refill (LDS-DMA of K-step t + 2) starts there, one piece behind every `every`-th MFMA through
+    the rest of the K-step — a lower request rate and a longer flight than form D's burst inside k-half 1.  B2 (between the k-halves, as
+    before): the pieces of K-step t + 1 have landed everywhere (a COUNTED vmcnt: the pieces of t + 2 issued since B1 stay in flight)."""
+    t = []
+    order = [(mi, ni) for mi in range(8) for ni in range(8)]
+    r1 = reads(1, buf)
+    r0 = reads(0, 1 - buf) if next_reads else []
+    d = dmas(buf, nxt) if refill else []
+    n = 0
+    slots = [b1 + 2 + every * i for i in range(16)]          # global MFMA slots (0..127) behind which piece i goes
+    if last is not None:                                      # ... or spread evenly up to slot `last`
+        slots = [b1 + 2 + round(i * (last - b1 - 2) / 15) for i in range(16)]
+    assert slots[-1] <= 126 and len(set(slots)) == 16, slots
+    for g in range(128):
+        half, j = divmod(g, 64)
+        mi, ni = order[j]
+        if refill and n < 16 and g == slots[n] - 1:
+            t.append(d[n][0])                      # m0 one MFMA ahead
+        t.append(mfma(mi, ni, half, zero and half == 0))
+        if half == 0 and j % reads_every == 0 and j // reads_every < 16:
+            t.append(r1[j // reads_every])
+        if half == 1 and j % 2 == 0 and j // 2 < len(r0):
+            t.append(r0[j // 2])
+        if g == b1:
+            t.append("s_waitcnt lgkmcnt(0)")
+            t.append("s_barrier")
+        if refill and n < 16 and g == slots[n]:
+            t.append(d[n][1]); n += 1
+        if g == 63 and b2:
+            issued = n                              # pieces of t + 2 issued so far stay outstanding
+            t.append(f"s_waitcnt vmcnt({issued})")
+            t.append("s_barrier")
+    if refill and advance:
+        t.append("s_add_u32 %[soff], %[soff], 128")
+    t.append("s_waitcnt lgkmcnt(0)")
+    return t
+
+
 def emit(name, lines):
     print(f"#define {name} \\")
     print(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
@@ -140,5 +184,26 @@ emit("G4W_R_STAGE0", pro)
 emit("G4W_R_LOOP", loop_of("R"))
 emit("G4W_R_TAIL", kstep(0, "R", request=False) + kstep(1, "R", refill=False, next_reads=False))
 # timing ablations of form R (wrong values): no barrier | no refill at all | every chunk from the same, L2-resident K-step
+def d2_loop(**kw):
+    return ["s_cmp_eq_u32 %[n2], 0", "s_cbranch_scc1 L_g4w_tail_%=", "L_g4w_loop_%=:"] + kstep_d2(0, **kw) + kstep_d2(1, **kw) + \
+           ["s_sub_u32 %[n2], %[n2], 1", "s_cmp_lg_u32 %[n2], 0", "s_cbranch_scc1 L_g4w_loop_%=", "L_g4w_tail_%=:"]
+emit("G4W_D2_LOOP", d2_loop())
+emit("G4W_D2_LOOP_A", d2_loop(b1=33, every=6))
+emit("G4W_D2_LOOP_B", d2_loop(b1=22, reads_every=1, last=124))
+emit("G4W_D2_LOOP_C", d2_loop(b1=26, reads_every=1, every=6))
 emit("G4W_R_LOOP_NOBAR", loop_of("R", write=False))            # V2: requests and waits, no LDS writes
 emit("G4W_R_LOOP_NOREFILL", loop_of("R", refill=False))
+
+# ---- the persistent kernel (gemm_bf16_w4p): one asm statement per tile.  K-steps 0 and 1 of the tile are in flight / in LDS when it starts
+# (staged by G4W_D_STAGE0 for the workgroup's first tile, by the previous tile's tail otherwise); the steady loop is form D2 (first barrier
+# behind MFMA 33, a piece behind every 6th MFMA from there); the TAIL's two K-steps refill their stage buffers with K-steps 0 and 1 of the
+# workgroup's NEXT tile (descriptors with zero records when there is none: no traffic), so the epilogue overlaps the next tile's loads.
+BEST = dict(b1=33, every=6)
+# (the wait for the tile's K-steps 0 and 1 is a statement of its own in the kernel: counted when the epilogue before it is the fast one)
+emit("G4W_P_FIRST", ["s_barrier"] + reads(0, 0) + ["s_waitcnt lgkmcnt(0)", "s_movk_i32 %[soff], 256"])
+# the tile's first pair of K-steps (accumulators start from 0 in the first one), then %[n2] more pairs in the loop
+emit("G4W_P_PAIR0", kstep_d2(0, zero=True, **BEST) + kstep_d2(1, **BEST))
+emit("G4W_P_LOOP", d2_loop(**BEST))
+emit("G4W_P_TAIL", ["s_mov_b32 %[soff], 0"] + kstep_d2(0, nxt=True, advance=False, **BEST) +
+     ["s_movk_i32 %[soff], 128"] + kstep_d2(1, nxt=True, advance=False, next_reads=False, b2=False, **BEST))
+emit("G4W_D_STAGE0_NOWAIT", flat(dmas(0)) + ["s_add_u32 %[soff], %[soff], 128"] + flat(dmas(1)))

@@ -14,14 +14,14 @@ def tab(prefix): return [t for t in tabs if t.startswith(prefix)][0]
 pmc, disp, sym, info = tab("rocpd_pmc_event"), tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol"), tab("rocpd_info_pmc")
 q = f"""select d.id, d.start, d.end - d.start, i.name, sum(e.value), count(*)
         from {pmc} e join {disp} d on e.event_id = d.event_id join {sym} s on d.kernel_id = s.id join {info} i on e.pmc_id = i.id
-        where s.kernel_name like '%gemm_bf16_t256%' group by d.id, i.name order by d.start"""
+        where (s.kernel_name like '%gemm_bf16_t256%' or s.kernel_name like '%gemm_bf16_w4p%') group by d.id, i.name order by d.start"""
 launches = {}
 for did, start, ns, name, val, cnt in c.execute(q):
     r = launches.setdefault(did, {"start": start, "ns": ns})
     r[name] = val / cnt if name.startswith("GRBM") else val
 rows = sorted(launches.values(), key=lambda r: r["start"])
 need = sum(p["launches"] for p in plan)
-assert len(rows) == need, f"{len(rows)} dispatches of gemm_bf16_t256 in the database, the plan has {need}"
+assert len(rows) == need, f"{len(rows)} dispatches of gemm_bf16_t256 / gemm_bf16_w4p in the database, the plan has {need}"
 res, k = [], 0
 for p in plan:
     chunk = rows[k + 1:k + p["launches"]]; k += p["launches"]

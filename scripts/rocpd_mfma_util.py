@@ -37,7 +37,7 @@ for db in sys.argv[2:]:
         r["avg_us"][key] = ns / cnt / 1e3
 
 result = {}
-want = ("gemm_bf16_t256", "attention_d128", "attention_q64", "gemm_bf16_t128", "gemm_bf16_deep", "qk_norm_rope", "layernorm_modulate", "conv2d_f32")
+want = ("gemm_bf16_w4p", "gemm_bf16_t256", "attention_d128", "attention_q64", "gemm_bf16_t128", "gemm_bf16_deep", "qk_norm_rope", "layernorm_modulate", "conv2d_f32")
 for k, r in sorted(rows.items(), key=lambda kv: -max(kv[1]["avg_us"].values()) * kv[1]["launches"]):
     if not any(w in k for w in want):
         continue

@@ -790,7 +790,7 @@ def test_gemm_kernels_are_bit_identical(gpu, M, N, K):
         outs.append(y)
         return [o.cpu() for o in outs]
 
-    codes = [1, 42, 43, 22, 23, 24, 13, 14, 113, 123, 133, 143, 0] + ([2] if N >= 256 and K >= 256 else [])      # 1xx: 192-column tiles
+    codes = [1, 42, 43, 22, 23, 24, 13, 14, 113, 123, 133, 143, 0] + ([2, 3] if N >= 256 and K >= 256 else [])      # 1xx: 192-column tiles; 3: the 4-wave persistent kernel (where K % 128 == 0, else the 8-wave one)
     try:
         res = {}
         for code in codes:
@@ -828,7 +828,7 @@ def test_specialised_epilogue_equals_the_general_one(gpu, M, N, K, rpb):
         outs.append(y)
         return [o.cpu() for o in outs]
 
-    codes = [0, 1, 43, 23, 14] + ([2] if N >= 256 and K >= 256 else [])
+    codes = [0, 1, 43, 23, 14] + ([2, 3] if N >= 256 and K >= 256 else [])
     try:
         for code in codes:
             ops.set_option("gemm_kernel", code)
@@ -987,3 +987,42 @@ def test_gemm_w4_experiment_is_bit_identical(gpu, M, N, K):
         finally:
             ops.set_option("gemm_kernel", 0)
         assert torch.equal(got, ref) and torch.equal(got2, ref2), kern
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (2500, 1100, 1024), (5337 * 2, 3072, 384), (4100, 768, 128 * 7), (70000, 512, 256)])
+def test_gemm_w4p_equals_the_8_wave_kernel(gpu, M, N, K):
+    """round 5: gemm_bf16_w4p (4 waves x 128 x 128, the hand-placed K loop generated by scripts/gen/gemm4w_kloop.py; "gemm_kernel" = 3, the policy's
+    choice for launches of >= 256 tiles with K % 128 == 0) against the persistent 8-wave kernel ("gemm_kernel" = 2): same MFMA chain per
+    output element, same epilogues -> same bits.  One tile, ragged M and N edges, tiles that cross a batch of the row map, an odd number of
+    K-step pairs, more tiles than one round (the persistent walk, the next-tile prefetch of the tail), two destinations, f32 output,
+    the narrow epilogue, gate + residual in place"""
+    from domain_rag_amd import ops
+    a, w, b = _randn((M, K), 41).to(gpu), _randn((N, K), 42, 0.05).to(gpu), _randn((N,), 43).to(gpu)
+    rpb = M // 2 if M % 2 == 0 else M
+    gate, resid = _randn((M // rpb, N), 44).to(gpu), _randn((M, N), 45).to(gpu)
+
+    def run_all():
+        outs = [ops.gemm(a, w), ops.gemm(a, w, bias=b, act=ops.ACT_GELU_TANH), ops.gemm(a, w, bias=b, act=ops.ACT_SILU, act_n0=(N // 2) // 256 * 256),
+                ops.gemm(a, w, out_f32=True)]
+        x = resid.clone()
+        ops.gemm(a, w, out=x, bias=b, M=M, lda=K, ldc=N, c_rows_per_batch=rpb, c_batch_stride=rpb * N, gate=gate, resid=x, ldg=N)
+        outs.append(x)
+        y = torch.zeros((M, N + 4), dtype=torch.bfloat16, device=gpu)        # ldc % 8 != 0: fragment epilogue
+        ops.gemm(a, w, out=y, bias=b, M=M, lda=K, ldc=N + 4)
+        outs.append(y)
+        if N >= 512:
+            n1 = 256
+            o1 = torch.full((M, n1 + 8), 7.0, dtype=torch.bfloat16, device=gpu); o2 = torch.full((M, N - n1), 7.0, dtype=torch.bfloat16, device=gpu)
+            ops.gemm(a, w, out=o1, bias=b, M=M, lda=K, ldc=n1 + 8, out2=o2, ldc2=N - n1, n_split=n1)
+            outs += [o1, o2]
+        return [o.cpu() for o in outs]
+
+    from domain_rag_amd import _lib
+    assert _lib.load().drag_gemm_bf16_choice(70000, 0, 512, 256) == 3 and _lib.load().drag_gemm_bf16_choice(2500, 0, 1100, 1024) != 3
+    try:
+        ops.set_option("gemm_kernel", 2); ref = run_all()
+        ops.set_option("gemm_kernel", 3); got = run_all()
+    finally:
+        ops.set_option("gemm_kernel", 0)
+    for i, (x, y) in enumerate(zip(ref, got)):
+        assert torch.isfinite(x.float()).all() and torch.equal(x, y), i
