@@ -433,8 +433,13 @@ __device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long o
 // The same for a wave tile of EIGHT column blocks (the 4-wave kernel's 128 x 128): two column groups through two slabs, software-pipelined by
 // hand — with one wave per SIMD nothing else covers the LDS round trip of a pass, so the slab writes of the next row block are issued
 // between a group's slab reads and its stores.  Operation for operation the arithmetic of staged_rows_fast (same bits).
-template <int MI, int FORM, bool ACT>
-__device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long off0, int bidx, int nw0, int l, f32x4_t (*acc)[8], char* scr) {
+// EDGE: the wave's rows may end before 128 (a ragged M edge: rows >= rows_valid are neither loaded nor stored) and may cross ONE batch
+// boundary of the output's row map (rows >= split belong to the next batch: base `off1 + row * ld` and the next batch's gate vector) — the
+// DiT's text stream is 8 batches of 1241 rows, its joint stream 8 of 5337: tiles that straddle a batch are the rule there.  Same
+// arithmetic; the interior form carries none of it.
+template <int MI, int FORM, bool ACT, bool EDGE = false>
+__device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long off0, int bidx, int nw0, int l, f32x4_t (*acc)[8], char* scr,
+                                                  int rows_valid = 1 << 30, int split = 1 << 30, long long off1 = 0) {
   const int q = l >> 4, r16 = l & 15;
   const int c = l & 7, rl = l >> 3;
   const ActCoef ac = act_coef(p.act);
@@ -455,16 +460,16 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
     woff[ni] = r16 * 128 + (((2 * ni + (q >> 1)) ^ (r16 & 7)) << 4) + (((q & 1) ^ (r16 >> 3)) << 3);
   const int roff = rl * 128 + ((c ^ rl) << 4);
   const int n = nw0 + c * 8;
-  float g[2][8];
+  u32x4_t gq[2][2];                // gate words [batch side][group] (EDGE: both sides of the batch boundary)
   if constexpr (FORM == 3) {
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
-      const u32x4_t gg = *(const u32x4_t*)(p.gate + (long long)bidx * p.ldg + n + 64 * grp);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { g[grp][2 * i] = bf_lo(gg[i]); g[grp][2 * i + 1] = bf_hi(gg[i]); }
+      gq[0][grp] = *(const u32x4_t*)(p.gate + (long long)bidx * p.ldg + n + 64 * grp);
+      if constexpr (EDGE) gq[1][grp] = split < rows_valid && split < 128 ? *(const u32x4_t*)(p.gate + (long long)(bidx + 1) * p.ldg + n + 64 * grp) : gq[0][grp];
     }
   }
   const unsigned lane_off = (unsigned)(rl * p.cm.ld + n);
+  const long long d01 = off1 - off0;         // EDGE: what a row past the boundary adds to its address
   bf16_t* const Cb = (bf16_t*)p.C + off0;
   const bf16_t* const Rb = FORM ? p.resid + off0 : nullptr;
   constexpr int RD = 2;
@@ -473,7 +478,15 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) rres[mi2 % RD][grp][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp);
+      for (int j = 0; j < 2; ++j) {
+        const int r = mi2 * 16 + j * 8 + rl;
+        if constexpr (EDGE) {
+          rres[mi2 % RD][grp][j] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (r < rows_valid) rres[mi2 % RD][grp][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp + (r >= split ? d01 : 0ll));
+        } else {
+          rres[mi2 % RD][grp][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp);
+        }
+      }
   };
   auto write_slab = [&](int mi, int grp) {
 #pragma unroll
@@ -515,18 +528,25 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
       if (mi + 1 < MI) write_slab(mi + 1, grp);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        const int r = mi * 16 + j * 8 + rl;
         if constexpr (FORM != 0) {
           const u32x4_t x = rres[mi % RD][grp][j];
           if constexpr (FORM == 3) {
+            u32x4_t gw = gq[0][grp];
+            if constexpr (EDGE) gw = r >= split ? gq[1][grp] : gq[0][grp];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              y[j][i] = pack2bf(bf_lo(x[i]) + rbf(g[grp][2 * i] * bf_lo(y[j][i])), bf_hi(x[i]) + rbf(g[grp][2 * i + 1] * bf_hi(y[j][i])));
+              y[j][i] = pack2bf(bf_lo(x[i]) + rbf(bf_lo(gw[i]) * bf_lo(y[j][i])), bf_hi(x[i]) + rbf(bf_hi(gw[i]) * bf_hi(y[j][i])));
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[j][i] = pack2bf(bf_lo(x[i]) + bf_lo(y[j][i]), bf_hi(x[i]) + bf_hi(y[j][i]));
           }
         }
-        *(u32x4_t*)(Cb + (long long)(mi * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp) = y[j];
+        if constexpr (EDGE) {
+          if (r < rows_valid) *(u32x4_t*)(Cb + (long long)(mi * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp + (r >= split ? d01 : 0ll)) = y[j];
+        } else {
+          *(u32x4_t*)(Cb + (long long)(mi * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp) = y[j];
+        }
       }
     }
     if constexpr (FORM != 0) {
@@ -558,6 +578,26 @@ __device__ __forceinline__ bool staged_epilogue(const GemmKArgs& p, int m0, int 
       else DRAG_FAST(1, false);
 #undef DRAG_FAST
       return true;
+    }
+    if constexpr (NI == 8) {
+      // full columns, but a ragged M edge and / or ONE batch boundary of the row map inside the tile (batches of >= 256 rows): the
+      // straight-line form with a row predicate and a per-row choice between the two batches' bases / gate vectors
+      const bool edge = n0 + TN <= p.N && p.cm.rpb >= TM && (long long)8 * p.cm.ld + p.N < (1ll << 31) && (long long)(p.M / p.cm.rpb + 1) * p.ldg < (1ll << 31);
+      if (edge && !p.epi_generic && (act_none || (act_all && !p.resid)) && !(p.gate && !p.resid)) {
+        const int rows_valid = p.M - mw0;
+        if (rows_valid > 0) {
+          const int bA = mw0 / p.cm.rpb;                              // the batch of the wave's first row
+          const int split = (bA + 1) * p.cm.rpb - mw0;                 // local row where the next batch starts (>= 128: not in this wave)
+          const long long off0 = p.cm.off(mw0);
+          const long long off1 = split < 128 && mw0 + split < p.M ? p.cm.off(mw0 + split) - (long long)split * p.cm.ld : off0;
+          if (!p.resid) {
+            if (act_none) staged_rows_fast8<MI, 0, false, true>(p, off0, bA, nw0, l, acc, scr, rows_valid, split, off1);
+            else staged_rows_fast8<MI, 0, true, true>(p, off0, bA, nw0, l, acc, scr, rows_valid, split, off1);
+          } else if (p.gate) staged_rows_fast8<MI, 3, false, true>(p, off0, bA, nw0, l, acc, scr, rows_valid, split, off1);
+          else staged_rows_fast8<MI, 1, false, true>(p, off0, bA, nw0, l, acc, scr, rows_valid, split, off1);
+        }
+        return m0 + TM <= p.M;          // every row stored: 32 stores per wave, as in the interior form
+      }
     }
   }
   if (m0 + TM <= p.M && n0 + TN <= p.N) {
