@@ -469,9 +469,22 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
     }
   }
   const unsigned lane_off = (unsigned)(rl * p.cm.ld + n);
-  const long long d01 = off1 - off0;         // EDGE: what a row past the boundary adds to its address
+  const long long d01 = off1 - off0;         // EDGE: what a row past the boundary adds to its address (elements; >= 0: batches ascend)
   bf16_t* const Cb = (bf16_t*)p.C + off0;
   const bf16_t* const Rb = FORM ? p.resid + off0 : nullptr;
+  // EDGE: the row predicate is the DESCRIPTOR's bound, not a branch (64 predicated loads / stores split the straight-line code into as
+  // many basic blocks with spills between them: the first version ran as slowly as the general epilogue): accesses at or past the first
+  // invalid row's byte offset are dropped / return zero by the load-store unit
+  __amdgpu_buffer_rsrc_t rsC, rsR;
+  unsigned d01b = 0;
+  if constexpr (EDGE) {
+    // (the bound is the first invalid row's FIRST byte in this wave's column range: a destination whose base is shifted — the second
+    //  buffer of a two-destination launch is addressed from C2 - n_split — has valid columns beyond row_start + ld)
+    const long long end = rows_valid >= 128 ? (1ll << 31) - 16 : ((long long)rows_valid * p.cm.ld + nw0 + (rows_valid > split ? d01 : 0ll)) * 2;
+    rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cb, 0, (unsigned)end, 0x00020000);
+    rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(FORM ? Rb : (const bf16_t*)Cb), 0, (unsigned)end, 0x00020000);
+    d01b = (unsigned)(d01 * 2);
+  }
   constexpr int RD = 2;
   u32x4_t rres[RD][2][2];          // [ring][group][j]
   auto load_resid = [&](int mi2) {
@@ -481,8 +494,8 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
       for (int j = 0; j < 2; ++j) {
         const int r = mi2 * 16 + j * 8 + rl;
         if constexpr (EDGE) {
-          rres[mi2 % RD][grp][j] = (u32x4_t){0u, 0u, 0u, 0u};
-          if (r < rows_valid) rres[mi2 % RD][grp][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp + (r >= split ? d01 : 0ll));
+          const unsigned vo = (unsigned)(((mi2 * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp) * 2) + (r >= split ? d01b : 0u);
+          rres[mi2 % RD][grp][j] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)vo, 0, 0);
         } else {
           rres[mi2 % RD][grp][j] = *(const u32x4_t*)(Rb + (long long)(mi2 * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp);
         }
@@ -543,7 +556,8 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
           }
         }
         if constexpr (EDGE) {
-          if (r < rows_valid) *(u32x4_t*)(Cb + (long long)(mi * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp + (r >= split ? d01 : 0ll)) = y[j];
+          const unsigned vo = (unsigned)(((mi * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp) * 2) + (r >= split ? d01b : 0u);
+          __builtin_amdgcn_raw_buffer_store_b128(y[j], rsC, (int)vo, 0, 0);
         } else {
           *(u32x4_t*)(Cb + (long long)(mi * 16 + j * 8) * p.cm.ld + lane_off + 64 * grp) = y[j];
         }
@@ -582,7 +596,8 @@ __device__ __forceinline__ bool staged_epilogue(const GemmKArgs& p, int m0, int 
     if constexpr (NI == 8) {
       // full columns, but a ragged M edge and / or ONE batch boundary of the row map inside the tile (batches of >= 256 rows): the
       // straight-line form with a row predicate and a per-row choice between the two batches' bases / gate vectors
-      const bool edge = n0 + TN <= p.N && p.cm.rpb >= TM && (long long)8 * p.cm.ld + p.N < (1ll << 31) && (long long)(p.M / p.cm.rpb + 1) * p.ldg < (1ll << 31);
+      const long long jump = p.cm.rpb < p.M ? p.cm.bs - (long long)p.cm.rpb * p.cm.ld : 0;      // what crossing a batch adds to a row's offset
+      const bool edge = n0 + TN <= p.N && p.cm.rpb >= TM && p.cm.ld >= TN / 2 && jump >= 0 && ((long long)(TM / 2 + 8) * p.cm.ld + p.N + jump) * 2 < (1ll << 31) - 16;
       if (edge && !p.epi_generic && (act_none || (act_all && !p.resid)) && !(p.gate && !p.resid)) {
         const int rows_valid = p.M - mw0;
         if (rows_valid > 0) {
