@@ -1592,6 +1592,9 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
   };
   if (choice == 3) {            // the 4-wave persistent kernel (one segment, K % 128 == 0: gemm_choice)
     k.tiles_m = (a->M + 255) / 256; k.tiles_n = (a->N + 255) / 256;
+    // its own tile walk (profiles/r05_gemm_w4p_group_m.log, interleaved, TFLOP/s at g = 2 | 4 | 8): (42 696, 21 504, 3072) 1468 | 1449 | 1419,
+    // (32 768, 9216, 3072) 1473 | 1497 | 1481, (32 768, 3072, 12 288) 1520 | 1528 | 1513, (32 768, 3072, 3072) 1456 | 1423 | 1451
+    if (drag_opt(DRAG_OPT_GEMM_GROUP_M) <= 0) k.group_m = a->N >= 16384 ? 2 : (a->N <= 3072 && a->K < 8192 ? 8 : 4);
     constexpr int lds4 = 131072 + 4 * 4096;
     static unsigned long long ready4 = 0;       // one bit per device: the attribute belongs to the device's copy of the kernel
     int dev4 = 0;
