@@ -1559,7 +1559,7 @@ static int gemm_choice(long long M1, long long M2, int N, int K, long long* cost
   long long cost = 0;
   int choice;
   // 3 = gemm_bf16_w4p (round 5): the same 256 x 256 tiles as four waves x (128 x 128) with the hand-placed K loop — same bits, +1...+5 % on
-  // the launches the persistent 8-wave kernel takes (profiles/r05_gemm_w4p_ab*.log) once a launch has at least one tile per CU; one row
+  // the launches the persistent 8-wave kernel takes (profiles/r05_gemm_w4p_*.log) once a launch has enough tiles (below); one row
   // segment, K a multiple of 128 ("gemm_w4" = 1: never; "gemm_kernel" = 3 forces it wherever it can run)
   const bool w4_ok = M2 == 0 && N >= 256 && K >= 256 && K % 128 == 0;
   if (force >= 10) choice = force;
@@ -1569,7 +1569,10 @@ static int gemm_choice(long long M1, long long M2, int N, int K, long long* cost
   else if (use_t256(M1, M2, N, K)) {
     choice = 2;
     cost = ((tile_rows(M1, M2, 256) * ((N + 255) / 256) + 255) / 256) * (256 + 256);
-    if (w4_ok && drag_opt(DRAG_OPT_GEMM_W4) != 1 && tile_rows(M1, 0, 256) * ((N + 255) / 256) >= 256) choice = 3;
+    // its fixed cost per tile is 7 us against 4.5 and its first tile starts cold: three rounds of tiles, or one with long K loops, amortise
+    // that (configs[1]'s two-round (1536, 21 504, 3072) launch lost 2 %: profiles/r05_gemm_w4p_fixed_cost.log)
+    const long long tiles4 = tile_rows(M1, 0, 256) * ((N + 255) / 256);
+    if (w4_ok && drag_opt(DRAG_OPT_GEMM_W4) != 1 && tiles4 >= 256 && (K >= 8192 || tiles4 >= 768)) choice = 3;
   } else choice = deep_policy(M1, M2, N, K, &cost);
   if (cost_out) *cost_out = cost;
   return choice;

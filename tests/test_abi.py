@@ -76,7 +76,8 @@ def test_gemm_tile_policy_is_a_function_of_the_launch_shape(built_lib):
     the property the batch-invariance tests rest on (the policy never looks at data, only at M, N, K)"""
     c = built_lib.drag_gemm_bf16_choice
     assert c(42696, 0, 9216, 3072) == 3 and c(42696, 0, 3072, 15360) == 3          # the headline's Linears: persistent 256x256, the 4-wave kernel (round 5)
-    assert c(42696, 0, 9216, 3072 + 64) == 2 and c(9928, 0, 3072, 3072) == 3       # an odd number of K-steps: the 8-wave kernel; the text stream (468 tiles)
+    assert c(42696, 0, 9216, 3072 + 64) == 2 and c(9928, 0, 9216, 3072) == 3       # an odd number of K-steps: the 8-wave kernel; the text stream (1404 tiles)
+    assert c(9928, 0, 3072, 3072) == 2 and c(9928, 0, 3072, 12288) == 3 and c(1536, 0, 21504, 3072) == 2   # 468 tiles: only with long K loops; configs[1]'s 504 tiles: 8 waves
     assert c(1536, 0, 3072, 15360) == 133                                           # one exact round of 96x192 tiles (configs[1])
     assert c(1536, 0, 12288, 3072) == 2 and c(512, 0, 12288, 3072) == 143           # 288 256x256 tiles beat 1536 96x128 | one exact round of 128x192
     assert c(512, 0, 3072, 3072) == 24 and c(1024, 0, 3072, 3072) == 43 and c(729, 0, 4096, 1152) == 33   # one round of 64x128 | 128x128 | 96x128 ring tiles

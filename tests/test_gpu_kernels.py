@@ -1018,7 +1018,7 @@ def test_gemm_w4p_equals_the_8_wave_kernel(gpu, M, N, K):
         return [o.cpu() for o in outs]
 
     from domain_rag_amd import _lib
-    assert _lib.load().drag_gemm_bf16_choice(70000, 0, 512, 256) == 3 and _lib.load().drag_gemm_bf16_choice(2500, 0, 1100, 1024) != 3
+    assert _lib.load().drag_gemm_bf16_choice(70000, 0, 1024, 256) == 3 and _lib.load().drag_gemm_bf16_choice(2500, 0, 1100, 1024) != 3
     try:
         ops.set_option("gemm_kernel", 2); ref = run_all()
         ops.set_option("gemm_kernel", 3); got = run_all()
