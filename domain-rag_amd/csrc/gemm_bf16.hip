@@ -1076,6 +1076,17 @@ __device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int 
   }
 }
 
+#if DRAG_EXP
+// experiment builds: shader-clock stamps of workgroup 0 / wave 0 around the pieces of a tile (drag_debug_w4_stamps copies them out)
+__device__ unsigned long long g_w4_stamps[8 * 64];
+#define W4_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (blockIdx.x == 0 && w == 0 && l == 0 && tile_no < 64) g_w4_stamps[tile_no * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define W4_STAMP(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
   constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * STAGE + 4 x 2 epilogue slabs of 2 KiB
@@ -1113,13 +1124,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
   asm volatile(G4W_D_STAGE0_NOWAIT : [soff] "+s"(soff)
                : "{v[128:143]}"(cur.vo), [rsa] "s"(cur.rsA), [rsw] "s"(cur.rsW), [ldsw] "s"(ldsw) : "scc", "memory");
   int stores_behind = 0;
+  [[maybe_unused]] int tile_no = 0;
   for (;;) {
+    W4_STAMP(0);
     const bool have_next = vb + P < nwg;
     w4_tile_state(p, have_next ? vb + P : vb, w, l, have_next, vo_in, nxt);
+    W4_STAMP(1);
     // K-steps 0 and 1 of this tile landed (this wave's pieces; the statement below opens with the barrier).  Behind an interior tile's fast
     // epilogue exactly 32 stores are younger than those pieces (VMEM operations of a wave retire in issue order): they may stay in flight
     if (stores_behind == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4_STAMP(2);
     f32x32_t accrow[8];                            // written by the statement (the first K-step's MFMAs start from the constant 0)
     unsigned n2 = (unsigned)(p.K / 128 - 2);       // pairs of K-steps in the steady loop: all but the first pair and the tail
     asm volatile(G4W_P_FIRST G4W_P_PAIR0 G4W_P_LOOP G4W_P_TAIL
@@ -1129,6 +1144,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
                  : "{v[128:143]}"(cur.vo), "{v[224:239]}"(nxt.vo), "{v[144:151]}"(rd), [rsa] "s"(cur.rsA), [rsw] "s"(cur.rsW),
                    [rsa2] "s"(nxt.rsA), [rsw2] "s"(nxt.rsW), [ldsw] "s"(ldsw)
                  : G4W_CLOBBERS, "scc", "memory");
+    W4_STAMP(3);
     f32x4_t acc[8][8];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
@@ -1144,6 +1160,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
     if (pd.wide) fast = staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, l, acc, smem + 2 * STAGE + w * 4096);
     else wave_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 128 + (l >> 4) * 4, acc);
     stores_behind = fast ? 32 : 0;
+    W4_STAMP(4);
+    ++tile_no;
     if (!have_next) break;
     cur = nxt;
     vb += P;
@@ -1670,6 +1688,11 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
 }
 
 extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) { return gemm_launch(a, nullptr, stream); }
+#if DRAG_EXP
+extern "C" int drag_debug_w4_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w4_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // which kernel a launch over M1 (+ M2: a merged pair) rows takes: 2 = the persistent 256x256 kernel, 0 = t128, else
 // 100 * (192-column tiles) + 10 * MI + ST of gemm_bf16_deep<MI, ST, NI> — for callers that account launches per kernel
