@@ -1046,9 +1046,9 @@ struct W4Tile {
   u32x4_t rsA, rsW;
   u32x16_t vo;      // [0:7] X chunks, [8:15] W chunks
 };
-// vo_in: the offsets of an INTERIOR tile inside one batch of the row map (row * ld, no clamp, no division): the same for every such tile, so
-// only the two descriptors are per-tile work there (scalar); edge tiles and tiles that cross a batch take the general form
-__device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int w, int l, bool valid, const u32x16_t& vo_in, W4Tile& t) {
+// An INTERIOR tile inside one batch of the row map has offsets row * ld (no clamp, no division); edge tiles and tiles that cross a batch
+// take the general form
+__device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int w, int l, bool valid, W4Tile& t) {
   auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   int tm, tn;
   pick_tile(p, tile, tm, tn);
@@ -1062,7 +1062,13 @@ __device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int 
   t.rsA = (u32x4_t){uni((uint32_t)pa), uni((uint32_t)(pa >> 32) & 0xffffu), valid ? uni((uint32_t)a_span) : 0u, 0x00020000u};
   t.rsW = (u32x4_t){uni((uint32_t)pw), uni((uint32_t)(pw >> 32) & 0xffffu), valid ? uni((uint32_t)((long long)wrows * p.K * 2)) : 0u, 0x00020000u};
   if (interior) {
-    t.vo = vo_in;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (w * 8 + i) * 8 + (l >> 3);
+      const int slot = (l & 7) ^ ((row >> 1) & 7);
+      t.vo[i] = (unsigned)((row * p.am.ld + slot * 8) * 2);
+      t.vo[8 + i] = (unsigned)((row * p.K + slot * 8) * 2);
+    }
     return;
   }
 #pragma unroll
@@ -1098,27 +1104,34 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
   int vb = (int)blockIdx.x;
   const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
   const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)w * 8192u));
-  const int p0 = (l >> 4) ^ ((l & 15) >> 1);
-  const int fa = (wr * 128 + (l & 15)) * 128;
-  const int fb = A_BYTES + (wc * 128 + (l & 15)) * 128;
-  u32x8_t rd;      // [buffer][X k-half 0, X k-half 1, W k-half 0, W k-half 1]
+  // Per-lane constants are RECOMPUTED from a laundered lane id in every tile (a handful of VALU instructions): hoisted out of the tile loop
+  // they are live across the K loop's statement, which leaves the compiler 88 free VGPRs (v0-v127 clobbered, v128-v151 / v224-v239 bound) —
+  // it spilled them to scratch, and every reload is an s_waitcnt vmcnt(0) that drains the previous epilogue's 32 stores before the next K
+  // loop may start (stamps: 2800 cycles of "tile state" per tile, all of it that wait)
+  auto lane_now = [&]() { int v = l; asm volatile("" : "+v"(v)); return v; };
+  // the same for the divisors of the tile walk and the row maps: the reciprocals of wave-uniform divisions are computed by the VALU, and
+  // hoisted they sit in VGPRs across the statement
+  auto args_now = [&]() {
+    GemmKArgs q = p;
+    asm volatile("" : "+s"(q.tiles_n), "+s"(q.tiles_m), "+s"(q.group_m), "+s"(q.am.rpb), "+s"(q.cm.rpb), "+s"(q.M), "+s"(q.K), "+s"(q.am.ld), "+s"(q.cm.ld));
+    return q;
+  };
+  auto read_addrs = [&](int lv) {      // [buffer][X k-half 0, X k-half 1, W k-half 0, W k-half 1]
+    const int p0 = (lv >> 4) ^ ((lv & 15) >> 1);
+    const int fa = (wr * 128 + (lv & 15)) * 128;
+    const int fb = A_BYTES + (wc * 128 + (lv & 15)) * 128;
+    u32x8_t rd;
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      rd[4 * b + ks] = lds0 + (unsigned)(b * STAGE + fa + ((p0 ^ (ks * 4)) << 4));
-      rd[4 * b + 2 + ks] = lds0 + (unsigned)(b * STAGE + fb + ((p0 ^ (ks * 4)) << 4));
-    }
-  u32x16_t vo_in;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = (w * 8 + i) * 8 + (l >> 3);
-    const int slot = (l & 7) ^ ((row >> 1) & 7);
-    vo_in[i] = (unsigned)(((long long)row * p.am.ld + slot * 8) * 2);
-    vo_in[8 + i] = (unsigned)(((long long)row * p.K + slot * 8) * 2);
-  }
+      for (int ks = 0; ks < 2; ++ks) {
+        rd[4 * b + ks] = lds0 + (unsigned)(b * STAGE + fa + ((p0 ^ (ks * 4)) << 4));
+        rd[4 * b + 2 + ks] = lds0 + (unsigned)(b * STAGE + fb + ((p0 ^ (ks * 4)) << 4));
+      }
+    return rd;
+  };
   W4Tile cur, nxt;
-  w4_tile_state(p, vb, w, l, true, vo_in, cur);
+  w4_tile_state(p, vb, w, lane_now(), true, cur);
   unsigned soff = 0;
   // the workgroup's first tile: K-steps 0 and 1 into the two stage buffers (every later tile finds them staged by its predecessor's tail)
   asm volatile(G4W_D_STAGE0_NOWAIT : [soff] "+s"(soff)
@@ -1128,7 +1141,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
   for (;;) {
     W4_STAMP(0);
     const bool have_next = vb + P < nwg;
-    w4_tile_state(p, have_next ? vb + P : vb, w, l, have_next, vo_in, nxt);
+    const int lt = lane_now();
+    w4_tile_state(args_now(), have_next ? vb + P : vb, w, lt, have_next, nxt);
+    const u32x8_t rd = read_addrs(lt);
     W4_STAMP(1);
     // K-steps 0 and 1 of this tile landed (this wave's pieces; the statement below opens with the barrier).  Behind an interior tile's fast
     // epilogue exactly 32 stores are younger than those pieces (VMEM operations of a wave retire in issue order): they may stay in flight
@@ -1145,6 +1160,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
                    [rsa2] "s"(nxt.rsA), [rsw2] "s"(nxt.rsW), [ldsw] "s"(ldsw)
                  : G4W_CLOBBERS, "scc", "memory");
     W4_STAMP(3);
+    const int le = lane_now();
     f32x4_t acc[8][8];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
@@ -1153,12 +1169,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mi][ni][r] = accrow[mi][4 * ni + r];
     int tm, tn;
-    pick_tile(p, vb, tm, tn);
+    const GemmKArgs pe = args_now();
+    pick_tile(pe, vb, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
-    const GemmKArgs pd = dest_of(p, n0);
+    const GemmKArgs pd = dest_of(pe, n0);
     bool fast = false;
-    if (pd.wide) fast = staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, l, acc, smem + 2 * STAGE + w * 4096);
-    else wave_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128 + (l & 15), n0, n0 + wc * 128 + (l >> 4) * 4, acc);
+    if (pd.wide) fast = staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, le, acc, smem + 2 * STAGE + w * 4096);
+    else wave_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128 + (le & 15), n0, n0 + wc * 128 + (le >> 4) * 4, acc);
     stores_behind = fast ? 32 : 0;
     W4_STAMP(4);
     ++tile_no;
