@@ -141,6 +141,28 @@ __device__ __forceinline__ ActCoef act_coef(int act) {
   }
 }
 
+// The activation of four consecutive columns, two values per instruction: the operations of  x * fast_sigmoid(x * (c0 + c1 x x))  in the
+// scalar order — (c1 x), fma(.., x, c0), x *, * (-log2 e), 2^, 1 +, 1 /, x * — so the bits are those of the scalar body; the six
+// non-transcendental ones become v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (the compiler's own vectoriser stops at the v_exp / v_rcp
+// pair: 7.5 instructions per value, 5 here; the GELU epilogue of a 256 x 256 tile was 3200 instructions per wave, a tenth of the K = 3072 tile)
+__device__ __forceinline__ void act4(float* v, ActCoef ac) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // torch: y = linear(x) is a bf16 tensor before the activation reads it
+    const f32x2_t x = {rbf(v[2 * h]), rbf(v[2 * h + 1])};
+    const f32x2_t m1 = ac.c1 * x;
+    const f32x2_t t = __builtin_elementwise_fma(m1, x, (f32x2_t){ac.c0, ac.c0});
+    const f32x2_t z = x * t;
+    const f32x2_t a = -1.4426950408889634f * z;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2_t d = 1.0f + e;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2_t y = x * r;
+    v[2 * h] = y[0];
+    v[2 * h + 1] = y[1];
+  }
+}
+
 // epilogue of one accumulator row-group: NI groups of 4 consecutive columns of ONE output row.
 // CHECK = false is the interior-tile fast path (no bounds tests, residual loads issued up front).
 template <int NI, bool CHECK>
@@ -161,12 +183,7 @@ __device__ __forceinline__ void epi_row(const GemmKArgs& p, long long coff, int 
     if (CHECK && n >= p.N) continue;
     float v[4] = {a[ni][0] + c[ni].b[0], a[ni][1] + c[ni].b[1], a[ni][2] + c[ni].b[2], a[ni][3] + c[ni].b[3]};
     if (p.act != DRAG_ACT_NONE && n >= p.act_n0) {
-      // torch: y = linear(x) is a bf16 tensor before the activation reads it
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x = rbf(v[r]);
-        v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
-      }
+      act4(v, ac);
     }
     if (p.gate) {
       // diffusers computes  x = x + gate * y  with y, gate, x bf16 tensors: y is rounded to
@@ -301,12 +318,7 @@ __device__ __forceinline__ void staged_rows(const GemmKArgs& p, int m0, int mw0,
       float v[4] = {acc[mi][NI0 + ni][0] + bias[ni][0], acc[mi][NI0 + ni][1] + bias[ni][1], acc[mi][NI0 + ni][2] + bias[ni][2],
                     acc[mi][NI0 + ni][3] + bias[ni][3]};
       if (actv[ni]) {
-        // torch: y = linear(x) is a bf16 tensor before the activation reads it
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = rbf(v[r]);
-          v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
-        }
+        act4(v, ac);
       }
       u32x2_t o;
       o[0] = pack2bf(v[0], v[1]);
@@ -396,11 +408,7 @@ __device__ __forceinline__ void staged_rows_fast(const GemmKArgs& p, long long o
       float v[4] = {acc[mi][NI0 + ni][0] + bias[ni][0], acc[mi][NI0 + ni][1] + bias[ni][1], acc[mi][NI0 + ni][2] + bias[ni][2],
                     acc[mi][NI0 + ni][3] + bias[ni][3]};
       if constexpr (ACT) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = rbf(v[r]);
-          v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
-        }
+        act4(v, ac);
       }
       u32x2_t o;
       o[0] = pack2bf(v[0], v[1]);
@@ -501,23 +509,26 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
         }
       }
   };
-  auto write_slab = [&](int mi, int grp) {
+  auto slab_values = [&](int mi, int grp, u32x2_t* o) {      // the arithmetic of one slab (registers only)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       float v[4] = {acc[mi][4 * grp + ni][0] + bias[grp][ni][0], acc[mi][4 * grp + ni][1] + bias[grp][ni][1],
                     acc[mi][4 * grp + ni][2] + bias[grp][ni][2], acc[mi][4 * grp + ni][3] + bias[grp][ni][3]};
       if constexpr (ACT) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = rbf(v[r]);
-          v[r] = x * fast_sigmoid(x * (ac.c0 + ac.c1 * x * x));
-        }
+        act4(v, ac);
       }
-      u32x2_t o;
-      o[0] = pack2bf(v[0], v[1]);
-      o[1] = pack2bf(v[2], v[3]);
-      *(u32x2_t*)(scr + grp * 2048 + woff[ni]) = o;
+      o[ni][0] = pack2bf(v[0], v[1]);
+      o[ni][1] = pack2bf(v[2], v[3]);
     }
+  };
+  auto slab_store = [&](int grp, const u32x2_t* o) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) *(u32x2_t*)(scr + grp * 2048 + woff[ni]) = o[ni];
+  };
+  auto write_slab = [&](int mi, int grp) {
+    u32x2_t o[4];
+    slab_values(mi, grp, o);
+    slab_store(grp, o);
   };
   if constexpr (FORM != 0) {
 #pragma unroll
@@ -533,12 +544,19 @@ __device__ __forceinline__ void staged_rows_fast8(const GemmKArgs& p, long long 
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         y[j] = *(const u32x4_t*)(scr + grp * 2048 + roff + j * 1024);
-        if (j == 1) y[j] = (u32x4_t){y[j][2], y[j][3], y[j][0], y[j][1]};
       }
-      // the slab is free once its two reads have been issued AND returned: the values above are consumed below, after the next row block's
-      // writes have been issued (the compiler's own lgkmcnt keeps the order: LDS operations of a wave complete in issue order)
-      asm volatile("" : "+v"(y[0]), "+v"(y[1]));
-      if (mi + 1 < MI) write_slab(mi + 1, grp);
+      // The slab's two reads are ISSUED; the next row block's arithmetic runs under their latency, and its writes to the same slab follow
+      // without a wait: the LDS operations of a wave execute in issue order, so a write issued behind a read cannot overtake it.  (Round 5
+      // measured the form that waited for the reads first — 16 exposed LDS round trips per tile, 7300 cycles for 707 instructions.)
+      __builtin_amdgcn_sched_barrier(0);
+      if (mi + 1 < MI) {
+        u32x2_t o[4];
+        slab_values(mi + 1, grp, o);
+        __builtin_amdgcn_sched_barrier(0);
+        slab_store(grp, o);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      y[1] = (u32x4_t){y[1][2], y[1][3], y[1][0], y[1][1]};
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = mi * 16 + j * 8 + rl;
@@ -1045,6 +1063,7 @@ typedef __attribute__((ext_vector_type(16))) uint32_t u32x16_t;
 struct W4Tile {
   u32x4_t rsA, rsW;
   u32x16_t vo;      // [0:7] X chunks, [8:15] W chunks
+  int m0, n0;       // the tile's first row / column (wave-uniform, in SGPRs: the epilogue of the tile reuses them instead of walking again)
 };
 // An INTERIOR tile inside one batch of the row map has offsets row * ld (no clamp, no division); edge tiles and tiles that cross a batch
 // take the general form
@@ -1052,7 +1071,9 @@ __device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int 
   auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   int tm, tn;
   pick_tile(p, tile, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = __builtin_amdgcn_readfirstlane(tm * 256), n0 = __builtin_amdgcn_readfirstlane(tn * 256);
+  t.m0 = m0;
+  t.n0 = n0;
   const long long a0 = p.am.off(m0);
   const int wrows = min(256, p.N - n0);
   const unsigned long long pa = (unsigned long long)(uintptr_t)(p.A + a0), pw = (unsigned long long)(uintptr_t)(p.W + (long long)n0 * p.K);
@@ -1168,10 +1189,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
       for (int ni = 0; ni < 8; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mi][ni][r] = accrow[mi][4 * ni + r];
-    int tm, tn;
     const GemmKArgs pe = args_now();
-    pick_tile(pe, vb, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = cur.m0, n0 = cur.n0;
     const GemmKArgs pd = dest_of(pe, n0);
     bool fast = false;
     if (pd.wide) fast = staged_epilogue<8, 256, 256, 8>(pd, m0, m0 + wr * 128, n0, n0 + wc * 128, le, acc, smem + 2 * STAGE + w * 4096);
@@ -1607,7 +1626,9 @@ static int gemm_choice(long long M1, long long M2, int N, int K, long long* cost
     // its fixed cost per tile is 7 us against 4.5 and its first tile starts cold: three rounds of tiles, or one with long K loops, amortise
     // that (configs[1]'s two-round (1536, 21 504, 3072) launch lost 2 %: profiles/r05_gemm_w4p_fixed_cost.log)
     const long long tiles4 = tile_rows(M1, 0, 256) * ((N + 255) / 256);
-    if (w4_ok && drag_opt(DRAG_OPT_GEMM_W4) != 1 && tiles4 >= 256 && (K >= 8192 || tiles4 >= 768)) choice = 3;
+    const int w4 = drag_opt(DRAG_OPT_GEMM_W4);      // 1 never | 2 every launch of the 8-wave kernel it can run | 3 those of >= 256 tiles
+    const bool enough = w4 == 2 ? true : w4 == 3 ? tiles4 >= 256 : tiles4 >= 256 && (K >= 8192 || tiles4 >= 768);
+    if (w4_ok && w4 != 1 && enough) choice = 3;
   } else choice = deep_policy(M1, M2, N, K, &cost);
   if (cost_out) *cost_out = cost;
   return choice;
