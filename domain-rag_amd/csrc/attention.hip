@@ -139,6 +139,7 @@ struct AttnArgs {
   int s_txt;
   float eps;
   int tune;       // measurement bits: 1 = static priority for the younger wave half, 2 = 16-byte epilogue stores
+  int items;      // attention_q64_kernel: (batch-head, query block) items in all = the one-item grid; a smaller grid walks them (persistent)
 };
 
 constexpr float DEFER_THR = 8.0f;     // log2 units; 0 = rescale on every increase (classic online softmax)
@@ -663,24 +664,55 @@ __device__ __forceinline__ void q64_unroll16(F&& f) {
   }
 }
 
+#if DRAG_EXP
+// experiment builds: shader-clock stamps of workgroup 0 / wave 0: [0] kernel start, [1] before the KV loop, then per tile [2 + 2 it] the wave
+// reaches the tile's vmcnt(0) + barrier, [3 + 2 it] it is past them; [2 + 2 nkv] loop done, [3 + 2 nkv] kernel end
+__device__ unsigned long long g_attn_stamps[512];
+#define ATTN_STAMP(slot)                                                                                                  \
+  do {                                                                                                                     \
+    if (blockIdx.x == 0 && w == 0 && l == 0 && (slot) < 512) g_attn_stamps[(slot)] = __builtin_amdgcn_s_memtime();         \
+  } while (0)
+#else
+#define ATTN_STAMP(slot) do { } while (0)
+#endif
 template <bool QPREP>
 __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * VT_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 K tiles | 2 V^T tiles | Q64_QLDS bytes of q rows on their way to registers
   const int w = wave_id(), l = lane_id();
+  ATTN_STAMP(0);
   const int hh = l >> 5;
   constexpr int QB = 256, CPW = 4;
   const int nqb = (p.S + QB - 1) / QB;
-  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int bh = (loc / nqb) * 8 + xcd;
-  if (bh >= p.B * p.H) return;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = (loc - (loc / nqb) * nqb) * QB + w * 64;        // group qg: queries q0 + 32 qg + (l & 31)
+  // An ITEM is a (batch, head) and a block of 256 queries: item & 7 = the XCD (heads 8 g + xcd share an L2), item >> 3 = (group, query block).
+  // A grid of p.items workgroups runs one item each; a smaller grid (a multiple of 8: one workgroup per CU) walks items i, i + grid, ... —
+  // all on the workgroup's XCD — and the KV stream of an item's last two tiles stages the NEXT item's K(0), K(1), V(0) where it would
+  // stage tiles that do not exist, the next item's q rows are requested before this item's output is stored: with one workgroup per CU
+  // (512 registers per wave) nothing else overlaps an item's seam — 6.5 % of an 84-tile item (profiles/r05_attn_q64_stamps.log)
+  struct Item { int b, h, q0; };
+  auto decode = [&](int item, Item& t) -> bool {
+    const int xcd = item & 7, loc = item >> 3;
+    const int bh = (loc / nqb) * 8 + xcd;
+    t.b = bh / p.H;
+    t.h = bh - t.b * p.H;
+    t.q0 = (loc - (loc / nqb) * nqb) * QB + w * 64;              // group qg: queries q0 + 32 qg + (l & 31)
+    return bh < p.B * p.H;
+  };
+  int item = (int)blockIdx.x;
+  Item cur;
+  if (!decode(item, cur)) return;      // (grids smaller than p.items are launched only when B * H is a multiple of 8: every item exists)
 
   bf16x8_t qf[2][8];
-  const bf16_t* kbase = p.k + (long long)b * p.qk_bs + h * 128;
-  const bf16_t* vbase = p.vt + ((long long)(b * p.H + h) * 128) * p.s_pad;
-  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.vt_bytes, 0x00020000);
+  auto k_descr = [&](const Item& t) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (long long)t.b * p.qk_bs + t.h * 128), 0, p.k_bytes, 0x00020000);
+  };
+  auto v_descr = [&](const Item& t) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + ((long long)(t.b * p.H + t.h) * 128) * p.s_pad), 0, p.vt_bytes, 0x00020000);
+  };
+  // the descriptors the LDS-DMA pieces go through, and what is subtracted from a piece's key index: in an item's last two tiles they are
+  // switched to the NEXT item's K (from tile nkv - 2 on) and V^T (tile nkv - 1) with s_pad subtracted — K(nkv), K(nkv + 1), V(nkv) become
+  // the next item's K(0), K(1), V(0), in the buffers where its prologue and first tile look for them (nkv even)
+  __amdgpu_buffer_rsrc_t rsK = k_descr(cur), rsV = v_descr(cur);
+  int ksub = 0, vsub = 0;
   // K staging offsets: lane's row of piece i inside a tile and its swizzled 16-byte slot as ONE loop-invariant byte offset; a piece's address is
   // that plus the tile's (uniform) byte offset — one v_add_u32 per piece (the clamp min(row, S - 1) and its 64-bit multiply-add cost three
   // VALU instructions per piece in a loop bound by its issue slots).  Rows past S fall outside the (batch, head) descriptor: the LDS-DMA
@@ -697,13 +729,13 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   }
   auto stage_k1 = [&](int buf, int kv0, int i) {
     const int c = w * CPW + i;
-    const unsigned ko = koff[i] + (unsigned)kv0 * (unsigned)(p.ld_qk * 2);
+    const unsigned ko = koff[i] + (unsigned)(kv0 - ksub) * (unsigned)(p.ld_qk * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + buf * KT_BYTES + c * 1024), 16, ko, 0, 0, 0);
   };
   auto stage_v1 = [&](int buf, int kv0, int i) {
     const int c = w * CPW + i;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)((DRAG_LDS char*)smem + 2 * KT_BYTES + buf * VT_BYTES + c * 1024),
-                                             16, voff[i], kv0 * 2, 0, 0);
+                                             16, voff[i], (kv0 - vsub) * 2, 0, 0);
   };
   const int krd = (l & 31) * 256, kx = l & 15;
   const int vrd = (l & 31) * 128, vx = ((l & 31) >> 1) & 7;
@@ -712,7 +744,138 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   for (int ks = 0; ks < 8; ++ks) ak[ks] = krd + (((2 * ks + hh) ^ kx) << 4);
 #pragma unroll
   for (int s2 = 0; s2 < 4; ++s2) av[s2] = vrd + (((2 * s2 + hh) ^ vx) << 4);
+  // LDS byte addresses of this lane's K / V^T fragment slots: one register each, added once (inside the steps hipcc re-derived them per read)
+  const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
+  unsigned akl[8], avl[4];
+  {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) akl[i] = lds0 + (unsigned)ak[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) avl[i] = lds0 + (unsigned)av[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(akl[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(avl[i]));
+  }
 
+  const int nkv = p.s_pad / 64;
+  const bool paired = (nkv & 1) == 0 && nkv >= 4;      // the last two tiles are peeled bodies that stage for the next item (buffer parities line up)
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto stage_first = [&]() {       // K(0), V(0), K(1) of the item rsK / rsV name
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_k1(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_v1(0, 0, i);
+    if (nkv > 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stage_k1(1, 64, i);
+    }
+  };
+  // Q load in two parts: the rows are REQUESTED (q_request: LDS-DMA, 16 bytes x 8 per lane and query group, every lane's pieces at
+  // lane-private LDS addresses — 16 KiB per wave beside the tiles, no registers) — for the next item before this item's output is
+  // stored, so the round trip runs under the epilogue — and turned into fragments later (q_fragments: read back, + RMSNorm / RoPE when
+  // QPREP, whose weight and table rows are L2-resident).  (Requested into registers, the 64 VGPRs were spilled around the epilogue and
+  // the spill stores waited for the loads they were meant to hide.)
+  // (what an item's seam derives from the lane id is recomputed per item from a laundered copy: hoisted out of the item loop it would sit
+  //  in VGPRs across the KV stream, which has 38 to spare — the first build of this loop spilled 1.3 KB to scratch, inside the stream too)
+  auto lane_now = [&]() { int v = l; asm volatile("" : "+v"(v)); return v; };
+  DRAG_LDS char* const qlds = (DRAG_LDS char*)smem + 2 * KT_BYTES + 2 * VT_BYTES + w * 16384;
+  auto q_request = [&](const Item& t, const int ll) {
+    // (the K descriptor's span fits q: same row stride, same batch stride, same 128 columns of a head)
+    __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + (long long)t.b * p.qk_bs + t.h * 128), 0, p.k_bytes, 0x00020000);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const int qr = min(t.q0 + 32 * qg + (ll & 31), p.S - 1);
+      const unsigned vo = (unsigned)qr * (unsigned)(p.ld_qk * 2) + (unsigned)((ll >> 5) * 16);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (DRAG_LDS void*)(qlds + (qg * 8 + ks) * 1024), 16, vo, ks * 32, 0, 0);   // (the column offset as the
+                                                                       // scalar offset: an instruction offset would move the LDS address as well)
+    }
+  };
+  auto q_fragments = [&](const Item& t, const int ll) {       // (the wave's own pieces: behind its s_waitcnt vmcnt(0), no barrier)
+    const int hh = ll >> 5;
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      u32x4_t raw[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) raw[ks] = *(const DRAG_LDS u32x4_t*)(qlds + (qg * 8 + ks) * 1024 + ll * 16);
+      if constexpr (!QPREP) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[qg][ks] = __builtin_bit_cast(bf16x8_t, raw[ks]);
+      } else {
+        const int qr = min(t.q0 + 32 * qg + (ll & 31), p.S - 1);
+        const bf16_t* wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
+        const float* cp = p.cosT + (long long)qr * 64 + hh * 4;
+        const float* sp = p.sinT + (long long)qr * 64 + hh * 4;
+        u32x4_t wr[8];
+        f32x4_t c4[8], s4[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          wr[ks] = *(const u32x4_t*)(wsel + ks * 16);
+          c4[ks] = *(const f32x4_t*)(cp + ks * 8);
+          s4[ks] = *(const f32x4_t*)(sp + ks * 8);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+            ss += a0 * a0;
+            ss += a1 * a1;
+          }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a0 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] & 0xffff)) * rs) * bf2f((bf16_t)(wr[ks][j] & 0xffff)));
+            const float a1 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] >> 16)) * rs) * bf2f((bf16_t)(wr[ks][j] >> 16)));
+            o[j] = pack2bf(a0 * c4[ks][j] - a1 * s4[ks][j], a1 * c4[ks][j] + a0 * s4[ks][j]);
+          }
+          qf[qg][ks] = __builtin_bit_cast(bf16x8_t, o);
+        }
+      }
+    }
+  };
+  stage_first();
+  q_request(cur, l);               // while those tiles are in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  q_fragments(cur, l);
+  // From here on the Q fragments exist ONLY in the AGPR half: the tied operand makes hipcc copy each fragment into an AGPR
+  // tuple once; a fragment that merely gets "a"-constrained at its uses stays in VGPRs and is re-copied before every use
+  // (64 v_accvgpr_write per KV tile and 64 VGPRs gone).  The next item's fragments go there as soon as they exist (the AGPR half has
+  // room beside the output accumulators; 64 more live VGPRs across the epilogue were spilled)
+  bf16x8_t qa[2][8];
+  auto q_to_agprs = [&]() {
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) asm volatile("; q fragment -> AGPR" : "=a"(qa[qg][ks]) : "0"(qf[qg][ks]));
+  };
+  q_to_agprs();
+  bool staged = true;              // K(0), V(0), K(1) of the item at hand are in the LDS (or on their way)
+  // The previous item's output stores are the YOUNGEST vector-memory operations when the next item begins: its q rows and first tiles were
+  // requested before them, and a wave's vector-memory operations retire in issue order — so the waits of the seam leave exactly that many
+  // operations in flight instead of draining the stores (their acknowledgements take microseconds).  0 = count unknown (a ragged query
+  // block skips stores): wait for everything
+  int stores_behind = 0;
+  auto wait_older_than_stores = [&]() {
+    if (stores_behind == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (stores_behind == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  for (;;) {                       // items of this workgroup
+  ATTN_STAMP(4 + 2 * (p.s_pad / 64));
+  const int b = cur.b, h = cur.h, q0 = cur.q0;
+  const bool has_next = item + (int)gridDim.x < p.items;
+  if (!staged) {                   // (an odd number of tiles: no peeled bodies staged for this item)
+    __syncthreads();               // every wave is done with the previous item's tiles
+    stage_first();
+  }
   f32x16_t oacc[2][4];
 #pragma unroll
   for (int qg = 0; qg < 2; ++qg)
@@ -721,77 +884,14 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[qg][i][r] = 0.f;
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-  const int nkv = p.s_pad / 64;
-  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) stage_k1(0, 0, i);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) stage_v1(0, 0, i);
-  if (nkv > 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stage_k1(1, 64, i);
-  }
-  // Q load (+ RMSNorm / RoPE when QPREP) while those tiles are in flight
-#pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
-    const int qr = min(q0 + 32 * qg + (l & 31), p.S - 1);
-    const bf16_t* qp = p.q + (long long)b * p.qk_bs + (long long)qr * p.ld_qk + h * 128 + hh * 8;
-    if constexpr (!QPREP) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) qf[qg][ks] = *(const bf16x8_t*)(qp + ks * 16);
-    } else {
-      const bf16_t* wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
-      const float* cp = p.cosT + (long long)qr * 64 + hh * 4;
-      const float* sp = p.sinT + (long long)qr * 64 + hh * 4;
-      u32x4_t raw[8], wr[8];
-      f32x4_t c4[8], s4[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        raw[ks] = *(const u32x4_t*)(qp + ks * 16);
-        wr[ks] = *(const u32x4_t*)(wsel + ks * 16);
-        c4[ks] = *(const f32x4_t*)(cp + ks * 8);
-        s4[ks] = *(const f32x4_t*)(sp + ks * 8);
-      }
-      float ss = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
-          ss += a0 * a0;
-          ss += a1 * a1;
-        }
-      ss += __shfl_xor(ss, 32, 64);
-      const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        u32x4_t o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a0 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] & 0xffff)) * rs) * bf2f((bf16_t)(wr[ks][j] & 0xffff)));
-          const float a1 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] >> 16)) * rs) * bf2f((bf16_t)(wr[ks][j] >> 16)));
-          o[j] = pack2bf(a0 * c4[ks][j] - a1 * s4[ks][j], a1 * c4[ks][j] + a0 * s4[ks][j]);
-        }
-        qf[qg][ks] = __builtin_bit_cast(bf16x8_t, o);
-      }
-    }
-  }
-  // From here on the Q fragments exist ONLY in the AGPR half: the tied operand makes hipcc copy each fragment into an AGPR
-  // tuple once; a fragment that merely gets "a"-constrained at its uses stays in VGPRs and is re-copied before every use
-  // (64 v_accvgpr_write per KV tile and 64 VGPRs gone).
-  bf16x8_t qa[2][8];
-#pragma unroll
-  for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("; q fragment -> AGPR" : "=a"(qa[qg][ks]) : "0"(qf[qg][ks]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_older_than_stores();                  // K(0), V(0), K(1) landed
   __syncthreads();
   f32x16_t scur[2][2], snext[2][2];          // [query group][key half]
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8_t kf = *(const bf16x8_t*)(smem + (ak[ks] + t * (32 * 256)));
+      const bf16x8_t kf = *(const bf16x8_t*)(smem + ((akl[ks] - lds0) + t * (32 * 256)));
 #pragma unroll
       for (int qg = 0; qg < 2; ++qg) {
         if (ks == 0) Q64_MFMA_S0(scur[qg][t], kf, qa[qg][ks]);
@@ -831,29 +931,40 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   // The last key group's P V (8 MFMAs on fragments and P words already in registers) and the row maxima of the tile that follows are
   // one block at the TOP of the next iteration: behind the barrier, with the first K fragment reads of the new tile already issued, the
   // eight MFMAs cover both the reads' latency and the 32 v_max3 of the two row-maximum trees (4 per gap).
-  // LDS byte addresses of this lane's K / V^T fragment slots: one register each, added once (inside the steps hipcc re-derived them per read)
-  unsigned akl[8], avl[4];
-  {
-    const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) akl[i] = lds0 + (unsigned)ak[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) avl[i] = lds0 + (unsigned)av[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(akl[i]));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(avl[i]));
-  }
   bf16x8_t vtr[4];              // the four V^T fragments of the trailing P V MFMAs (read in steps 14 / 15, used after the next barrier)
   u32x4_t pk[2][4];             // packed P: key group kg of a tile is consumed in its steps 4 kg + 4 .. 4 kg + 7, group 3 after the next barrier
+  // knext / vnext: the K / V^T pieces of this tile's stream are the NEXT item's (the item's last two tiles, whose own pieces would be tiles
+  // that do not exist): K(0) into buffer 0 from tile nkv - 2, K(1) into buffer 1 and V(0) into buffer 0 from tile nkv - 1
   auto body = [&](const int it, auto par, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2], auto firstc) {
     constexpr int PAR = decltype(par)::value;
     constexpr bool FIRST = decltype(firstc)::value;
+    if constexpr (!FIRST) {
+      if (paired && it >= nkv - 2) {                 // (two scalar compares per tile; the switch itself once per item)
+        Item nx;
+        const bool have = has_next && decode(item + (int)gridDim.x, nx);
+        if (PAR == 0) {
+          rsK = have ? k_descr(nx) : __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, 0, 0x00020000);    // (no next item: zero records, the pieces stage zeros)
+          ksub = p.s_pad;
+        } else {
+          rsV = have ? v_descr(nx) : __builtin_amdgcn_make_buffer_rsrc((void*)p.vt, 0, 0, 0x00020000);
+          vsub = p.s_pad;
+        }
+      }
+    }
     constexpr int KN = ((PAR + 1) & 1) * KT_BYTES;
     constexpr int VB = 2 * KT_BYTES + PAR * VT_BYTES;
     const int kv0 = it * 64;
+#if DRAG_EXP
+    const unsigned long long t_reach = __builtin_amdgcn_s_memtime();      // (stored behind the barrier: a store here would be waited for by the vmcnt(0))
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#if DRAG_EXP
+    if (blockIdx.x == 0 && w == 0 && l == 0 && 3 + 2 * it < 512) {
+      g_attn_stamps[2 + 2 * it] = t_reach;
+      g_attn_stamps[3 + 2 * it] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     bf16x8_t kfr[3], vfr[3];      // fragment rings (step g uses slot g % 3)
     // RULE of this kernel: a fragment requested by an asm ds_read reaches compiler-visible code only through q64_landed (the s_waitcnt
     // that retires it, with the fragment as an in/out operand), and between the read and that wait there are asm statements only.  hipcc
@@ -984,6 +1095,7 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    ATTN_STAMP(1);
     body(0, P0{}, scur, snext, std::true_type{});                // (the first tile's row maxima come from the prologue)
     if (nkv > 1) body(1, P1{}, snext, scur, std::false_type{});
     for (int it = 2; it < nkv; it += 2) {
@@ -995,6 +1107,13 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int qg = 0; qg < 2; ++qg) Q64P_MFMA_O(oacc[qg][dt], vtr[dt], pk[qg][3]);
+    ATTN_STAMP(2 + 2 * nkv);
+  }
+  const int le = lane_now();         // the epilogue's and the next item's lane arithmetic (see lane_now)
+  Item nxt = cur;
+  if (has_next) {                    // the next item's q rows: requested before this item's output is stored, in flight under the epilogue
+    decode(item + (int)gridDim.x, nxt);
+    q_request(nxt, le);
   }
 
 #pragma unroll
@@ -1002,9 +1121,9 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
     Q64_SETTLE_O(oacc, qg);
     const float lt = l_run[qg] + __shfl_xor(l_run[qg], 32, 64);
     const float inv = 1.0f / lt;
-    const int qrow = q0 + 32 * qg + (l & 31);
+    const int qrow = q0 + 32 * qg + (le & 31);
     if (p.tune & 2) {
-      bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 8 * hh;
+      bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 8 * (le >> 5);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -1019,7 +1138,7 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
           if (qrow < p.S) *(u32x4_t*)(op + 32 * dt + 8 * g) = o;
         }
     } else if (qrow < p.S) {
-      bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 4 * hh;
+      bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 4 * (le >> 5);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -1031,9 +1150,32 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
         }
     }
   }
+  ATTN_STAMP(3 + 2 * (p.s_pad / 64));
+  if (!has_next) break;
+  stores_behind = q0 + 64 <= p.S ? ((p.tune & 2) ? 16 : 32) : 0;      // (every row of the wave valid: every store instruction was issued)
+  wait_older_than_stores();        // the q rows (the RoPE table rows q_fragments loads queue behind the stores; Q fragments computed BEFORE the
+                                   //  epilogue instead — rows requested a tile earlier — cost spills in the q-preparation instantiation)
+  q_fragments(nxt, le);
+  q_to_agprs();
+  ATTN_STAMP(5 + 2 * (p.s_pad / 64));
+  item += (int)gridDim.x;
+  cur = nxt;
+  if (!paired) {                   // (paired: the stream switched both already)
+    rsK = k_descr(cur);
+    rsV = v_descr(cur);
+  }
+  ksub = vsub = 0;
+  staged = paired;
+  }
 }
 
 }  // namespace
+
+#if DRAG_EXP
+extern "C" int drag_debug_attn_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int drag_qk_norm_rope_vt_bf16(void* qkv, void* vt, const void* wq_txt, const void* wk_txt,
                                          const void* wq_img, const void* wk_img, const float* rope_cos,
@@ -1181,8 +1323,33 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
     else { if (qprep) hipLaunchKernelGGL((attention_d128_kernel<4, 1, true, true, true>), grid, dim3(256), 0, st, p);
            else hipLaunchKernelGGL((attention_d128_kernel<4, 1, false, true, true>), grid, dim3(256), 0, st, p); }
   } else if (q64) {
-    if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attention_q64_kernel<false>), grid, dim3(256), 0, st, p);
+    // 64 KiB of tiles + 64 KiB for the q rows of the next item (LDS-DMA).  One workgroup per CU walks the items (persistent) when every
+    // item exists (B * H a multiple of 8) and the tiles pair up (an even number, >= 4: the stream's last two tiles stage for the next item);
+    // otherwise, and under "attn_walk" = 2, one item per workgroup
+    constexpr int lds64 = 2 * KT_BYTES + 2 * VT_BYTES + 4 * 16384;
+    static unsigned long long ready64 = 0;       // one bit per device: the attribute belongs to the device's copy of the kernel
+    static int ncu64 = 0;
+    int dev64 = 0;
+    (void)hipGetDevice(&dev64);
+    if (!((ready64 >> (dev64 & 63)) & 1ull)) {
+      DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
+                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess,
+                 "drag_attention: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      ready64 |= 1ull << (dev64 & 63);
+    }
+    if (ncu64 == 0) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev64) != hipSuccess || n <= 0) n = 256;
+      ncu64 = (n & ~7) ? (n & ~7) : 8;
+    }
+    p.items = (int)grid.x;
+    const int nkv64 = p.s_pad / 64;
+    const int popt = drag_opt(DRAG_OPT_ATTN_WALK);             // 0 policy | 2 one item per workgroup | n >= 8 (a multiple of 8): n workgroups (tests: many items each)
+    const int pgrid = popt >= 8 && popt % 8 == 0 ? popt : ncu64;
+    const bool walk = popt != 2 && (B * H) % 8 == 0 && nkv64 % 2 == 0 && nkv64 >= 4 && p.items > pgrid;
+    const dim3 grid64(walk ? (unsigned)pgrid : grid.x);
+    if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid64, dim3(256), lds64, st, p);
+    else hipLaunchKernelGGL((attention_q64_kernel<false>), grid64, dim3(256), lds64, st, p);
 #if DRAG_EXP
   } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 0 && fits32 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&
              nqb2 * groups > persist_slots()) {

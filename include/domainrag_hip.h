@@ -34,9 +34,11 @@ const char* drag_last_error(void);
  *   through the row groups' maxima by policy — k <= 128 and 8 192 < N <= 131 072, or N <= 524 288 with at most 4 queries | always the
  *   sampled-threshold form | the two-launch form wherever it applies: k <= 128, 8 192 < N <= 1 048 576), "gemm_pair" 0 | 1 | 2
  *   (drag_gemm_bf16_pair: merge unless both problems fill the chip alone | never | always), "topk_qreg" 0 | 1 (d = 512 scan: query tile in
- *   registers | read from LDS per corpus chunk).
+ *   registers | read from LDS per corpus chunk), "gemm_w4" 0 | 1 | 2 | 3 (gemm_bf16_w4p by policy | never | wherever it can run | launches of
+ *   >= 256 tiles), "attn_walk" 0 | 2 | n (the 64-query attention kernel: one workgroup per CU walks the (batch-head, query block) items when
+ *   it can | one item per workgroup | n workgroups, n a multiple of 8).
  * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
- * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_TOPK_PATH, $DRAG_GEMM_PAIR, $DRAG_TOPK_QREG.  Returns 0, or -1 for an unknown name. */
+ * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_TOPK_PATH, $DRAG_GEMM_PAIR, $DRAG_TOPK_QREG, $DRAG_GEMM_W4, $DRAG_ATTN_WALK.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 /* 1 when the library was built with DRAG_EXPERIMENTS=1 and carries the kernels behind "attn_persist", "attn_sched" = 3 and "topk_qt"
  * (measured non-improvements kept for their A/B records), else 0.  A pure query: no option is touched. */

@@ -285,6 +285,47 @@ def test_attention_q64_with_fused_q_prep_equals_the_8_wave_kernel(gpu, B, S, H, 
         ops.set_option("attn_q64", 0)
 
 
+@pytest.mark.parametrize("B,S,H,s_txt,qprep", [(2, 1150, 4, 300, True), (1, 1100, 8, 0, False), (2, 5337, 4, 1241, True), (1, 4130, 8, 0, False),
+                                              (1, 1280, 8, 200, True)])
+def test_attention_q64_walking_its_items_equals_one_item_per_workgroup(gpu, B, S, H, s_txt, qprep):
+    """round 5: one workgroup per CU walks the (batch-head, query block) items of the 64-query kernel; the KV stream of an item's last two
+    tiles stages the NEXT item's K(0), K(1), V(0) and the next item's q rows travel by LDS-DMA under the epilogue.  "attn_walk" = 8 / 16 puts
+    every item behind 8 / 16 workgroups (up to 21 items each, across heads and batches), 2 is one item per workgroup: same bits — also for
+    ragged last query blocks, the last tile's mask, and shapes the policy does not walk (S = 1100: 18 tiles pair up; S = 4130: 65 do not)"""
+    from domain_rag_amd import ops
+    D = H * 128
+    g = torch.Generator().manual_seed(S * 3 + H)
+    qkv = torch.randn(B, S, 3 * D, generator=g).bfloat16().to(gpu)
+    w = [(1 + 0.1 * torch.randn(128, generator=g)).bfloat16().to(gpu) for _ in range(4)]
+    ang = torch.rand(S, 64, generator=g) * 6.28
+    cos, sin = torch.cos(ang).contiguous().to(gpu), torch.sin(ang).contiguous().to(gpu)
+    s_pad = (S + 63) // 64 * 64
+    vt = torch.empty(B, H, 128, s_pad, device=gpu, dtype=torch.bfloat16)
+    if qprep:
+        ops.k_norm_rope_vt(qkv, vt, w[1], w[3], cos, sin, B, S, H, 3 * D, s_txt)
+    else:
+        ops.qk_norm_rope_vt(qkv, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
+
+    def run(walk):
+        ops.set_option("attn_walk", walk)
+        o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
+        if qprep:
+            ops.attention_qprep(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128), w[0], w[2], cos, sin, s_txt)
+        else:
+            ops.attention(qkv, qkv.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
+        return o.cpu()
+    try:
+        ops.set_option("attn_q64", 1)
+        ref = run(2)
+        assert torch.isfinite(ref.float()).all()
+        for walk in (8, 16, 0, 8):
+            got = run(walk)
+            assert torch.isfinite(got.float()).all(), f"attn_walk {walk}: {torch.isnan(got.float()).any(-1).sum().item()} rows with NaN"
+            assert torch.equal(got, ref), walk
+    finally:
+        ops.set_option("attn_q64", 0); ops.set_option("attn_walk", 0)
+
+
 @pytest.mark.parametrize("S", [1087, 4160])
 def test_attention_hot_key_in_every_lane_half(gpu, S):
     """round 4: one key per run whose score sits 150 octaves above every row's running maximum, at positions of a KV tile in both lane halves
