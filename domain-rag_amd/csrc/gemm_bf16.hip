@@ -73,6 +73,8 @@ struct GemmKArgs {
   void* C2;
   int ld2, n_split;
   int group_m;    // M tiles per group of the tile walk (8; "gemm_group_m" option for measurements)
+  int ldw;          // W's row stride in elements (= K, except in a split-K launch: the whole K of the Linear)
+  long long w_boff; // split-K launch (gemm_bf16_w4p only): what row batch b of A adds to W's base (elements): batch b multiplies columns b K .. b K + K - 1
   int epi_generic; // "gemm_epilogue" = 1: every tile takes the general staged epilogue (tests compare it with the specialised one bit for bit)
   // optional second row segment (drag_gemm_bf16_pair): M tiles >= seg_tiles_m belong to a second problem with its own operands and
   // row maps but the same N, K and epilogue form — a double block's text and image Linears as ONE launch of the non-persistent kernels
@@ -1076,19 +1078,20 @@ __device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int 
   t.n0 = n0;
   const long long a0 = p.am.off(m0);
   const int wrows = min(256, p.N - n0);
-  const unsigned long long pa = (unsigned long long)(uintptr_t)(p.A + a0), pw = (unsigned long long)(uintptr_t)(p.W + (long long)n0 * p.K);
+  const unsigned long long pa = (unsigned long long)(uintptr_t)(p.A + a0),
+                           pw = (unsigned long long)(uintptr_t)(p.W + (long long)n0 * p.ldw + (p.w_boff ? (long long)(m0 / p.am.rpb) * p.w_boff : 0ll));
   const bool interior = m0 + 256 <= p.M && wrows == 256 && m0 / p.am.rpb == (m0 + 255) / p.am.rpb;
   const long long a_span = interior ? ((long long)255 * p.am.ld + p.K) * 2 : (p.am.off(min(m0 + 255, p.M - 1)) - a0 + p.K) * 2;
   // no next tile: descriptors with zero records — the tail's loads return zeros without touching memory
   t.rsA = (u32x4_t){uni((uint32_t)pa), uni((uint32_t)(pa >> 32) & 0xffffu), valid ? uni((uint32_t)a_span) : 0u, 0x00020000u};
-  t.rsW = (u32x4_t){uni((uint32_t)pw), uni((uint32_t)(pw >> 32) & 0xffffu), valid ? uni((uint32_t)((long long)wrows * p.K * 2)) : 0u, 0x00020000u};
+  t.rsW = (u32x4_t){uni((uint32_t)pw), uni((uint32_t)(pw >> 32) & 0xffffu), valid ? uni((uint32_t)(((long long)(wrows - 1) * p.ldw + p.K) * 2)) : 0u, 0x00020000u};
   if (interior) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = (w * 8 + i) * 8 + (l >> 3);
       const int slot = (l & 7) ^ ((row >> 1) & 7);
       t.vo[i] = (unsigned)((row * p.am.ld + slot * 8) * 2);
-      t.vo[8 + i] = (unsigned)((row * p.K + slot * 8) * 2);
+      t.vo[8 + i] = (unsigned)((row * p.ldw + slot * 8) * 2);
     }
     return;
   }
@@ -1099,7 +1102,7 @@ __device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int 
     const int ra = min(m0 + row, p.M - 1);                 // clamp: rows past the edge are never stored
     t.vo[i] = (unsigned)((p.am.off(ra) - a0 + slot * 8) * 2);
     const int rw = min(row, wrows - 1);
-    t.vo[8 + i] = (unsigned)(((long long)rw * p.K + slot * 8) * 2);
+    t.vo[8 + i] = (unsigned)(((long long)rw * p.ldw + slot * 8) * 2);
   }
 }
 
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
   // hoisted they sit in VGPRs across the statement
   auto args_now = [&]() {
     GemmKArgs q = p;
-    asm volatile("" : "+s"(q.tiles_n), "+s"(q.tiles_m), "+s"(q.group_m), "+s"(q.am.rpb), "+s"(q.cm.rpb), "+s"(q.M), "+s"(q.K), "+s"(q.am.ld), "+s"(q.cm.ld));
+    asm volatile("" : "+s"(q.tiles_n), "+s"(q.tiles_m), "+s"(q.group_m), "+s"(q.am.rpb), "+s"(q.cm.rpb), "+s"(q.M), "+s"(q.K), "+s"(q.am.ld), "+s"(q.cm.ld), "+s"(q.ldw));
     return q;
   };
   auto read_addrs = [&](int lv) {      // [buffer][X k-half 0, X k-half 1, W k-half 0, W k-half 1]
@@ -1553,6 +1556,7 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   k.cm.rpb = c_rpb > 0 ? c_rpb : M; k.cm.bs = c_bs; k.cm.ld = ldc;
   k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
   k.a_bytes = 0; k.w_bytes = 0;
+  k.ldw = K; k.w_boff = 0;
   k.C2 = nullptr; k.ld2 = 0; k.n_split = 0;
   k.seg_tiles_m = 0; k.A2 = nullptr; k.W2 = nullptr; k.Cs2 = nullptr; k.bias2 = nullptr; k.gate2 = nullptr; k.resid2 = nullptr;
   k.M2 = 0; k.ldg2 = 0; k.wide2 = 0; k.am2 = RowMap{1, 0, 0}; k.cm2 = RowMap{1, 0, 0};
@@ -1574,7 +1578,7 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
 }
 
 // argument checks + kernel arguments of one row segment
-static int gemm_prepare(GemmKArgs& k, const drag_gemm_args* a) {
+static int gemm_prepare(GemmKArgs& k, const drag_gemm_args* a, bool k_slices = false) {
   DRAG_CHECK(a != nullptr, "drag_gemm_bf16: null args");
   DRAG_CHECK(a->A && a->W && a->C, "drag_gemm_bf16: null operand pointer");
   DRAG_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "drag_gemm_bf16: M, N, K must be positive");
@@ -1590,10 +1594,12 @@ static int gemm_prepare(GemmKArgs& k, const drag_gemm_args* a) {
   k.am.bs = a->a_batch_stride; k.am.ld = a->lda;
   k.cv = ConvMap{1, 1, 1, 1, 64, 1, 0, 0};
   // in-tile offsets are 32-bit and must grow with the row index
-  DRAG_CHECK(k.am.rpb >= a->M || k.am.bs >= (long long)(k.am.rpb - 1) * k.am.ld,
+  // (k_slices: the row batches of a split-K launch are K slices of the SAME rows — batch stride = the slice width; its tiles never
+  //  cross a batch: M % 256 == 0)
+  DRAG_CHECK(k_slices || k.am.rpb >= a->M || k.am.bs >= (long long)(k.am.rpb - 1) * k.am.ld,
              "drag_gemm_bf16: a_batch_stride must not be smaller than one batch of rows");
   DRAG_CHECK(((long long)BM * a->lda + a->K) * 2 < (1ll << 30) && (long long)BN * a->K * 2 < (1ll << 31) &&
-                 (k.am.rpb >= a->M || (k.am.bs - (long long)(k.am.rpb - 1) * k.am.ld) * 2 < (1ll << 30)),
+                 (k_slices || k.am.rpb >= a->M || (k.am.bs - (long long)(k.am.rpb - 1) * k.am.ld) * 2 < (1ll << 30)),
              "drag_gemm_bf16: tile span too large for 32-bit offsets");
   if (a->C2 != nullptr) {
     DRAG_CHECK(a->n_split > 0 && a->n_split < a->N && a->n_split % 256 == 0, "drag_gemm_bf16: n_split must be a multiple of 256 inside (0, N)");
@@ -1635,15 +1641,17 @@ static int gemm_choice(long long M1, long long M2, int N, int K, long long* cost
 }
 
 // one launch over the rows of `a` and, when b != nullptr, of a second segment with the same N, K and epilogue form
-static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* stream) {
+// w_total_k > 0: `a` is the stacked form of a split-K launch (gemm_splitk): row batch b of A is K slice b, W's rows are w_total_k wide
+static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* stream, int w_total_k = 0) {
   GemmKArgs k, k2;
-  if (int rc = gemm_prepare(k, a)) return rc;
+  if (int rc = gemm_prepare(k, a, w_total_k > 0)) return rc;
+  if (w_total_k > 0) { k.ldw = w_total_k; k.w_boff = a->K; }
   if (b != nullptr) {
     if (int rc = gemm_prepare(k2, b)) return rc;
     k.A2 = k2.A; k.W2 = k2.W; k.Cs2 = k2.C; k.bias2 = k2.bias; k.gate2 = k2.gate; k.resid2 = k2.resid;
     k.M2 = k2.M; k.ldg2 = k2.ldg; k.wide2 = k2.wide; k.am2 = k2.am; k.cm2 = k2.cm;
   }
-  const int choice = gemm_choice(a->M, b ? b->M : 0, a->N, a->K);
+  const int choice = w_total_k > 0 ? 3 : gemm_choice(a->M, b ? b->M : 0, a->N, a->K);      // (the W offsets of the slices exist in gemm_bf16_w4p only)
   const hipStream_t st_ = (hipStream_t)stream;
   auto tiles_of = [&](int tm) {            // each segment starts on a tile boundary
     k.tiles_m = (a->M + tm - 1) / tm;
@@ -1725,7 +1733,121 @@ static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* s
   return 0;
 }
 
-extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) { return gemm_launch(a, nullptr, stream); }
+// --------------------------------------------------------------------------------------------
+// Split-K (round 5): a Linear with few output tiles and a long K — the single blocks' proj_out at batch 1, 1536 x 3072 x 15 360: 72 tiles
+// of 256 x 256 on 256 CUs, or 256 tiles of 96 x 192 with half the arithmetic intensity (today's choice: 177 us, L2 -> LDS bound) — runs as
+// ONE launch of gemm_bf16_w4p over S stacked K slices ((S M) x N x (K / S), f32 partial products into the caller's workspace: 216 tiles,
+// 115 us) and one pass that adds the slices in order and applies the epilogue (splitk_reduce_kernel, the arithmetic of epi_row).  The sum
+// of S f32 chains is not the single chain's bits: the one place where the kernel choice changes the last bit of an output — accuracy
+// against the f32 oracle is the same (tests) — hence policy only where it pays (below) and "gemm_splitk" = 1 to switch it off.
+// The workspace is the caller's (drag_gemm_set_workspace, per device): no allocation on the launch path, safe under graph capture;
+// launches that use it must be ordered on one stream.
+// --------------------------------------------------------------------------------------------
+static void* g_splitk_ws[64];
+static long long g_splitk_ws_bytes[64];
+extern "C" int drag_gemm_set_workspace(void* ptr, int64_t bytes) {
+  int dev = 0;
+  DRAG_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "drag_gemm_set_workspace: no current device");
+  DRAG_CHECK((ptr == nullptr) == (bytes <= 0) && ((uintptr_t)ptr & 255) == 0, "drag_gemm_set_workspace: a 256-byte aligned device buffer and its size, or (null, 0)");
+  g_splitk_ws[dev] = ptr;
+  g_splitk_ws_bytes[dev] = ptr ? (long long)bytes : 0;
+  return 0;
+}
+
+struct SplitReduceArgs {
+  const float* part;      // [S][M][N]
+  bf16_t* C;
+  const bf16_t *bias, *gate, *resid;
+  int S, M, N, ldg;
+  RowMap cm;
+};
+// one thread = four consecutive columns of one row: v = bias + sum over the slices in order; then epi_row's forms
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = p.N / 4;
+  if (i >= (long long)p.M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+  f32x4_t v = *(const f32x4_t*)(p.part + (long long)m * p.N + n);
+  for (int s = 1; s < p.S; ++s) {
+    const f32x4_t t = *(const f32x4_t*)(p.part + ((long long)s * p.M + m) * p.N + n);
+    v += t;
+  }
+  if (p.bias) {
+    const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
+    v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
+  }
+  const long long coff = p.cm.off(m) + n;
+  if (p.resid) {
+    const u32x2_t rr = *(const u32x2_t*)(p.resid + coff);
+    const float x[4] = {bf_lo(rr[0]), bf_hi(rr[0]), bf_lo(rr[1]), bf_hi(rr[1])};
+    if (p.gate) {      // diffusers: x + gate * y with y, gate, x bf16 tensors: y rounded first, the product rounded, then the sum
+      const u32x2_t gg = *(const u32x2_t*)(p.gate + (long long)(m / p.cm.rpb) * p.ldg + n);
+      const float g[4] = {bf_lo(gg[0]), bf_hi(gg[0]), bf_lo(gg[1]), bf_hi(gg[1])};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * rbf(v[r]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(v[r]);
+    }
+  }
+  u32x2_t o;
+  o[0] = pack2bf(v[0], v[1]);
+  o[1] = pack2bf(v[2], v[3]);
+  *(u32x2_t*)(p.C + coff) = o;
+}
+
+// slices of a launch (0: not split).  Policy: at most 96 tiles of 256 x 256 (three eighths of the chip), K >= 12 288, as many slices as fit
+// one round of workgroups (<= 8, slices of whole 128-wide K-step pairs, >= 1024 wide); "gemm_splitk": 1 never | n >= 2 that many where valid
+static int splitk_slices(const drag_gemm_args* a) {
+  const int opt = drag_opt(DRAG_OPT_GEMM_SPLITK);
+  if (opt == 1 || drag_opt(DRAG_OPT_GEMM_KERNEL) != 0) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || g_splitk_ws[dev] == nullptr) return 0;
+  if (a->M % 256 || a->N % 256 || a->out_f32 || a->C2 || a->act != DRAG_ACT_NONE) return 0;
+  if (a->a_rows_per_batch > 0 && a->a_rows_per_batch < a->M) return 0;          // A is one dense batch
+  if (a->ldc % 4 || a->ldg % 4 || (a->c_rows_per_batch > 0 && a->c_batch_stride % 4)) return 0;
+  const long long tiles = (long long)(a->M / 256) * (a->N / 256);
+  int best = 0;
+  for (int s = 2; s <= 8; ++s) {
+    if (a->K % (128 * s) || a->K / s < 1024 || tiles * s > 256) continue;
+    if ((long long)s * a->M * a->N * 4 > g_splitk_ws_bytes[dev]) continue;
+    best = s;
+  }
+  if (opt >= 2) return (a->K % (128 * opt) == 0 && a->K / opt >= 256 && (long long)opt * a->M * a->N * 4 <= g_splitk_ws_bytes[dev]) ? opt : 0;
+  return (tiles <= 96 && a->K >= 12288) ? best : 0;      // (K = 8192: two slices of 72 tiles lose 3 %: profiles/r05_gemm_splitk_ab.log)
+}
+
+static int gemm_splitk(const drag_gemm_args* a, int S, void* stream) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  drag_gemm_args v{};
+  v.A = a->A; v.W = a->W; v.C = g_splitk_ws[dev];
+  v.M = S * a->M; v.N = a->N; v.K = a->K / S;
+  v.lda = a->lda; v.a_rows_per_batch = a->M; v.a_batch_stride = a->K / S;
+  v.ldc = a->N; v.c_rows_per_batch = a->M; v.c_batch_stride = (long long)a->M * a->N;
+  v.out_f32 = 1;
+  if (int rc = gemm_launch(&v, nullptr, stream, a->K)) return rc;
+  SplitReduceArgs r{};
+  r.part = (const float*)g_splitk_ws[dev]; r.C = (bf16_t*)a->C;
+  r.bias = (const bf16_t*)a->bias; r.gate = (const bf16_t*)a->gate; r.resid = (const bf16_t*)a->resid;
+  r.S = S; r.M = a->M; r.N = a->N; r.ldg = a->ldg;
+  r.cm.rpb = a->c_rows_per_batch > 0 ? a->c_rows_per_batch : a->M; r.cm.bs = a->c_batch_stride; r.cm.ld = a->ldc;
+  const long long n = (long long)a->M * (a->N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
+  DRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
+  if (a != nullptr && a->A && a->W && a->C && a->M > 0 && a->N > 0 && a->K > 0) {
+    if (const int S = splitk_slices(a)) {
+      DRAG_CHECK(!(a->gate && !a->resid), "drag_gemm_bf16: gate needs resid");
+      return gemm_splitk(a, S, stream);
+    }
+  }
+  return gemm_launch(a, nullptr, stream);
+}
+extern "C" int drag_gemm_bf16_splitk_slices(const drag_gemm_args* a) { return a ? splitk_slices(a) : 0; }
 #if DRAG_EXP
 extern "C" int drag_debug_w4_stamps(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w4_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;

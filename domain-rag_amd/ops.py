@@ -43,6 +43,8 @@ class GemmRecorder:
         if conv == "f32":
             return "conv2d_f32_kernel"
         M, N, K = shape
+        if isinstance(conv, tuple) and conv[0] == "splitk":  # drag_gemm_bf16 as stacked K slices + the reduce pass (one recorded interval)
+            return "gemm_bf16_w4p + splitk_reduce_kernel"
         M1, M2 = (conv[1], conv[2]) if isinstance(conv, tuple) else (M, 0)
         if conv is True:                                     # the 3x3 convolutions take t256 or t128 only, by their own predicate
             return "gemm_bf16_t256<1>" if _lib.load().drag_conv3x3_bf16_choice(M, N, K // 9) == 2 else "gemm_bf16_t128<1>"
@@ -170,6 +172,29 @@ def _recorded(call, shape, kind=False):
     _recorder.is_conv.append(kind)
 
 
+_gemm_workspaces: dict[int, torch.Tensor] = {}
+
+
+def gemm_workspace(device: torch.device, mbytes: int | None = None) -> None:
+    """register this device's split-K workspace with the library (``drag_gemm_set_workspace``): ``gemm`` does it once per device with
+    $DRAG_GEMM_WORKSPACE_MB (default 64; 0 = none, no launch is split) — a Linear of few output tiles and a long K (batch-1 proj_out /
+    ff down-projections) then runs as stacked K slices + one reduce pass.  Not taken during stream capture (the buffer must outlive the
+    graph: call this before capturing)."""
+    import os
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if mbytes is None:
+        mbytes = int(os.environ.get("DRAG_GEMM_WORKSPACE_MB", "64"))
+    lib = _lib.load()
+    with torch.cuda.device(idx):
+        if mbytes <= 0:
+            _gemm_workspaces[idx] = torch.empty(0, dtype=torch.uint8, device=device)
+            check(lib.drag_gemm_set_workspace(None, 0), "drag_gemm_set_workspace")
+            return
+        ws = torch.empty(mbytes << 20, dtype=torch.uint8, device=device)
+        check(lib.drag_gemm_set_workspace(ctypes.c_void_p(ws.data_ptr()), ws.numel()), "drag_gemm_set_workspace")
+        _gemm_workspaces[idx] = ws
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, bias=None, act: int = ACT_NONE,
          act_n0: int = 0, gate=None, resid=None, out_f32: bool = False, M: int | None = None,
          a_rows_per_batch: int = 0, a_batch_stride: int = 0, lda: int | None = None,
@@ -180,9 +205,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, b
     count ``M`` and the batched-row addressing (rows_per_batch, batch_stride, ld) explicitly; by
     default ``a`` is a dense [M, K] matrix and ``out`` a dense [M, N] one."""
     lib = _lib.load()
+    if a.is_cuda and a.device.index not in _gemm_workspaces and not torch.cuda.is_current_stream_capturing():
+        gemm_workspace(a.device)
     args, out, shape = _gemm_args(a, w, out, bias, act, act_n0, gate, resid, out_f32, M, a_rows_per_batch, a_batch_stride, lda,
                                   c_rows_per_batch, c_batch_stride, ldc, ldg, out2, ldc2, n_split)
-    _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16"), shape)
+    slices = lib.drag_gemm_bf16_splitk_slices(ctypes.byref(args)) if _recorder is not None else 0
+    _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(args), _stream()), "drag_gemm_bf16"), shape, ("splitk", slices) if slices else False)
     return out
 
 

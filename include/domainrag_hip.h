@@ -36,9 +36,10 @@ const char* drag_last_error(void);
  *   (drag_gemm_bf16_pair: merge unless both problems fill the chip alone | never | always), "topk_qreg" 0 | 1 (d = 512 scan: query tile in
  *   registers | read from LDS per corpus chunk), "gemm_w4" 0 | 1 | 2 | 3 (gemm_bf16_w4p by policy | never | wherever it can run | launches of
  *   >= 256 tiles), "attn_walk" 0 | 2 | n (the 64-query attention kernel: one workgroup per CU walks the (batch-head, query block) items when
- *   it can | one item per workgroup | n workgroups, n a multiple of 8).
+ *   it can | one item per workgroup | n workgroups, n a multiple of 8), "gemm_splitk" 0 | 1 | n (split-K by policy | never | n slices wherever valid: see
+ *   drag_gemm_set_workspace).
  * Initial values: $DRAG_ATTN_SCHED, $DRAG_ATTN_W4, $DRAG_ATTN_TUNE, $DRAG_ATTN_Q64, $DRAG_ATTN_PERSIST, $DRAG_GEMM_KERNEL,
- * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_TOPK_PATH, $DRAG_GEMM_PAIR, $DRAG_TOPK_QREG, $DRAG_GEMM_W4, $DRAG_ATTN_WALK.  Returns 0, or -1 for an unknown name. */
+ * $DRAG_GEMM_GROUP_M, $DRAG_LN_GENERIC, $DRAG_TOPK_GRID, $DRAG_TOPK_DEPTH, $DRAG_TOPK_QT, $DRAG_TOPK_SELECT, $DRAG_TOPK_DENSE_SAMPLE, $DRAG_TOPK_PATH, $DRAG_GEMM_PAIR, $DRAG_TOPK_QREG, $DRAG_GEMM_W4, $DRAG_ATTN_WALK, $DRAG_GEMM_SPLITK.  Returns 0, or -1 for an unknown name. */
 int drag_set_option(const char* name, int32_t value);
 /* 1 when the library was built with DRAG_EXPERIMENTS=1 and carries the kernels behind "attn_persist", "attn_sched" = 3 and "topk_qt"
  * (measured non-improvements kept for their A/B records), else 0.  A pure query: no option is touched. */
@@ -104,6 +105,16 @@ int drag_conv3x3_bf16_choice(int64_t M, int Cout, int Cin);
 /* the policy's cost model for that launch: (tile rounds on the busiest CU) x (tile rows + tile columns), i.e. proportional to what the
  * busiest CU pulls through its L2 -> LDS path per K-step; comparable between launches of equal K.  0 under a forced "gemm_kernel". */
 int64_t drag_gemm_bf16_cost(int M1, int M2, int N, int K);
+/* Split-K (round 5): a device buffer drag_gemm_bf16 may use for f32 partial products on the CURRENT device ((null, 0) takes it back).
+ * With one registered, a Linear of at most 96 output tiles of 256 x 256 and K >= 12 288 without activation — M, N multiples of 256, one dense
+ * A batch, bf16 output: the single blocks' proj_out and the ff down-projections at batch 1 (transformer_flux.py FluxSingleTransformerBlock /
+ * FeedForward reached from the pipelines above at 512 x 512, batch 1) — runs as S stacked K slices in one launch plus one pass that adds
+ * them in order and applies bias / gate / residual: same arithmetic per slice, the sum of S f32 chains instead of one (the only launch
+ * whose last bit depends on the kernel choice; "gemm_splitk" = 1 switches it off, n >= 2 asks for n slices wherever they fit).  Needs
+ * S * M * N * 4 bytes; launches that use the buffer must be ordered on one stream.  Nothing is allocated on the launch path. */
+int drag_gemm_set_workspace(void* ptr, int64_t bytes);
+/* the slices drag_gemm_bf16 would use for these arguments right now (0: one launch, not split) — host-only, for callers that account launches */
+int drag_gemm_bf16_splitk_slices(const drag_gemm_args* args);
 
 /* ---------------------------------------------------------------------------------------
  * drag_conv3x3_bf16 — 3x3 convolution as an implicit GEMM on the same MFMA main loop.

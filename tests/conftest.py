@@ -27,3 +27,17 @@ def gpu(built_lib):
     if not torch.cuda.is_available():
         pytest.fail("test is marked gpu but no GPU is visible (domain-rag_amd has no CPU fallback)")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _split_k_policy_restored():
+    """a test that switches "gemm_splitk" off for its bit comparisons and then fails must not leave it off for the tests after it"""
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from domain_rag_amd import ops
+            ops.set_option("gemm_splitk", 0)
+    except Exception:
+        pass
+

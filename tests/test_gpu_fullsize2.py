@@ -237,6 +237,11 @@ def test_configs1_shape_routes_are_bit_identical_and_match_oracle(gpu, monkeypat
 
     def run(n):
         return model(hidden[:n].to(gpu), enc[:n].to(gpu), pooled[:n].to(gpu), t[:n], img_ids, txt_ids, None).clone()
+    # (round 5: a launch the policy runs as split K slices — this shape's proj_out, and the ff down-projections when they are NOT merged
+    #  into a pair — sums S f32 chains instead of one: the one kernel choice that moves the last bit.  The bit comparisons between routes
+    #  and batch sizes run with it off; the split route is held to the oracle's bar below)
+    split = run(1)
+    ops.set_option("gemm_splitk", 1)
     merged = run(1)
     try:
         ops.set_option("gemm_pair", 1)
@@ -259,5 +264,9 @@ def test_configs1_shape_routes_are_bit_identical_and_match_oracle(gpu, monkeypat
         ref = oflux.flux_forward(params, ocfg, hidden[:1], enc[:1], pooled[:1], t[:1], img_ids, txt_ids, None)
         ref32 = oflux.flux_forward({k: v.float() for k, v in params.items()}, ocfg, hidden[:1].float(), enc[:1].float(), pooled[:1].float(),
                                    t[:1], img_ids, txt_ids, None, time_dtype=torch.bfloat16)
+    ops.set_option("gemm_splitk", 0)
     e, e_or = _rel(merged, ref32), _rel(ref, ref32)
     assert e < _tol(e_or, 1e-2), _msg("configs[1] shape", e, e_or)
+    e_s = _rel(split, ref32)
+    assert e_s < _tol(e_or, 1e-2) and e_s < 1.05 * e + 1e-4, _msg("configs[1] shape, split-K route", e_s, e_or)
+    assert not torch.equal(split, merged) or lib.drag_gemm_set_workspace is None     # (the split route really ran)

@@ -1067,3 +1067,58 @@ def test_gemm_w4p_equals_the_8_wave_kernel(gpu, M, N, K):
         ops.set_option("gemm_kernel", 0)
     for i, (x, y) in enumerate(zip(ref, got)):
         assert torch.isfinite(x.float()).all() and torch.equal(x, y), i
+
+
+@pytest.mark.parametrize("M,N,K,want", [(1536, 3072, 15360, 3), (1024, 3072, 12288, 4), (512, 3072, 12288, 8), (256, 512, 8192, 8), (2048, 3072, 8192, 2)])
+def test_gemm_split_k_equals_one_launch_to_the_last_bf16_bit_or_so(gpu, M, N, K, want):
+    """round 5: a Linear of few output tiles and a long K (configs[1]'s proj_out: 1536 x 3072 x 15 360, 72 tiles of 256 x 256 on 256 CUs) runs
+    as S stacked K slices in ONE launch of gemm_bf16_w4p (f32 partials into the registered workspace) + one pass that adds the slices in
+    order and applies bias / gate / residual.  The sum of S f32 chains is not the single chain's bits — the one launch whose last bit
+    depends on the kernel choice — so: the slices the policy picks; against the unsplit launch ("gemm_splitk" = 1) at most one bf16 ulp
+    apart on a few elements; against the float64 product of the same bf16 operands no further away than the unsplit launch; the forms
+    plain / bias / bias + residual / bias + gate + residual on a two-batch row map; and what must NOT split (activation, ragged M, f32 out)"""
+    import ctypes
+    from domain_rag_amd import _lib, ops
+    a, w, b = _randn((M, K), 51).to(gpu), _randn((N, K), 52, 0.05).to(gpu), _randn((N,), 53).to(gpu)
+    rpb = M // 2
+    gate, resid = _randn((2, N), 54).to(gpu), _randn((M, N), 55).to(gpu)
+    ref64 = (a.double() @ w.double().T).cpu()
+
+    def run_all():
+        outs = [ops.gemm(a, w), ops.gemm(a, w, bias=b)]
+        x = resid.clone(); ops.gemm(a, w, out=x, bias=b, resid=x); outs.append(x)
+        y = resid.clone()
+        ops.gemm(a, w, out=y, bias=b, M=M, lda=K, ldc=N, c_rows_per_batch=rpb, c_batch_stride=rpb * N, gate=gate, resid=y, ldg=N)
+        outs.append(y)
+        return [o.cpu() for o in outs]
+
+    def slices(**kw):
+        args, _, _ = ops._gemm_args(a, w, None, kw.get("bias"), kw.get("act", ops.ACT_NONE), 0, None, None, kw.get("out_f32", False), kw.get("M"), 0, 0, None, 0, 0, None, 0,
+                                    None, 0, 0)
+        return _lib.load().drag_gemm_bf16_splitk_slices(ctypes.byref(args))
+    try:
+        ops.gemm(a[:256], w[:256])                       # (registers the workspace)
+        ops.set_option("gemm_splitk", 0)
+        assert slices() == (want if (M // 256) * (N // 256) <= 96 and K >= 12288 else 0)
+        assert slices(act=ops.ACT_GELU_TANH, bias=b) == 0 and slices(out_f32=True) == 0 and slices(M=M - 8) == 0
+        ops.set_option("gemm_splitk", 1); assert slices() == 0
+        ref = run_all()
+        ops.set_option("gemm_splitk", want); assert slices() == want
+        got = run_all()
+    finally:
+        ops.set_option("gemm_splitk", 0)
+    exact = [ref64, ref64 + b.double().cpu(), None, None]
+    for i, (x, y) in enumerate(zip(ref, got)):
+        assert torch.isfinite(y.float()).all(), i
+        d = (x.float() - y.float()).abs()
+        # one bf16 ulp of the larger value, plus the f32 accumulation noise of a K-long chain (what the two summation orders may differ by
+        # before the rounding: it is all there is to an output that happens to land near zero)
+        ulp = torch.maximum(x.float().abs(), y.float().abs()) * 2.0 ** -7 + 1e-4
+        if i >= 2:      # out = resid + round(...): when the two cancel, an ulp of the rounded TERM is many ulps of the output
+            ulp = (torch.maximum(x.float().abs(), y.float().abs()) + resid.float().abs().cpu()) * 2.0 ** -6 + 1e-4
+        assert (d <= ulp).all(), (i, float((d / ulp).max()))
+        assert (d > 0).float().mean() < 0.2, (i, float((d > 0).float().mean()))       # (one rounding boundary crossed here and there)
+        if exact[i] is not None:
+            e_ref, e_got = (x.double() - exact[i]).abs().max(), (y.double() - exact[i]).abs().max()
+            assert e_got <= 1.05 * e_ref + 1e-3, (i, float(e_ref), float(e_got))
+
