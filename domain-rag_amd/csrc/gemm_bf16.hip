@@ -1897,6 +1897,8 @@ extern "C" int drag_gemm_bf16_pair(const drag_gemm_args* a, const drag_gemm_args
   DRAG_CHECK(a->C2 == nullptr && b->C2 == nullptr, "drag_gemm_bf16_pair: no two-destination outputs");
   DRAG_CHECK((a->gate != nullptr) == (b->gate != nullptr) && (a->resid != nullptr) == (b->resid != nullptr) && (a->bias != nullptr) == (b->bias != nullptr),
              "drag_gemm_bf16_pair: the two problems must have the same epilogue operands");
+  // (a pair whose problems would each split K by policy — the double blocks' ff down-projections at batch 1 — stays a pair: two split
+  //  launches are 4 % faster alone and 1.2 % of configs[1] slower in the pipeline: profiles/r05_gemm_splitk_pairs_in_configs1.log)
   if (!drag_gemm_bf16_pair_merges(a->M, b->M, a->N, a->K)) {
     if (int rc = gemm_launch(a, nullptr, stream)) return rc;
     return gemm_launch(b, nullptr, stream);

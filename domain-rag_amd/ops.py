@@ -247,8 +247,9 @@ def gemm_pair(first: dict, second: dict):
         _recorded(lambda: check(lib.drag_gemm_bf16_pair(ctypes.byref(a1), ctypes.byref(a2), _stream()), "drag_gemm_bf16_pair"),
                   (s1[0] + s2[0], s1[1], s1[2]), ("pair", s1[0], s2[0]))
     else:       # two launches (what the library would issue itself), accounted one by one
-        _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(a1), _stream()), "drag_gemm_bf16"), s1)
-        _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(a2), _stream()), "drag_gemm_bf16"), s2)
+        for args_i, s_i in ((a1, s1), (a2, s2)):
+            sl = lib.drag_gemm_bf16_splitk_slices(ctypes.byref(args_i)) if _recorder is not None else 0
+            _recorded(lambda: check(lib.drag_gemm_bf16(ctypes.byref(args_i), _stream()), "drag_gemm_bf16"), s_i, ("splitk", sl) if sl else False)
     return o1, o2
 
 
