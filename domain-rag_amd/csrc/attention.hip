@@ -875,6 +875,7 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   if (!staged) {                   // (an odd number of tiles: no peeled bodies staged for this item)
     __syncthreads();               // every wave is done with the previous item's tiles
     stage_first();
+    stores_behind = 0;             // (these pieces are YOUNGER than the previous item's stores: the wait below has to cover everything)
   }
   f32x16_t oacc[2][4];
 #pragma unroll
@@ -1346,7 +1347,8 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
     const int nkv64 = p.s_pad / 64;
     const int popt = drag_opt(DRAG_OPT_ATTN_WALK);             // 0 policy | 2 one item per workgroup | n >= 8 (a multiple of 8): n workgroups (tests: many items each)
     const int pgrid = popt >= 8 && popt % 8 == 0 ? popt : ncu64;
-    const bool walk = popt != 2 && (B * H) % 8 == 0 && nkv64 % 2 == 0 && nkv64 >= 4 && p.items > pgrid;
+    // (a forced grid also walks items whose tiles do not pair up: each item then stages its own first tiles behind a barrier — tests)
+    const bool walk = popt != 2 && (B * H) % 8 == 0 && (popt >= 8 || (nkv64 % 2 == 0 && nkv64 >= 4)) && p.items > pgrid;
     const dim3 grid64(walk ? (unsigned)pgrid : grid.x);
     if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid64, dim3(256), lds64, st, p);
     else hipLaunchKernelGGL((attention_q64_kernel<false>), grid64, dim3(256), lds64, st, p);

@@ -286,12 +286,13 @@ def test_attention_q64_with_fused_q_prep_equals_the_8_wave_kernel(gpu, B, S, H, 
 
 
 @pytest.mark.parametrize("B,S,H,s_txt,qprep", [(2, 1150, 4, 300, True), (1, 1100, 8, 0, False), (2, 5337, 4, 1241, True), (1, 4130, 8, 0, False),
-                                              (1, 1280, 8, 200, True)])
+                                              (1, 1280, 8, 200, True), (1, 1216, 8, 100, True)])
 def test_attention_q64_walking_its_items_equals_one_item_per_workgroup(gpu, B, S, H, s_txt, qprep):
     """round 5: one workgroup per CU walks the (batch-head, query block) items of the 64-query kernel; the KV stream of an item's last two
     tiles stages the NEXT item's K(0), K(1), V(0) and the next item's q rows travel by LDS-DMA under the epilogue.  "attn_walk" = 8 / 16 puts
     every item behind 8 / 16 workgroups (up to 21 items each, across heads and batches), 2 is one item per workgroup: same bits — also for
-    ragged last query blocks, the last tile's mask, and shapes the policy does not walk (S = 1100: 18 tiles pair up; S = 4130: 65 do not)"""
+    ragged last query blocks, the last tile's mask, and tile counts that do not pair up (S = 4130: 65 tiles, S = 1216: 19 — a forced grid walks those
+    too, every item staging its own first tiles behind a barrier; the policy leaves them one item per workgroup)"""
     from domain_rag_amd import ops
     D = H * 128
     g = torch.Generator().manual_seed(S * 3 + H)
