@@ -61,6 +61,7 @@ SIGNATURES = {
     "drag_gemm_bf16_cost": (c_int64, [c_int, c_int, c_int, c_int]),
     "drag_gemm_set_workspace": (c_int, [c_void_p, c_int64]),
     "drag_gemm_bf16_splitk_slices": (c_int, [ctypes.POINTER(GemmArgs)]),
+    "drag_gemm_bf16_pair_splitk_slices": (c_int, [ctypes.POINTER(GemmArgs), ctypes.POINTER(GemmArgs)]),
     "drag_qk_norm_rope_vt_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "drag_attention_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float, c_void_p]),
     "drag_k_norm_rope_vt_bf16": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),

@@ -75,6 +75,7 @@ struct GemmKArgs {
   int group_m;    // M tiles per group of the tile walk (8; "gemm_group_m" option for measurements)
   int ldw;          // W's row stride in elements (= K, except in a split-K launch: the whole K of the Linear)
   long long w_boff; // split-K launch (gemm_bf16_w4p only): what row batch b of A adds to W's base (elements): batch b multiplies columns b K .. b K + K - 1
+  int split_m1;     // split-K launch of a PAIR: rows >= split_m1 of every K slice are the second problem's (operands A2 / W2, same row stride); 0: one problem
   int epi_generic; // "gemm_epilogue" = 1: every tile takes the general staged epilogue (tests compare it with the specialised one bit for bit)
   // optional second row segment (drag_gemm_bf16_pair): M tiles >= seg_tiles_m belong to a second problem with its own operands and
   // row maps but the same N, K and epilogue form — a double block's text and image Linears as ONE launch of the non-persistent kernels
@@ -1076,10 +1077,18 @@ __device__ __forceinline__ void w4_tile_state(const GemmKArgs& p, int tile, int 
   const int m0 = __builtin_amdgcn_readfirstlane(tm * 256), n0 = __builtin_amdgcn_readfirstlane(tn * 256);
   t.m0 = m0;
   t.n0 = n0;
-  const long long a0 = p.am.off(m0);
+  long long a0 = p.am.off(m0);
   const int wrows = min(256, p.N - n0);
-  const unsigned long long pa = (unsigned long long)(uintptr_t)(p.A + a0),
-                           pw = (unsigned long long)(uintptr_t)(p.W + (long long)n0 * p.ldw + (p.w_boff ? (long long)(m0 / p.am.rpb) * p.w_boff : 0ll));
+  const bf16_t *Ab = p.A, *Wb = p.W;
+  if (p.w_boff) {                            // split-K: row batch = K slice; in a pair's launch the rows behind split_m1 are the second problem's
+    const int sl = m0 / p.am.rpb, r = m0 - sl * p.am.rpb;
+    Wb += (long long)sl * p.w_boff;
+    if (p.split_m1 > 0 && r >= p.split_m1) {
+      Ab = p.A2; Wb = p.W2 + (long long)sl * p.w_boff;
+      a0 = (long long)sl * p.am.bs + (long long)(r - p.split_m1) * p.am.ld;
+    }
+  }
+  const unsigned long long pa = (unsigned long long)(uintptr_t)(Ab + a0), pw = (unsigned long long)(uintptr_t)(Wb + (long long)n0 * p.ldw);
   const bool interior = m0 + 256 <= p.M && wrows == 256 && m0 / p.am.rpb == (m0 + 255) / p.am.rpb;
   const long long a_span = interior ? ((long long)255 * p.am.ld + p.K) * 2 : (p.am.off(min(m0 + 255, p.M - 1)) - a0 + p.K) * 2;
   // no next tile: descriptors with zero records — the tail's loads return zeros without touching memory
@@ -1556,7 +1565,7 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   k.cm.rpb = c_rpb > 0 ? c_rpb : M; k.cm.bs = c_bs; k.cm.ld = ldc;
   k.ldg = ldg; k.act = act; k.act_n0 = act_n0; k.out_f32 = out_f32;
   k.a_bytes = 0; k.w_bytes = 0;
-  k.ldw = K; k.w_boff = 0;
+  k.ldw = K; k.w_boff = 0; k.split_m1 = 0;
   k.C2 = nullptr; k.ld2 = 0; k.n_split = 0;
   k.seg_tiles_m = 0; k.A2 = nullptr; k.W2 = nullptr; k.Cs2 = nullptr; k.bias2 = nullptr; k.gate2 = nullptr; k.resid2 = nullptr;
   k.M2 = 0; k.ldg2 = 0; k.wide2 = 0; k.am2 = RowMap{1, 0, 0}; k.cm2 = RowMap{1, 0, 0};
@@ -1642,10 +1651,13 @@ static int gemm_choice(long long M1, long long M2, int N, int K, long long* cost
 
 // one launch over the rows of `a` and, when b != nullptr, of a second segment with the same N, K and epilogue form
 // w_total_k > 0: `a` is the stacked form of a split-K launch (gemm_splitk): row batch b of A is K slice b, W's rows are w_total_k wide
-static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* stream, int w_total_k = 0) {
+static int gemm_launch(const drag_gemm_args* a, const drag_gemm_args* b, void* stream, int w_total_k = 0, const drag_gemm_args* split_second = nullptr) {
   GemmKArgs k, k2;
   if (int rc = gemm_prepare(k, a, w_total_k > 0)) return rc;
-  if (w_total_k > 0) { k.ldw = w_total_k; k.w_boff = a->K; }
+  if (w_total_k > 0) {
+    k.ldw = w_total_k; k.w_boff = a->K;
+    if (split_second) { k.split_m1 = a->a_rows_per_batch - split_second->M; k.A2 = (const bf16_t*)split_second->A; k.W2 = (const bf16_t*)split_second->W; }
+  }
   if (b != nullptr) {
     if (int rc = gemm_prepare(k2, b)) return rc;
     k.A2 = k2.A; k.W2 = k2.W; k.Cs2 = k2.C; k.bias2 = k2.bias; k.gate2 = k2.gate; k.resid2 = k2.resid;
@@ -1755,7 +1767,8 @@ extern "C" int drag_gemm_set_workspace(void* ptr, int64_t bytes) {
 }
 
 struct SplitReduceArgs {
-  const float* part;      // [S][M][N]
+  const float* part;      // [S][slice_rows][N]; this problem's rows begin at row0 of every slice
+  int slice_rows, row0;
   bf16_t* C;
   const bf16_t *bias, *gate, *resid;
   int S, M, N, ldg;
@@ -1767,9 +1780,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs p) {
   const int n4 = p.N / 4;
   if (i >= (long long)p.M * n4) return;
   const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
-  f32x4_t v = *(const f32x4_t*)(p.part + (long long)m * p.N + n);
+  f32x4_t v = *(const f32x4_t*)(p.part + (long long)(p.row0 + m) * p.N + n);
   for (int s = 1; s < p.S; ++s) {
-    const f32x4_t t = *(const f32x4_t*)(p.part + ((long long)s * p.M + m) * p.N + n);
+    const f32x4_t t = *(const f32x4_t*)(p.part + ((long long)s * p.slice_rows + p.row0 + m) * p.N + n);
     v += t;
   }
   if (p.bias) {
@@ -1798,37 +1811,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs p) {
 
 // slices of a launch (0: not split).  Policy: at most 96 tiles of 256 x 256 (three eighths of the chip), K >= 12 288, as many slices as fit
 // one round of workgroups (<= 8, slices of whole 128-wide K-step pairs, >= 1024 wide); "gemm_splitk": 1 never | n >= 2 that many where valid
-static int splitk_slices(const drag_gemm_args* a) {
+static int splitk_slices(const drag_gemm_args* a, const drag_gemm_args* b = nullptr) {
   const int opt = drag_opt(DRAG_OPT_GEMM_SPLITK);
   if (opt == 1 || drag_opt(DRAG_OPT_GEMM_KERNEL) != 0) return 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || g_splitk_ws[dev] == nullptr) return 0;
-  if (a->M % 256 || a->N % 256 || a->out_f32 || a->C2 || a->act != DRAG_ACT_NONE) return 0;
-  if (a->a_rows_per_batch > 0 && a->a_rows_per_batch < a->M) return 0;          // A is one dense batch
-  if (a->ldc % 4 || a->ldg % 4 || (a->c_rows_per_batch > 0 && a->c_batch_stride % 4)) return 0;
-  const long long tiles = (long long)(a->M / 256) * (a->N / 256);
+  auto fits = [](const drag_gemm_args* x) {
+    return x->M % 256 == 0 && x->N % 256 == 0 && !x->out_f32 && !x->C2 && x->act == DRAG_ACT_NONE &&
+           !(x->a_rows_per_batch > 0 && x->a_rows_per_batch < x->M) &&          // A is one dense batch
+           x->ldc % 4 == 0 && x->ldg % 4 == 0 && !(x->c_rows_per_batch > 0 && x->c_batch_stride % 4);
+  };
+  if (!fits(a) || (b && (!fits(b) || b->lda != a->lda || b->N != a->N || b->K != a->K))) return 0;
+  const long long rows = a->M + (b ? b->M : 0);
+  const long long tiles = (rows / 256) * (a->N / 256);
   int best = 0;
   for (int s = 2; s <= 8; ++s) {
     if (a->K % (128 * s) || a->K / s < 1024 || tiles * s > 256) continue;
-    if ((long long)s * a->M * a->N * 4 > g_splitk_ws_bytes[dev]) continue;
+    if ((long long)s * rows * a->N * 4 > g_splitk_ws_bytes[dev]) continue;
     best = s;
   }
-  if (opt >= 2) return (a->K % (128 * opt) == 0 && a->K / opt >= 256 && (long long)opt * a->M * a->N * 4 <= g_splitk_ws_bytes[dev]) ? opt : 0;
+  if (opt >= 2) return (a->K % (128 * opt) == 0 && a->K / opt >= 256 && (long long)opt * rows * a->N * 4 <= g_splitk_ws_bytes[dev]) ? opt : 0;
   return (tiles <= 96 && a->K >= 12288) ? best : 0;      // (K = 8192: two slices of 72 tiles lose 3 %: profiles/r05_gemm_splitk_ab.log)
 }
 
-static int gemm_splitk(const drag_gemm_args* a, int S, void* stream) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  drag_gemm_args v{};
-  v.A = a->A; v.W = a->W; v.C = g_splitk_ws[dev];
-  v.M = S * a->M; v.N = a->N; v.K = a->K / S;
-  v.lda = a->lda; v.a_rows_per_batch = a->M; v.a_batch_stride = a->K / S;
-  v.ldc = a->N; v.c_rows_per_batch = a->M; v.c_batch_stride = (long long)a->M * a->N;
-  v.out_f32 = 1;
-  if (int rc = gemm_launch(&v, nullptr, stream, a->K)) return rc;
+static int splitk_reduce(const drag_gemm_args* a, int S, int slice_rows, int row0, const float* part, void* stream) {
   SplitReduceArgs r{};
-  r.part = (const float*)g_splitk_ws[dev]; r.C = (bf16_t*)a->C;
+  r.part = part; r.slice_rows = slice_rows; r.row0 = row0; r.C = (bf16_t*)a->C;
   r.bias = (const bf16_t*)a->bias; r.gate = (const bf16_t*)a->gate; r.resid = (const bf16_t*)a->resid;
   r.S = S; r.M = a->M; r.N = a->N; r.ldg = a->ldg;
   r.cm.rpb = a->c_rows_per_batch > 0 ? a->c_rows_per_batch : a->M; r.cm.bs = a->c_batch_stride; r.cm.ld = a->ldc;
@@ -1838,16 +1846,33 @@ static int gemm_splitk(const drag_gemm_args* a, int S, void* stream) {
   return 0;
 }
 
+// b != nullptr: a pair (same N, K, row stride of A): ONE partial launch over S x (M_a + M_b) rows, one reduce pass per problem
+static int gemm_splitk(const drag_gemm_args* a, const drag_gemm_args* b, int S, void* stream) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int rows = a->M + (b ? b->M : 0);
+  drag_gemm_args v{};
+  v.A = a->A; v.W = a->W; v.C = g_splitk_ws[dev];
+  v.M = S * rows; v.N = a->N; v.K = a->K / S;
+  v.lda = a->lda; v.a_rows_per_batch = rows; v.a_batch_stride = a->K / S;
+  v.ldc = a->N; v.c_rows_per_batch = rows; v.c_batch_stride = (long long)rows * a->N;
+  v.out_f32 = 1;
+  if (int rc = gemm_launch(&v, nullptr, stream, a->K, b)) return rc;
+  if (int rc = splitk_reduce(a, S, rows, 0, (const float*)g_splitk_ws[dev], stream)) return rc;
+  return b ? splitk_reduce(b, S, rows, a->M, (const float*)g_splitk_ws[dev], stream) : 0;
+}
+
 extern "C" int drag_gemm_bf16(const drag_gemm_args* a, void* stream) {
   if (a != nullptr && a->A && a->W && a->C && a->M > 0 && a->N > 0 && a->K > 0) {
     if (const int S = splitk_slices(a)) {
       DRAG_CHECK(!(a->gate && !a->resid), "drag_gemm_bf16: gate needs resid");
-      return gemm_splitk(a, S, stream);
+      return gemm_splitk(a, nullptr, S, stream);
     }
   }
   return gemm_launch(a, nullptr, stream);
 }
 extern "C" int drag_gemm_bf16_splitk_slices(const drag_gemm_args* a) { return a ? splitk_slices(a) : 0; }
+extern "C" int drag_gemm_bf16_pair_splitk_slices(const drag_gemm_args* a, const drag_gemm_args* b) { return a && b ? splitk_slices(a, b) : 0; }
 #if DRAG_EXP
 extern "C" int drag_debug_w4_stamps(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w4_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
@@ -1897,8 +1922,15 @@ extern "C" int drag_gemm_bf16_pair(const drag_gemm_args* a, const drag_gemm_args
   DRAG_CHECK(a->C2 == nullptr && b->C2 == nullptr, "drag_gemm_bf16_pair: no two-destination outputs");
   DRAG_CHECK((a->gate != nullptr) == (b->gate != nullptr) && (a->resid != nullptr) == (b->resid != nullptr) && (a->bias != nullptr) == (b->bias != nullptr),
              "drag_gemm_bf16_pair: the two problems must have the same epilogue operands");
-  // (a pair whose problems would each split K by policy — the double blocks' ff down-projections at batch 1 — stays a pair: two split
-  //  launches are 4 % faster alone and 1.2 % of configs[1] slower in the pipeline: profiles/r05_gemm_splitk_pairs_in_configs1.log)
+  // a pair of few tiles and a long K (the double blocks' ff down-projections at batch 1: (1024 + 512) x 3072 x 12 288) splits as ONE partial
+  // launch over both problems' rows + a reduce pass each: 150 -> 112 us alone, configs[1] 103.6 -> 102.7 ms.  (Two separately split launches
+  // were 4 % faster than the merged pair alone and 1.2 % of configs[1] slower in the pipeline: profiles/r05_gemm_splitk_pairs_in_configs1.log.)
+  if (a->A && a->W && a->C && b->A && b->W && b->C && a->M > 0 && b->M > 0 && a->N > 0 && a->K > 0) {
+    if (const int S = splitk_slices(a, b)) {
+      DRAG_CHECK(!(a->gate && !a->resid), "drag_gemm_bf16_pair: gate needs resid");
+      return gemm_splitk(a, b, S, stream);
+    }
+  }
   if (!drag_gemm_bf16_pair_merges(a->M, b->M, a->N, a->K)) {
     if (int rc = gemm_launch(a, nullptr, stream)) return rc;
     return gemm_launch(b, nullptr, stream);

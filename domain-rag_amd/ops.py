@@ -243,7 +243,13 @@ def gemm_pair(first: dict, second: dict):
         raise ValueError(f"gemm_pair: the two problems must share N and K (got {s1} and {s2})")
     if (a1.act, a1.act_n0, a1.out_f32) != (a2.act, a2.act_n0, a2.out_f32):
         raise ValueError("gemm_pair: the two problems must share activation, act_n0 and output type")
-    if lib.drag_gemm_bf16_pair_merges(s1[0], s2[0], s1[1], s1[2]):
+    if first["a"].is_cuda and first["a"].device.index not in _gemm_workspaces and not torch.cuda.is_current_stream_capturing():
+        gemm_workspace(first["a"].device)
+    slices = lib.drag_gemm_bf16_pair_splitk_slices(ctypes.byref(a1), ctypes.byref(a2))
+    if slices:                   # one partial launch over both problems' rows + a reduce pass each (one recorded interval)
+        _recorded(lambda: check(lib.drag_gemm_bf16_pair(ctypes.byref(a1), ctypes.byref(a2), _stream()), "drag_gemm_bf16_pair"),
+                  (s1[0] + s2[0], s1[1], s1[2]), ("splitk", slices))
+    elif lib.drag_gemm_bf16_pair_merges(s1[0], s2[0], s1[1], s1[2]):
         _recorded(lambda: check(lib.drag_gemm_bf16_pair(ctypes.byref(a1), ctypes.byref(a2), _stream()), "drag_gemm_bf16_pair"),
                   (s1[0] + s2[0], s1[1], s1[2]), ("pair", s1[0], s2[0]))
     else:       # two launches (what the library would issue itself), accounted one by one

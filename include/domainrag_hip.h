@@ -115,6 +115,9 @@ int64_t drag_gemm_bf16_cost(int M1, int M2, int N, int K);
 int drag_gemm_set_workspace(void* ptr, int64_t bytes);
 /* the slices drag_gemm_bf16 would use for these arguments right now (0: one launch, not split) — host-only, for callers that account launches */
 int drag_gemm_bf16_splitk_slices(const drag_gemm_args* args);
+/* the same for drag_gemm_bf16_pair(a, b): a pair that splits runs ONE partial launch over both problems' rows (same row stride of A required)
+ * and one reduce pass per problem */
+int drag_gemm_bf16_pair_splitk_slices(const drag_gemm_args* a, const drag_gemm_args* b);
 
 /* ---------------------------------------------------------------------------------------
  * drag_conv3x3_bf16 — 3x3 convolution as an implicit GEMM on the same MFMA main loop.

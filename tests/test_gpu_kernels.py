@@ -1123,3 +1123,37 @@ def test_gemm_split_k_equals_one_launch_to_the_last_bf16_bit_or_so(gpu, M, N, K,
             e_ref, e_got = (x.double() - exact[i]).abs().max(), (y.double() - exact[i]).abs().max()
             assert e_got <= 1.05 * e_ref + 1e-3, (i, float(e_ref), float(e_got))
 
+
+@pytest.mark.parametrize("M1,M2,N,K", [(1024, 512, 3072, 12288), (256, 768, 512, 12288)])
+def test_gemm_pair_split_k_is_one_partial_launch_over_both_problems(gpu, M1, M2, N, K):
+    """round 5: a pair of few tiles and a long K (the double blocks' ff down-projections at batch 1) runs as ONE launch over S x (M1 + M2)
+    stacked rows — the rows behind M1 of every K slice read the second problem's A and W — and one reduce pass per problem with its own
+    bias / gate / residual / destination.  Against the pair with "gemm_splitk" = 1 (same bits as two plain launches): within one bf16 ulp
+    of the larger term; against float64: no further away; each problem's epilogue operands stay its own"""
+    import ctypes
+    from domain_rag_amd import _lib, ops
+    def prob(M, seed):
+        return dict(a=_randn((M, K), seed).to(gpu), w=_randn((N, K), seed + 1, 0.05).to(gpu), bias=_randn((N,), seed + 2).to(gpu),
+                    gate=_randn((1, N), seed + 3).to(gpu), resid=_randn((M, N), seed + 4).to(gpu), ldg=N, c_rows_per_batch=M, c_batch_stride=M * N)
+    p1, p2 = prob(M1, 61), prob(M2, 71)
+
+    def run():
+        o1, o2 = ops.gemm_pair(dict(p1, out=torch.empty(M1, N, dtype=torch.bfloat16, device=gpu)), dict(p2, out=torch.empty(M2, N, dtype=torch.bfloat16, device=gpu)))
+        return o1.cpu(), o2.cpu()
+    try:
+        ops.gemm(p1["a"][:256], p1["w"][:256])            # (registers the workspace)
+        ops.set_option("gemm_splitk", 1); ref = run()
+        ops.set_option("gemm_splitk", 0); got = run()
+        a1, _, _ = ops._gemm_args(p1["a"], p1["w"], None, None, ops.ACT_NONE, 0, None, None, False, None, 0, 0, None, 0, 0, None, 0, None, 0, 0)
+        a2, _, _ = ops._gemm_args(p2["a"], p2["w"], None, None, ops.ACT_NONE, 0, None, None, False, None, 0, 0, None, 0, 0, None, 0, None, 0, 0)
+        assert _lib.load().drag_gemm_bf16_pair_splitk_slices(ctypes.byref(a1), ctypes.byref(a2)) >= 2
+    finally:
+        ops.set_option("gemm_splitk", 0)
+    for (x, y, pr) in ((ref[0], got[0], p1), (ref[1], got[1], p2)):
+        v64 = pr["a"].double() @ pr["w"].double().T + pr["bias"].double()
+        exact = (pr["resid"].double() + pr["gate"].double() * v64).cpu()
+        d = (x.float() - y.float()).abs()
+        tol = (torch.maximum(x.float().abs(), y.float().abs()) + pr["resid"].float().abs().cpu()) * 2.0 ** -6 + 1e-4
+        assert torch.isfinite(y.float()).all() and (d <= tol).all(), float((d / tol).max())
+        assert (x.double() - exact).abs().max() * 1.05 + 1e-2 >= (y.double() - exact).abs().max()
+
