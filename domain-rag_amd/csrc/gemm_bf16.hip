@@ -1774,27 +1774,30 @@ struct SplitReduceArgs {
   int S, M, N, ldg;
   RowMap cm;
 };
-// one thread = four consecutive columns of one row: v = bias + sum over the slices in order; then epi_row's forms
+// one thread = four consecutive columns of one row: v = bias + sum over the slices in order; then epi_row's forms.  Every load of the thread —
+// S partial quads, bias, gate, residual — is issued before the first add (S is a template parameter: with a run-time loop the compiler
+// waited for slice s before requesting s + 1: 28 us for the 75 MB of a (1536, 3072) x 3 launch, a third of the HBM rate)
+template <int S>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs p) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N / 4;
   if (i >= (long long)p.M * n4) return;
   const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
-  f32x4_t v = *(const f32x4_t*)(p.part + (long long)(p.row0 + m) * p.N + n);
-  for (int s = 1; s < p.S; ++s) {
-    const f32x4_t t = *(const f32x4_t*)(p.part + ((long long)s * p.slice_rows + p.row0 + m) * p.N + n);
-    v += t;
-  }
-  if (p.bias) {
-    const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
-    v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
-  }
+  f32x4_t part[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) part[s] = __builtin_nontemporal_load((const f32x4_t*)(p.part + ((long long)s * p.slice_rows + p.row0 + m) * p.N + n));
   const long long coff = p.cm.off(m) + n;
+  u32x2_t bb = {0u, 0u}, rr = {0u, 0u}, gg = {0u, 0u};
+  if (p.bias) bb = *(const u32x2_t*)(p.bias + n);
+  if (p.resid) rr = *(const u32x2_t*)(p.resid + coff);
+  if (p.gate) gg = *(const u32x2_t*)(p.gate + (long long)(m / p.cm.rpb) * p.ldg + n);
+  f32x4_t v = part[0];
+#pragma unroll
+  for (int s = 1; s < S; ++s) v += part[s];
+  if (p.bias) { v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]); }
   if (p.resid) {
-    const u32x2_t rr = *(const u32x2_t*)(p.resid + coff);
     const float x[4] = {bf_lo(rr[0]), bf_hi(rr[0]), bf_lo(rr[1]), bf_hi(rr[1])};
     if (p.gate) {      // diffusers: x + gate * y with y, gate, x bf16 tensors: y rounded first, the product rounded, then the sum
-      const u32x2_t gg = *(const u32x2_t*)(p.gate + (long long)(m / p.cm.rpb) * p.ldg + n);
       const float g[4] = {bf_lo(gg[0]), bf_hi(gg[0]), bf_lo(gg[1]), bf_hi(gg[1])};
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * rbf(v[r]));
@@ -1830,7 +1833,7 @@ static int splitk_slices(const drag_gemm_args* a, const drag_gemm_args* b = null
     if ((long long)s * rows * a->N * 4 > g_splitk_ws_bytes[dev]) continue;
     best = s;
   }
-  if (opt >= 2) return (a->K % (128 * opt) == 0 && a->K / opt >= 256 && (long long)opt * rows * a->N * 4 <= g_splitk_ws_bytes[dev]) ? opt : 0;
+  if (opt >= 2) return (opt <= 8 && a->K % (128 * opt) == 0 && a->K / opt >= 256 && (long long)opt * rows * a->N * 4 <= g_splitk_ws_bytes[dev]) ? opt : 0;
   return (tiles <= 96 && a->K >= 12288) ? best : 0;      // (K = 8192: two slices of 72 tiles lose 3 %: profiles/r05_gemm_splitk_ab.log)
 }
 
@@ -1841,7 +1844,13 @@ static int splitk_reduce(const drag_gemm_args* a, int S, int slice_rows, int row
   r.S = S; r.M = a->M; r.N = a->N; r.ldg = a->ldg;
   r.cm.rpb = a->c_rows_per_batch > 0 ? a->c_rows_per_batch : a->M; r.cm.bs = a->c_batch_stride; r.cm.ld = a->ldc;
   const long long n = (long long)a->M * (a->N / 4);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
+  const dim3 g((unsigned)((n + 255) / 256));
+  switch (S) {
+#define DRAG_RED(S_) case S_: hipLaunchKernelGGL(splitk_reduce_kernel<S_>, g, dim3(256), 0, (hipStream_t)stream, r); break
+    DRAG_RED(2); DRAG_RED(3); DRAG_RED(4); DRAG_RED(5); DRAG_RED(6); DRAG_RED(7); DRAG_RED(8);
+#undef DRAG_RED
+    default: DRAG_CHECK(false, "drag_gemm_bf16: 2 ... 8 K slices");
+  }
   DRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -1,4 +1,6 @@
-"""configs[1] (graph replay, as bench.py's side field runs it): split-K never | single launches only (pairs stay merged) | pairs too — interleaved in one process"""
+"""configs[1] (graph replay, as bench.py's side field runs it): split-K never | single launches only (pairs stay merged) | pairs too — interleaved in one process.
+The middle mode needs a library whose drag_gemm_bf16_pair honours DRAG_SPLITK_KEEP_PAIRS (a measurement build of round 5: profiles/r05_gemm_splitk_pairs_in_configs1.log);
+with the committed library it equals the third."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
