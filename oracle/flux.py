@@ -109,14 +109,36 @@ def ln(x):
 
 
 # --------------------------------------------------------------------------- blocks
+def adaln_zero(p, name, temb, x):
+    """AdaLayerNormZero: Linear(SiLU(temb)) -> six chunks in the order (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp,
+    gate_mlp); returns (LN(x) * (1 + scale_msa) + shift_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp).  Pinned against the
+    importable upstream twin `transformers...qwen2_5_omni.Qwen2_5_OmniAdaLayerNormZero` (tests/test_oracle_upstream_twins.py)."""
+    mod = _lin(F.silu(temb), p, name)
+    sh_msa, sc_msa, g_msa, sh_mlp, sc_mlp, g_mlp = mod.chunk(6, dim=1)
+    return ln(x) * (1 + sc_msa[:, None]) + sh_msa[:, None], g_msa, sh_mlp, sc_mlp, g_mlp
+
+
+def gated_mlp_residual(p, ff, x, attn_out, g_msa, sh_mlp, sc_mlp, g_mlp):
+    """the half of a double-stream block behind its attention: x += gate_msa * attn; x += gate_mlp * FF(LN(x) * (1 + scale_mlp)
+    + shift_mlp) with FF = Linear -> GELU(tanh) -> Linear.  Twin: qwen2_5_omni `DiTDecoderLayer.forward` behind `self.attn`."""
+    x = x + g_msa[:, None] * attn_out
+    n2 = ln(x) * (1 + sc_mlp[:, None]) + sh_mlp[:, None]
+    h = _lin(F.gelu(_lin(n2, p, ff + "net.0.proj"), approximate="tanh"), p, ff + "net.2")
+    return x + g_mlp[:, None] * h
+
+
+def adaln_continuous(p, name, temb, x):
+    """AdaLayerNormContinuous (norm_out): Linear(SiLU(temb)) -> (scale, shift) in THAT order.  Twin: qwen2_5_omni
+    `Qwen2_5_OmniAdaLayerNormZero_Final`."""
+    mod = _lin(F.silu(temb), p, name)
+    scale, shift = mod.chunk(2, dim=1)
+    return ln(x) * (1 + scale)[:, None] + shift[:, None]
+
+
 def double_block(p, pre, cfg, hs, ehs, temb, cos, sin):
     H = cfg.num_attention_heads
-    mod = _lin(F.silu(temb), p, pre + "norm1.linear")
-    sh_msa, sc_msa, g_msa, sh_mlp, sc_mlp, g_mlp = mod.chunk(6, dim=1)
-    cmod = _lin(F.silu(temb), p, pre + "norm1_context.linear")
-    csh_msa, csc_msa, cg_msa, csh_mlp, csc_mlp, cg_mlp = cmod.chunk(6, dim=1)
-    n_hs = ln(hs) * (1 + sc_msa[:, None]) + sh_msa[:, None]
-    n_ehs = ln(ehs) * (1 + csc_msa[:, None]) + csh_msa[:, None]
+    n_hs, g_msa, sh_mlp, sc_mlp, g_mlp = adaln_zero(p, pre + "norm1.linear", temb, hs)
+    n_ehs, cg_msa, csh_mlp, csc_mlp, cg_mlp = adaln_zero(p, pre + "norm1_context.linear", temb, ehs)
 
     q = rms_norm(_heads(_lin(n_hs, p, pre + "attn.to_q"), H), p[pre + "attn.norm_q.weight"])
     k = rms_norm(_heads(_lin(n_hs, p, pre + "attn.to_k"), H), p[pre + "attn.norm_k.weight"])
@@ -133,15 +155,8 @@ def double_block(p, pre, cfg, hs, ehs, temb, cos, sin):
     o = _lin(o, p, pre + "attn.to_out.0")
     eo = _lin(eo, p, pre + "attn.to_add_out")
 
-    hs = hs + g_msa[:, None] * o
-    n2 = ln(hs) * (1 + sc_mlp[:, None]) + sh_mlp[:, None]
-    ff = _lin(F.gelu(_lin(n2, p, pre + "ff.net.0.proj"), approximate="tanh"), p, pre + "ff.net.2")
-    hs = hs + g_mlp[:, None] * ff
-
-    ehs = ehs + cg_msa[:, None] * eo
-    cn2 = ln(ehs) * (1 + csc_mlp[:, None]) + csh_mlp[:, None]
-    cff = _lin(F.gelu(_lin(cn2, p, pre + "ff_context.net.0.proj"), approximate="tanh"), p, pre + "ff_context.net.2")
-    ehs = ehs + cg_mlp[:, None] * cff
+    hs = gated_mlp_residual(p, pre + "ff.", hs, o, g_msa, sh_mlp, sc_mlp, g_mlp)
+    ehs = gated_mlp_residual(p, pre + "ff_context.", ehs, eo, cg_msa, csh_mlp, csc_mlp, cg_mlp)
     return ehs, hs
 
 
@@ -203,10 +218,7 @@ def flux_forward(p: dict, cfg: FluxConfig, hidden, enc, pooled, timestep, img_id
         if taps is not None:
             taps[f"single.{i}"] = x
     x = x[:, enc.shape[1]:]
-    mod = _lin(F.silu(temb), p, "norm_out.linear")
-    scale, shift = mod.chunk(2, dim=1)
-    x = ln(x) * (1 + scale)[:, None] + shift[:, None]
-    return _lin(x, p, "proj_out")
+    return _lin(adaln_continuous(p, "norm_out.linear", temb, x), p, "proj_out")
 
 
 # --------------------------------------------------------------------------- scheduler

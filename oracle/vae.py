@@ -5,7 +5,8 @@ Restates diffusers 0.33.1 ``AutoencoderKL.encode/decode`` (Encoder/Decoder/UNetM
 ResnetBlock2D/Attention/Upsample2D/Downsample2D), ``DiagonalGaussianDistribution``,
 ``FluxPipeline._pack_latents/_unpack_latents``, ``FluxFillPipeline.prepare_mask_latents`` and
 ``VaeImageProcessor`` — un-vendored; anchored on pipe(...) batch_generate_flux_kshot.py:467-474 and
-pipe_fill(...) outpainting_updown_sampling_redux.py:1246-1257.  PARITY UNPINNED (no reference tests).
+pipe_fill(...) outpainting_updown_sampling_redux.py:1246-1257.  Not pinned on the reference (it holds no tests); the blocks and both stacks ARE pinned on their importable upstream twins
+(transformers JanusVQVAE*, tests/test_oracle_upstream_twins.py).
 """
 from __future__ import annotations
 
