@@ -19,16 +19,16 @@ UPSTREAM TWINS (round 6; tests/test_oracle_upstream_twins.py — CPU, shared ran
 diffusers cannot be imported here, but `transformers` ships code of the same lineage with the same arithmetic:
 
   oracle lines                                   twin (transformers 5.x, importable here)                       bar
-  vae.py  resnet()                    :26-31     janus JanusVQVAEResnetBlock (GroupNorm-32 eps 1e-6, swish,     2e-5 rel (fp32; F.silu vs x*sigmoid(x))
+  vae.py  resnet()                    :27-32     janus JanusVQVAEResnetBlock (GroupNorm-32 eps 1e-6, swish,     2e-5 rel (fp32; F.silu vs x*sigmoid(x))
                                                  3x3 convs, 1x1 shortcut)
-  vae.py  mid_attention()             :34-43     janus JanusVQVAEAttnBlock (single head, scale C^-0.5,          2e-5 rel (SDPA vs bmm + softmax)
+  vae.py  mid_attention()             :35-44     janus JanusVQVAEAttnBlock (single head, scale C^-0.5,          2e-5 rel (SDPA vs bmm + softmax)
                                                  residual; 1x1 convs = the Linear weights)
-  vae.py  decode() up-sample          :56-57     janus JanusVQVAEConvUpsample (nearest 2x, conv pad 1)          bit-exact
-  vae.py  encode_moments() down-sample:69-70     janus JanusVQVAEConvDownsample (pad (0,1,0,1), stride 2)       bit-exact
-  vae.py  decode() whole stack        :46-59     janus JanusVQVAEDecoder, also at the Flux VAE's own plan       5e-5 rel
+  vae.py  decode() up-sample          :57-58     janus JanusVQVAEConvUpsample (nearest 2x, conv pad 1)          bit-exact
+  vae.py  encode_moments() down-sample:70-71     janus JanusVQVAEConvDownsample (pad (0,1,0,1), stride 2)       bit-exact
+  vae.py  decode() whole stack        :47-60     janus JanusVQVAEDecoder, also at the Flux VAE's own plan       5e-5 rel
                                                  (1, 2, 4, 4) x 2 resnets (+1 in the decoder); the twin's
                                                  extra level attention silenced by a zero proj_out
-  vae.py  encode_moments() whole stack:62-76     janus JanusVQVAEEncoder (double_latent: mean | logvar)         5e-5 rel
+  vae.py  encode_moments() whole stack:63-76     janus JanusVQVAEEncoder (double_latent: mean | logvar)         5e-5 rel
   flux.py rms_norm()                             t5 T5LayerNorm, fp32 and bf16                                  bit-exact
   flux.py apply_rope()                           gptj apply_rotary_pos_emb + rotate_every_two                   bit-exact (fp32; bf16 via the float copy)
   flux.py rope_tables() (per axis)               gptj create_sinusoidal_positions                               2e-5 abs (twin is float32, oracle float64)
