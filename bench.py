@@ -468,6 +468,25 @@ def run_generate(args, d: Dist):
     dn, dms, dfl = bk.get(dom, (0, 0.0, 0.0))
     traffic, traffic_src = _pmc_traffic({"gemm_bf16_w4p": "gemm_bf16_w4p", "gemm_bf16_t256<0>": "gemm_bf16_t256ILi0"}.get(dom, dom))
     achieved = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+    # the second-hottest kernel (a quarter of the step): the attention launches of the same sampled steps, bracketed the same way
+    ak = rec.attention_by_kernel()
+    adom = max(ak, key=lambda k: ak[k][1]) if ak else None
+    attention = None
+    if adom is not None:
+        an, ams, afl = ak[adom]
+        a_ach = afl / (ams * 1e-3) / 1e12 if ams > 0 else 0.0
+        attention = {"kernel": adom, "launches_timed": an, "avg_launch_ms": ams / max(an, 1), "achieved": a_ach, "peak": MFMA_BF16_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": a_ach / MFMA_BF16_PEAK_TF,
+                     "flops_per_launch": afl / max(an, 1),
+                     "note": "algorithmic 4 S^2 128 flops per (batch, head) / event-bracketed launch time on the launch stream; the fused q "
+                             "preparation (RMSNorm + RoPE of the query rows) runs inside the same launch and is not counted as flops",
+                     "all_kernels": {k: {"launches": v[0], "avg_launch_ms": v[1] / max(v[0], 1),
+                                         "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in ak.items()}}
+    pw = power.summary()
+    if pw is not None and pw.get("socket_w_mean"):
+        # energy of the timed region on rank 0's GPU: mean socket power x the region's seconds / the images this GPU produced
+        pw["joules_per_image"] = pw["socket_w_mean"] * dt / (args.steps * args.batch)
+        pw["joules_note"] = "mean sampled socket W x timed seconds / images of this GPU (rank 0); whole pipeline, idle gaps included"
     out = {
         "metric": f"composited images/sec @{args.res}^2, {args.denoise_steps} Flux-Redux steps", "value": images / dt, "unit": "images/s",
         "n_gpus": d.world, "rccl_ranks": d.rccl_ranks if d.rccl_ranks is not None else 1, "steps": args.steps, "warmup": args.warmup,
@@ -492,7 +511,8 @@ def run_generate(args, d: Dist):
                                                                   "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0}
                                                               for k, v in bk.items()}},
                      "e2e_mfma_frac": job.flops_per_image() * images / d.world / dt / (MFMA_BF16_PEAK_TF * 1e12),
-                     "mfma_util_pmc": _pmc_mfma_util(), "power": power.summary()},
+                     "attention": attention,
+                     "mfma_util_pmc": _pmc_mfma_util(), "power": pw},
     }
     if not args.no_side_configs and d.world == 1:
         del job

@@ -1224,6 +1224,22 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
                             const void* wq_txt, const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt,
                             float eps, void* stream, bool vrow = false);
 
+// which kernel family a call of S keys takes (one policy for the launch and for drag_attention_bf16_choice)
+static void attention_family(int32_t S, bool vrow, bool& w8, bool& q64) {
+  w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
+  // "attn_q64": 0 = policy (the 4-wave x 64-query kernel for S >= 4096, where it is 4-5 % ahead; below that its 256-query blocks fill
+  // the chip worse: S = 1753 911 vs 982 TFLOP/s), 1 = whenever S >= 1024, 2 = never (the 8-wave / 4-wave x 32-query family: measurements, tests)
+  const int q64opt = drag_opt(DRAG_OPT_ATTN_Q64);
+  q64 = !vrow && q64opt != 2 && ((q64opt == 1 && S >= 1024) || (q64opt == 0 && w8 && (!DRAG_EXP || drag_opt(DRAG_OPT_ATTN_PERSIST) == 0)));
+}
+
+// 64 = attention_q64_kernel, 8 / 4 = attention_d128_kernel<8 | 4 waves, ...> — for callers that account launches per kernel (bench.py)
+extern "C" int drag_attention_bf16_choice(int32_t S, int32_t v_row_major) {
+  bool w8, q64;
+  attention_family(S, v_row_major != 0, w8, q64);
+  return q64 ? 64 : (w8 ? 8 : 4);
+}
+
 extern "C" int drag_attention_bf16(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t S,
                                    int32_t H, int32_t ld_qk, int64_t qk_batch_stride, int32_t ld_o,
                                    int64_t o_batch_stride, float scale, void* stream) {
@@ -1297,11 +1313,8 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
   const bool fits32 = kall < (1ll << 32) && vall < (1ll << 32);
   p.k_bytes_all = fits32 ? (unsigned)kall : 0u; p.vt_bytes_all = fits32 ? (unsigned)vall : 0u;
   const int groups = (B * H + 7) / 8;
-  const bool w8 = !drag_opt(DRAG_OPT_ATTN_W4) && S >= 4096;     // 8-wave blocks halve the DMA issue per wave; below ~4k keys 128-query blocks balance better (S=1753: 945 vs 843 TFLOP/s)
-  // "attn_q64": 0 = policy (the 4-wave x 64-query kernel for S >= 4096, where it is 4-5 % ahead; below that its 256-query blocks fill
-  // the chip worse: S = 1753 911 vs 982 TFLOP/s), 1 = whenever S >= 1024, 2 = never (the 8-wave / 4-wave x 32-query family: measurements, tests)
-  const int q64opt = drag_opt(DRAG_OPT_ATTN_Q64);
-  const bool q64 = !vrow && q64opt != 2 && ((q64opt == 1 && S >= 1024) || (q64opt == 0 && w8 && (!DRAG_EXP || drag_opt(DRAG_OPT_ATTN_PERSIST) == 0)));
+  bool w8, q64;
+  attention_family(S, vrow, w8, q64);
   const int QB = (w8 || q64) ? 256 : 128;
   const int nqb2 = (S + QB - 1) / QB;
   const dim3 grid(8 * groups * nqb2);

@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
   unsigned soff = 0;
   // the workgroup's first tile: K-steps 0 and 1 into the two stage buffers (every later tile finds them staged by its predecessor's tail)
   asm volatile(G4W_D_STAGE0_NOWAIT : [soff] "+s"(soff)
-               : "{v[128:143]}"(cur.vo), [rsa] "s"(cur.rsA), [rsw] "s"(cur.rsW), [ldsw] "s"(ldsw) : "scc", "memory");
+               : "{v[128:143]}"(cur.vo), [rsa] "s"(cur.rsA), [rsw] "s"(cur.rsW), [ldsw] "s"(ldsw) : "scc", "m0", "memory");
   int stores_behind = 0;
   [[maybe_unused]] int tile_no = 0;
   for (;;) {
@@ -1941,8 +1941,10 @@ extern "C" int drag_gemm_bf16_pair(const drag_gemm_args* a, const drag_gemm_args
     }
   }
   if (!drag_gemm_bf16_pair_merges(a->M, b->M, a->N, a->K)) {
-    if (int rc = gemm_launch(a, nullptr, stream)) return rc;
-    return gemm_launch(b, nullptr, stream);
+    // two launches: each through drag_gemm_bf16, i.e. under the SAME policy (split-K included) a caller issuing them one by one gets —
+    // domain-rag_amd/ops.py gemm_pair does exactly that to account them separately, and the two APIs must give the same bits
+    if (int rc = drag_gemm_bf16(a, stream)) return rc;
+    return drag_gemm_bf16(b, stream);
   }
   return gemm_launch(a, b, stream);
 }

@@ -29,6 +29,7 @@ class GemmRecorder:
         self.events = []
         self.shapes = []
         self.is_conv = []
+        self.attn = []              # (start, end, flops, kernel name) of the bf16 attention launches of the sampled steps
 
     def totals(self):
         torch.cuda.synchronize()
@@ -64,6 +65,15 @@ class GemmRecorder:
         agg: dict = {}
         for (s, e, f), shp, cv in zip(self.events, self.shapes, self.is_conv):
             a = agg.setdefault(self.kernel_of(shp, cv), [0, 0.0, 0.0])
+            a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f
+        return agg
+
+    def attention_by_kernel(self):
+        """{kernel name: (launches, total_ms, flops)} of the recorded drag_attention*_bf16 launches"""
+        torch.cuda.synchronize()
+        agg: dict = {}
+        for s, e, f, name in self.attn:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f
         return agg
 
@@ -172,7 +182,44 @@ def _recorded(call, shape, kind=False):
     _recorder.is_conv.append(kind)
 
 
+def _recorded_attention(call, B, S, H, qprep, vrow):
+    """run one head_dim-128 attention launch, bracketed by events when a recorder is installed (4 S^2 128 flops per batch and head:
+    q k^T and p v; the kernel name from the library's own dispatch, ``drag_attention_bf16_choice``)"""
+    if _recorder is None:
+        call()
+        return
+    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_ev.record()
+    call()
+    e_ev.record()
+    fam = _lib.load().drag_attention_bf16_choice(S, int(vrow))
+    q = "true" if qprep else "false"
+    name = f"attention_q64_kernel<{q}>" if fam == 64 else f"attention_d128_kernel<{fam}, ..., {q}, ...>"
+    _recorder.attn.append((s_ev, e_ev, 4.0 * S * S * 128 * H * B, name))
+
+
 _gemm_workspaces: dict[int, torch.Tensor] = {}
+_retired_workspaces: list[torch.Tensor] = []      # replaced workspaces stay alive: captured graphs may still hold their addresses
+_workspace_stream: dict[int, int] = {}            # device -> the stream whose launches last used the workspace
+
+
+def _workspace_guard(a: torch.Tensor) -> None:
+    """the library picks the workspace of hipGetDevice() and one buffer serves every stream of a device: refuse a launch whose operands
+    live on another device than the current one, and order a launch on a NEW stream behind the previous stream's work (split launches
+    on two streams would otherwise race on the partial sums).  Nothing is recorded during capture: a graph is one stream's work."""
+    idx = a.device.index
+    if idx != torch.cuda.current_device():
+        raise RuntimeError(f"gemm: operands on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()} "
+                           "(the library launches on — and takes the split-K workspace of — the current device)")
+    if torch.cuda.is_current_stream_capturing():
+        return
+    st = torch.cuda.current_stream()
+    last = _workspace_stream.get(idx)
+    if last is not None and last != st.cuda_stream:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(last, device=a.device) if last != 0 else torch.cuda.default_stream(a.device))
+        st.wait_event(ev)
+    _workspace_stream[idx] = st.cuda_stream
 
 
 def gemm_workspace(device: torch.device, mbytes: int | None = None) -> None:
@@ -185,6 +232,13 @@ def gemm_workspace(device: torch.device, mbytes: int | None = None) -> None:
     if mbytes is None:
         mbytes = int(os.environ.get("DRAG_GEMM_WORKSPACE_MB", "64"))
     lib = _lib.load()
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("gemm_workspace: not during stream capture (the buffer must outlive the graph: register it before capturing)")
+    old = _gemm_workspaces.get(idx)
+    if old is not None and old.numel() > 0:
+        # a hipGraph captured while `old` was registered replays launches that hold its address (flux.forward_graphed): the buffer is
+        # retired, not freed — a re-registration costs memory, never a use-after-free on replay
+        _retired_workspaces.append(old)
     with torch.cuda.device(idx):
         if mbytes <= 0:
             _gemm_workspaces[idx] = torch.empty(0, dtype=torch.uint8, device=device)
@@ -207,6 +261,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, *, b
     lib = _lib.load()
     if a.is_cuda and a.device.index not in _gemm_workspaces and not torch.cuda.is_current_stream_capturing():
         gemm_workspace(a.device)
+    if a.is_cuda:
+        _workspace_guard(a)
     args, out, shape = _gemm_args(a, w, out, bias, act, act_n0, gate, resid, out_f32, M, a_rows_per_batch, a_batch_stride, lda,
                                   c_rows_per_batch, c_batch_stride, ldc, ldg, out2, ldc2, n_split)
     slices = lib.drag_gemm_bf16_splitk_slices(ctypes.byref(args)) if _recorder is not None else 0
@@ -245,6 +301,8 @@ def gemm_pair(first: dict, second: dict):
         raise ValueError("gemm_pair: the two problems must share activation, act_n0 and output type")
     if first["a"].is_cuda and first["a"].device.index not in _gemm_workspaces and not torch.cuda.is_current_stream_capturing():
         gemm_workspace(first["a"].device)
+    if first["a"].is_cuda:
+        _workspace_guard(first["a"])
     slices = lib.drag_gemm_bf16_pair_splitk_slices(ctypes.byref(a1), ctypes.byref(a2))
     if slices:                   # one partial launch over both problems' rows + a reduce pass each (one recorded interval)
         _recorded(lambda: check(lib.drag_gemm_bf16_pair(ctypes.byref(a1), ctypes.byref(a2), _stream()), "drag_gemm_bf16_pair"),
@@ -276,8 +334,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     lib = _lib.load()
     _need(q, torch.bfloat16, "q")
     _need(out, torch.bfloat16, "out")
-    check(lib.drag_attention_bf16(_p(q), _p(k), _p(vt), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o,
-                                  o_batch_stride, scale, _stream()), "drag_attention_bf16")
+    _recorded_attention(lambda: check(lib.drag_attention_bf16(_p(q), _p(k), _p(vt), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o,
+                                                              o_batch_stride, scale, _stream()), "drag_attention_bf16"), B, S, H, False, False)
 
 
 def k_norm_rope_vt(qkv: torch.Tensor, vt: torch.Tensor, wk_txt, wk_img, rope_cos, rope_sin, B: int, S: int, H: int, ld: int,
@@ -300,9 +358,9 @@ def attention_qprep(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: tor
     _need(out, torch.bfloat16, "out")
     if rope_cos is not None:
         _need(rope_cos, torch.float32, "rope_cos")
-    check(lib.drag_attention_qprep_bf16(_p(q), _p(k), _p(vt), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale,
-                                        _p(wq_txt), _p(wq_img), _p(rope_cos), _p(rope_sin), s_txt, eps, _stream()),
-          "drag_attention_qprep_bf16")
+    _recorded_attention(lambda: check(lib.drag_attention_qprep_bf16(_p(q), _p(k), _p(vt), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o,
+                                                                    o_batch_stride, scale, _p(wq_txt), _p(wq_img), _p(rope_cos), _p(rope_sin),
+                                                                    s_txt, eps, _stream()), "drag_attention_qprep_bf16"), B, S, H, True, False)
 
 
 def attention_v(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, ld_qk: int,
@@ -316,9 +374,9 @@ def attention_v(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Te
     _need(out, torch.bfloat16, "out")
     if rope_cos is not None:
         _need(rope_cos, torch.float32, "rope_cos")
-    check(lib.drag_attention_v_bf16(_p(q), _p(k), _p(v), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride, scale,
-                                    _p(wq_txt), _p(wq_img), _p(rope_cos), _p(rope_sin), s_txt, eps, _stream()),
-          "drag_attention_v_bf16")
+    _recorded_attention(lambda: check(lib.drag_attention_v_bf16(_p(q), _p(k), _p(v), _p(out), B, S, H, ld_qk, qk_batch_stride, ld_o, o_batch_stride,
+                                                                scale, _p(wq_txt), _p(wq_img), _p(rope_cos), _p(rope_sin), s_txt, eps, _stream()),
+                                      "drag_attention_v_bf16"), B, S, H, wq_txt is not None, True)
 
 
 def layernorm(x: torch.Tensor, y: torch.Tensor, M: int, D: int, *, scale=None, shift=None, gamma=None, beta=None,

@@ -162,8 +162,10 @@ def loop_of(form, **kw):
 
 
 print("// generated by scripts/gen/gemm4w_kloop.py — do not edit; see the generator for the register map and the schedule")
-print("#define G4W_CLOBBERS " + ", ".join(f'"v{i}"' for i in range(128)))
-print("#define G4W_CLOBBERS_R " + ", ".join(f'"v{i}"' for i in list(range(128)) + list(range(G0, G0 + 64))))
+# m0 is written before every LDS-DMA piece: nothing hipcc emits around the statements uses it today, but an LDS-DMA builtin, a readlane or a
+# movrel next to them would otherwise be free to assume its own m0 value survives
+print("#define G4W_CLOBBERS " + ", ".join(f'"v{i}"' for i in range(128)) + ', "m0"')
+print("#define G4W_CLOBBERS_R " + ", ".join(f'"v{i}"' for i in list(range(128)) + list(range(G0, G0 + 64))) + ', "m0"')
 print()
 # ---- form D: prologue = K-steps 0, 1 by LDS-DMA (soffset 0, 128; %[soff] leaves at 256), steady loop over pairs of K-steps (%[n2] pairs),
 # tail = the last two K-steps without refill

@@ -12,6 +12,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """the full-size end-to-end test's CPU oracle (two minutes of host time, independent of the HIP path) starts in a background thread as
+    soon as the collection holds that test, and runs under the GPU tests in front of it (tests/test_gpu_fullsize_e2e.py)"""
+    if os.environ.get("DRAG_ORACLE_PREFETCH", "1") == "0" or session.config.option.collectonly:
+        return
+    for it in session.items:
+        if it.name == "test_fullsize_fill_pipeline_vs_oracle":
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    import __graft_entry__ as ge
+                    ge.build()
+                    it.module.start_oracle_prefetch(torch.device("cuda:0"))
+            except Exception as e:      # the test then computes its oracle inline
+                print(f"[conftest] oracle prefetch not started: {e!r}", file=sys.stderr)
+            break
+
+
 @pytest.fixture(scope="session")
 def built_lib():
     """Build (or reuse) libdomainrag_hip.so; hipcc cross-compiles without a GPU."""

@@ -65,3 +65,18 @@ def test_retrieval_workload_with_three_ranks_sharing_one_gpu():
     assert out["n_gpus"] == 3 and out["rccl_ranks"] == 3 and "NOT a measurement" in out["debug_share_gpu"]
     assert out["planted_neighbour_first"].startswith("16/16")
     assert out["allgather"]["bytes_received_per_gpu"] == 2 * 1667 * 512 * 4
+
+
+@pytest.mark.gpu
+def test_retrieval_workload_with_eight_ranks_sharing_one_gpu():
+    """the REAL rank count of the `--gpus 8` line, before a SCALE record is ever taken: eight processes on GPU 0
+    (gloo collectives, a reduced corpus; NOT a measurement) run the corpus / query sharding of eight ranks (500 rows and 8 queries each),
+    the one all-gather of eight padded shards into the global row order (seven foreign shards received per rank) and rank 0's merge and
+    report; every planted neighbour of rank 0's query shard must come back first"""
+    r = _run(["--gpus", "8", "--debug-share-gpu", "--workload", "retrieval", "--steps", "1", "--warmup", "0", "--corpus", "4000",
+              "--queries", "64", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and "NOT a measurement" in out["debug_share_gpu"]
+    assert out["planted_neighbour_first"].startswith("8/8")
+    assert out["allgather"]["bytes_received_per_gpu"] == 7 * 500 * 512 * 4

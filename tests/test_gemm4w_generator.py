@@ -88,3 +88,33 @@ def test_structure_of_the_product_stream():
     # the tail refills with the NEXT tile's operands, the loop with this tile's
     assert all("%[rsa2]" in ln or "%[rsw2]" in ln for ln in m["G4W_P_TAIL"] if ln.startswith("buffer_load"))
     assert all("%[rsa]" in ln or "%[rsw]" in ln for ln in m["G4W_P_LOOP"] if ln.startswith("buffer_load"))
+
+
+def test_every_register_the_product_stream_writes_is_an_output_or_a_clobber():
+    """ the statement of gemm_bf16_w4p declares a[0:255] as outputs, %[n2] / %[soff] as read-write operands and G4W_CLOBBERS +
+    "scc" as clobbers: every destination register named in the text must be one of those — m0 (written before each LDS-DMA piece) included"""
+    m = _macros()
+    text = open(HEADER).read()
+    clob = set(re.findall(r'"(\w+)"', re.search(r"#define G4W_CLOBBERS (.*)", text).group(1)))
+    assert "m0" in clob and {f"v{i}" for i in range(128)} <= clob
+    src = open(os.path.join(ROOT, "domain-rag_amd", "csrc", "gemm_bf16.hip")).read()
+    for stmt in re.findall(r"asm volatile\((G4W_D_STAGE0_NOWAIT|G4W_P_FIRST G4W_P_PAIR0 G4W_P_LOOP G4W_P_TAIL)(.*?)\);", src, re.S):
+        assert '"m0"' in stmt[1] or "G4W_CLOBBERS" in stmt[1], stmt[0]
+    written = set()
+    for piece in ("G4W_P_FIRST", "G4W_P_PAIR0", "G4W_P_LOOP", "G4W_P_TAIL", "G4W_D_STAGE0_NOWAIT"):
+        for ln in m[piece]:
+            op = ln.split()[0]
+            if op.endswith(":") or op in ("s_waitcnt", "s_barrier", "s_cbranch_scc1", "s_cmp_eq_u32", "s_cmp_lg_u32"):
+                continue
+            if op == "buffer_load_dwordx4":
+                assert ln.rstrip().endswith(" lds"), ln          # LDS-DMA: no register destination
+                continue
+            dst = ln.split(None, 1)[1].split(",")[0].strip()
+            written.add(dst)
+    for d in written:
+        mm = re.match(r"([av])\[(\d+):(\d+)\]$", d)
+        if mm:
+            lo, hi = int(mm.group(2)), int(mm.group(3))
+            assert (mm.group(1) == "a" and hi <= 255) or (mm.group(1) == "v" and hi <= 127), d       # accumulators (outputs) | fragments (clobbers)
+        else:
+            assert d in ("m0", "%[soff]", "%[n2]"), d

@@ -219,6 +219,248 @@ def test_gemm_pair_and_two_destinations_with_outliers(gpu):
     _gemm_check(torch.cat([oa, ob], 1), a3, w3, what="two destinations")
 
 
+# ------------------------------------------------------------------ gemm_bf16_w4p: the kernel that runs two thirds of a composite batch
+#  — the families above pick their kernel by launch shape and the policy sends none of those shapes to the 4-wave
+# kernel (>= 768 tiles, or >= 256 with K >= 8192), whose evidence was bit-equality with the 8-wave kernel on N(0, 1) operands.  Here it is
+# checked against float64 directly: FORCED ("gemm_kernel" = 3) on shapes small enough for a host float64 product, and through the POLICY on
+# shapes it really takes (the float64 product then on the GPU, by torch — the checker, not the product).
+class _forced_w4p:
+    def __enter__(self):
+        from domain_rag_amd import ops
+        ops.set_option("gemm_kernel", 3)
+
+    def __exit__(self, *exc):
+        from domain_rag_amd import ops
+        ops.set_option("gemm_kernel", 0)
+
+
+def _gemm_check_gpu(out, a, w, *, bias=None, what="", extra_roundings=0):
+    """_gemm_check with the float64 yardstick computed on the device (operands already there)"""
+    a64, w64 = a.double(), w.double()
+    ref = a64 @ w64.T
+    mag = a64.abs() @ w64.abs().T
+    if bias is not None:
+        ref = ref + bias.double()
+        mag = mag + bias.double().abs()
+    err = (out.double() - ref).abs()
+    bound = (1.001 + extra_roundings) * BAR_OUT * ref.abs() + BAR_ACC * mag + 1e-40
+    assert torch.isfinite(out.float()).all().item(), f"{what}: non-finite outputs"
+    ratio = (err / bound).max().item()
+    assert ratio <= 1.0, f"{what}: worst err/bound {ratio:.2f}; max err/S {(err / (mag + 1e-300)).max().item():.2e}"
+    return (err / (mag + 1e-300)).max().item()
+
+
+def _is_w4p(M, N, K):
+    from domain_rag_amd import _lib
+    return _lib.load().drag_gemm_bf16_choice(M, 0, N, K) == 3
+
+
+@pytest.mark.parametrize("factor", [1e2, 1e3])
+@pytest.mark.parametrize("M", [2304, 2400])
+def test_gemm_w4p_forced_outlier_channels(gpu, M, factor):
+    """27 | 30 tiles (the second with a ragged last tile row: the EDGE epilogue, whose row predicate is a buffer-descriptor bound)"""
+    from domain_rag_amd import ops
+    N, K = 768, 3072
+    a, w, ch = _outlier_operands(M, N, K, 70 + M, factor)
+    bias = _bf(torch.randn(N, generator=_g(3)))
+    with _forced_w4p():
+        out = ops.gemm(a.to(gpu), w.to(gpu), bias=bias.to(gpu))
+        out_act = ops.gemm(a.to(gpu), w.to(gpu), bias=bias.to(gpu), act=ops.ACT_GELU_TANH)
+    _gemm_check(out, a, w, bias=bias, what=f"w4p forced, outliers x{factor:g}, M {M}")
+    # GELU(tanh) on the float32 accumulator, one rounding: against float64 of the same pre-activation.  |gelu'| <= 1.13, so the pre-activation's
+    # accumulation error passes through at most amplified by that; the tanh form itself is evaluated in float32 (~1e-6 relative).
+    y = a.double() @ w.double().T + bias.double()
+    mag = a.double().abs() @ w.double().abs().T + bias.double().abs()
+    ref = torch.nn.functional.gelu(y, approximate="tanh")
+    err = (out_act.double().cpu() - ref).abs()
+    bound = 1.01 * BAR_OUT * ref.abs() + 1.2 * BAR_ACC * mag + 1e-6 * ref.abs() + 1e-30
+    assert torch.isfinite(out_act.float()).all().item() and not (err > bound).any(), (err / bound).max().item()
+
+
+def test_gemm_w4p_forced_cancelling_rows(gpu):
+    from domain_rag_amd import ops
+    M, N, K = 2400, 512, 2048
+    g = _g(M)
+    u = _bf(torch.randn(M, K // 2, generator=g) * 8)
+    v = _bf(torch.randn(N, K // 2, generator=g))
+    d = _bf(v.float() * (2.0 ** -7) * torch.sign(torch.randn(N, K // 2, generator=g)))
+    a = torch.cat([u, -u], 1).contiguous()
+    w = torch.cat([v, _bf(v.float() + d.float())], 1).contiguous()
+    with _forced_w4p():
+        out = ops.gemm(a.to(gpu), w.to(gpu))
+        out32 = ops.gemm(a.to(gpu), w.to(gpu), out_f32=True)
+    ref = a.double() @ w.double().T
+    mag = a.double().abs() @ w.double().abs().T
+    assert (mag / ref.abs().clamp_min(1e-30)).median() > 50
+    _gemm_check(out, a, w, what="w4p forced, cancelling")
+    # the float32 output carries no output rounding at all: the accumulation bar alone
+    assert ((out32.double().cpu() - ref).abs() <= BAR_ACC * mag + 1e-40).all()
+
+
+def test_gemm_w4p_forced_subnormal_and_max_bf16_operands(gpu):
+    from domain_rag_amd import ops
+    M, N, K = 600, 256, 512
+    g = _g(M + 1)
+    a = _bf(torch.randn(M, K, generator=g) * (2.0 ** -129))
+    assert (a.float().abs() < BF16_MIN_NORMAL).float().mean() > 0.9 and (a.float() != 0).float().mean() > 0.5
+    w = _bf(torch.randn(N, K, generator=g) * (2.0 ** 100))
+    sign = torch.sign(torch.randn(M, K, generator=g))
+    a2 = _bf(sign * BF16_MAX)
+    w2 = _bf(torch.randn(N, K, generator=g) * (2.0 ** -110))
+    a3 = _bf(torch.randn(M, K, generator=g) * (2.0 ** -70))
+    w3 = _bf(torch.randn(N, K, generator=g) * (2.0 ** -64))
+    with _forced_w4p():
+        out = ops.gemm(a.to(gpu), w.to(gpu))
+        out2 = ops.gemm(a2.to(gpu), w2.to(gpu))
+        out3 = ops.gemm(a3.to(gpu), w3.to(gpu)).cpu()
+    assert (a.double() @ w.double().T).abs().median() > 2.0 ** -34
+    _gemm_check(out, a, w, what="w4p forced, subnormal activations")
+    _gemm_check(out2, a2, w2, what="w4p forced, max-bf16 activations")
+    ref3 = _bf((a3.float() @ w3.float().T))
+    assert (out3.double() - ref3.double()).abs().max() <= 2 * 2.0 ** -133 + BAR_OUT * ref3.double().abs().max()
+
+
+@pytest.mark.parametrize("S", [1241, 1280])
+def test_gemm_w4p_forced_gate_residual_across_a_row_map_batch(gpu, S):
+    """x + gate * (a w^T + b) in place on a two-batch row map.  S = 1241 (the DiT's text stream): the tile of rows 1024..1279 holds the end of
+    batch 0 and the start of batch 1 — the EDGE epilogue's per-row choice between two bases and two gate vectors; the last tile is ragged.
+    S = 1280: batches on tile boundaries (the fast form).  Outlier channels in a, massive activations in the residual stream."""
+    from domain_rag_amd import ops
+    B, N, K = 2, 1024, 3072
+    M = B * S
+    a, w, _ = _outlier_operands(M, N, K, 5 + S, 1e3)
+    g = _g(9)
+    bias = _bf(torch.randn(N, generator=g))
+    gate = _bf(torch.randn(B, N, generator=g) * 0.5)
+    resid = torch.randn(M, N, generator=g)
+    resid[:, ::257] *= 500.0
+    resid = _bf(resid)
+    # each batch sits at its own place inside a larger buffer, as the joint [txt, img] stream does: batch stride > rows * ld
+    stride = (S + 37) * N
+    buf = torch.full((B * (S + 37) * N,), 3.0, dtype=torch.bfloat16)
+    for b in range(B):
+        buf[b * stride: b * stride + S * N] = resid[b * S:(b + 1) * S].reshape(-1)
+    x = buf.to(gpu)
+    with _forced_w4p():
+        ops.gemm(a.to(gpu), w.to(gpu), x, bias=bias.to(gpu), gate=gate.to(gpu), resid=x, M=M, lda=K, ldc=N, c_rows_per_batch=S, c_batch_stride=stride, ldg=N)
+    got = x.cpu()
+    out = torch.cat([got[b * stride: b * stride + S * N].view(S, N) for b in range(B)])
+    for b in range(B):      # the gaps between the batches are nobody's to write
+        assert (got[b * stride + S * N: (b + 1) * stride] == 3.0).all()
+    y = a.double() @ w.double().T + bias.double()
+    mag = a.double().abs() @ w.double().abs().T + bias.double().abs()
+    gy = gate.double().repeat_interleave(S, 0) * y
+    ref = resid.double() + gy
+    err = (out.double() - ref).abs()
+    bound = 1.02 * BAR_OUT * (ref.abs() + 2 * gy.abs()) + 2 * BAR_ACC * mag
+    assert torch.isfinite(out.float()).all().item() and not (err > bound).any(), (err / bound).max().item()
+
+
+def test_gemm_w4p_forced_two_destinations_with_outliers(gpu):
+    """q|k|v + proj_mlp as one launch into two buffers: columns >= n_split go to the second (addressed from C2 - n_split; the EDGE bound is
+    the first invalid row's first byte IN THE WAVE'S COLUMNS — round 5's finding iii)"""
+    from domain_rag_amd import ops
+    M, N, K = 2500, 1024, 1024
+    a3, w3, _ = _outlier_operands(M, N, K, 33, 1e3)
+    bias = _bf(torch.randn(N, generator=_g(4)))
+    oa = torch.full((M + 3, 512), 5.0, dtype=torch.bfloat16, device=gpu); ob = torch.full((M + 3, 512), 5.0, dtype=torch.bfloat16, device=gpu)
+    with _forced_w4p():
+        ops.gemm(a3.to(gpu), w3.to(gpu), oa, bias=bias.to(gpu), M=M, lda=K, ldc=512, out2=ob, ldc2=512, n_split=512)
+    assert (oa[M:] == 5.0).all() and (ob[M:] == 5.0).all()                      # rows behind the ragged edge untouched in BOTH buffers
+    _gemm_check(torch.cat([oa[:M], ob[:M]], 1), a3, w3, bias=bias, what="w4p forced, two destinations")
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 6144, 384), (4096, 4096, 12288), (2 * 5337, 9216, 3072)])
+def test_gemm_w4p_by_policy_outliers_and_cancellation(gpu, M, N, K):
+    """shapes the POLICY gives to gemm_bf16_w4p (asserted): 768 tiles at an odd number of K-step pairs; 256 tiles at K = 12 288; the DiT's
+    q|k|v launch at B = 2 (ragged edge, 36 x 42 tiles = several rounds of the persistent walk).  Outlier channels, then cancelling halves."""
+    from domain_rag_amd import ops
+    assert _is_w4p(M, N, K)
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    a = torch.randn(M, K, generator=g)
+    ch = torch.randperm(K, generator=g)[: max(1, K // 1000)]
+    a[:, ch] *= 1e3
+    w = torch.randn(N, K, generator=g) * 0.02
+    idx = torch.randint(0, N * K, (N * K // 1000,), generator=g)
+    w.view(-1)[idx] *= 100.0
+    a, w = _bf(a).to(gpu), _bf(w).to(gpu)
+    bias = _bf(torch.randn(N, generator=g)).to(gpu)
+    out = ops.gemm(a, w, bias=bias)
+    worst = _gemm_check_gpu(out, a, w, bias=bias, what=f"w4p by policy, outliers ({M}, {N}, {K})")
+    assert worst < 1e-6
+    del out
+    # cancelling halves along K
+    u = _bf(torch.randn(M, K // 2, generator=g) * 8).to(gpu)
+    v = _bf(torch.randn(N, K // 2, generator=g)).to(gpu)
+    sgn = torch.sign(torch.randn(N, K // 2, generator=g)).to(gpu)
+    a2 = torch.cat([u, -u], 1).contiguous()
+    w2 = torch.cat([v, _bf(v.float() * (1 + 2.0 ** -7 * sgn))], 1).contiguous()
+    out2 = ops.gemm(a2, w2)
+    _gemm_check_gpu(out2, a2, w2, what=f"w4p by policy, cancelling ({M}, {N}, {K})")
+
+
+@pytest.mark.parametrize("M,N,K", [(1536, 3072, 15360), (512, 3072, 12288)])
+def test_gemm_split_k_stacked_launch_on_outliers(gpu, M, N, K):
+    """the split-K route (S stacked K slices in one gemm_bf16_w4p launch with per-batch W offsets + the reduce pass; the policy's choice for
+    these shapes, asserted) on outlier channels that all fall into ONE slice and on cancelling halves that fall into DIFFERENT slices —
+    the f32 partials must carry the cancellation; bias + gate + residual through the reduce pass"""
+    import ctypes
+    from domain_rag_amd import _lib, ops
+    g = torch.Generator(device="cpu").manual_seed(K + M)
+    a = torch.randn(M, K, generator=g)
+    a[:, 5:K // 16:97] *= 1e3                                  # every outlier channel inside the first K slice
+    w = torch.randn(N, K, generator=g) * 0.02
+    a, w = _bf(a).to(gpu), _bf(w).to(gpu)
+    bias = _bf(torch.randn(N, generator=g)).to(gpu)
+    ops.gemm(a[:256], w[:256])                                 # (registers the workspace)
+    args, _, _ = ops._gemm_args(a, w, None, bias, ops.ACT_NONE, 0, None, None, False, None, 0, 0, None, 0, 0, None, 0, None, 0, 0)
+    assert _lib.load().drag_gemm_bf16_splitk_slices(ctypes.byref(args)) >= 2
+    out = ops.gemm(a, w, bias=bias)
+    _gemm_check_gpu(out, a, w, bias=bias, what=f"split-K, outliers in one slice ({M}, {N}, {K})")
+    u = _bf(torch.randn(M, K // 2, generator=g) * 8).to(gpu)
+    v = _bf(torch.randn(N, K // 2, generator=g)).to(gpu)
+    sgn = torch.sign(torch.randn(N, K // 2, generator=g)).to(gpu)
+    a2 = torch.cat([u, -u], 1).contiguous()
+    w2 = torch.cat([v, _bf(v.float() * (1 + 2.0 ** -7 * sgn))], 1).contiguous()
+    out2 = ops.gemm(a2, w2)
+    _gemm_check_gpu(out2, a2, w2, what=f"split-K, cancelling across slices ({M}, {N}, {K})")
+    # gate + residual through the reduce pass
+    gate = _bf(torch.randn(1, N, generator=g) * 0.5).to(gpu)
+    resid = torch.randn(M, N, generator=g); resid[:, ::257] *= 500.0
+    resid = _bf(resid).to(gpu)
+    x = resid.clone()
+    ops.gemm(a, w, x, bias=bias, gate=gate, resid=x, c_rows_per_batch=M, c_batch_stride=M * N, ldg=N)
+    y = a.double() @ w.double().T + bias.double()
+    mag = a.double().abs() @ w.double().abs().T + bias.double().abs()
+    gy = gate.double() * y
+    ref = resid.double() + gy
+    err = (x.double() - ref).abs()
+    bound = 1.02 * BAR_OUT * (ref.abs() + 2 * gy.abs()) + 2 * BAR_ACC * mag
+    assert torch.isfinite(x.float()).all().item() and not (err > bound).any().item(), (err / bound).max().item()
+
+
+def test_gemm_pair_split_k_on_outliers(gpu):
+    """the pair form of the split (configs[1]'s ff down-projections: ONE partial launch over both problems' stacked rows, the rows behind M1
+    of every slice reading the second problem's A and W) with outlier channels in one problem only: nothing may leak across `split_m1`"""
+    import ctypes
+    from domain_rag_amd import _lib, ops
+    M1, M2, N, K = 1024, 512, 3072, 12288
+    g = torch.Generator(device="cpu").manual_seed(77)
+    a1 = torch.randn(M1, K, generator=g); a1[:, 11::1000] *= 1e3
+    a2 = torch.randn(M2, K, generator=g) * 1e-3                                   # a quiet second problem: a leak of the first would drown it
+    w1 = torch.randn(N, K, generator=g) * 0.02
+    w2 = torch.randn(N, K, generator=g) * 0.02
+    a1, a2, w1, w2 = _bf(a1).to(gpu), _bf(a2).to(gpu), _bf(w1).to(gpu), _bf(w2).to(gpu)
+    o1 = torch.empty(M1, N, dtype=torch.bfloat16, device=gpu); o2 = torch.empty(M2, N, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(a1[:256], w1[:256])
+    g1, _, _ = ops._gemm_args(a1, w1, None, None, ops.ACT_NONE, 0, None, None, False, None, 0, 0, None, 0, 0, None, 0, None, 0, 0)
+    g2, _, _ = ops._gemm_args(a2, w2, None, None, ops.ACT_NONE, 0, None, None, False, None, 0, 0, None, 0, 0, None, 0, None, 0, 0)
+    assert _lib.load().drag_gemm_bf16_pair_splitk_slices(ctypes.byref(g1), ctypes.byref(g2)) >= 2
+    ops.gemm_pair(dict(a=a1, w=w1, out=o1), dict(a=a2, w=w2, out=o2))
+    _gemm_check_gpu(o1, a1, w1, what="pair split-K, loud problem")
+    _gemm_check_gpu(o2, a2, w2, what="pair split-K, quiet problem")
+
+
 # ------------------------------------------------------------------ row softmax (the VAE's mid-block attention)
 @pytest.mark.parametrize("cols", [100, 4096, 16384])
 def test_softmax_rows_dominant_logit_at_every_lane_position(gpu, cols):

@@ -17,18 +17,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_fullsize_fill_pipeline_vs_oracle(gpu):
-    from domain_rag_amd import fill_pipeline as fp, redux, vae, vit
-    from domain_rag_amd.flux import FluxTransformerHIP
+RES, STEPS, STRENGTH = 1024, 2, 1.0
+
+
+def _inputs(gpu):
+    """everything the two routes share, from seeds (private generators: safe to draw from two threads)"""
+    from domain_rag_amd import redux, vae, vit
     from domain_rag_amd.flux_params import FluxConfig, init_params
-    from oracle import fill as ofill, flux as oflux, redux as ored, vit as ovit
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    t0 = time.time()
-    res, steps, strength = 1024, 2, 1.0
+    res = RES
     cfg = FluxConfig(in_channels=384)
     assert (cfg.num_layers, cfg.num_single_layers, cfg.num_attention_heads) == (19, 38, 24)
     tp_dev = init_params(cfg, seed=0, device=gpu)              # 11.9 G parameters: drawn on the GPU, the oracle gets a host copy
-    tp = {k: v.cpu() for k, v in tp_dev.items()}
     vcfg = vae.VaeConfig()
     vp = vae.init_params(vcfg, seed=1)
     vitcfg = vit.VitConfig.siglip_so400m()
@@ -45,31 +44,88 @@ def test_fullsize_fill_pipeline_vs_oracle(gpu):
     en = torch.randn(1, 16, res // 8, res // 8, generator=g).bfloat16()
     mn = torch.randn(1, 16, res // 8, res // 8, generator=g).bfloat16()
     nt = torch.randn(1, (res // 16) ** 2, 64, generator=g).bfloat16()
+    return dict(cfg=cfg, tp_dev=tp_dev, vcfg=vcfg, vp=vp, vitcfg=vitcfg, vitp=vitp, rp=rp, image=image, mask=mask, bg=bg, t5=t5, pooled=pooled,
+                en=en, mn=mn, nt=nt)
+
+
+def _oracle(x, with_f32, t0):
+    """the CPU oracle's composite(s) for the inputs `x`: {"bf16": (uint8 image, float image)[, "f32": ...]}"""
+    from oracle import fill as ofill, flux as oflux, redux as ored, vit as ovit
+    cfg, vcfg, vitcfg = x["cfg"], x["vcfg"], x["vitcfg"]
+    tp = {k: v.cpu() for k, v in x["tp_dev"].items()}
+    res_or = {}
+    ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32))[: 2 if with_f32 else 1]:
+        cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
+        with torch.no_grad():
+            lat = ovit.siglip_last_hidden_state(x["vitp"], 384, 14, 1152, 16, 27, 4304, ovit.normalize_u8(x["bg"], vitcfg.mean, vitcfg.std), dt)
+            pes, pps = ored.redux_prior(lat, cast(x["rp"]), x["t5"].to(dt), x["pooled"].to(dt), [1.0], [1.0])
+            u8, img = ofill.fill_pipeline(cast(tp), ocfg, cast(x["vp"]), dict(block_out=vcfg.block_out_channels, layers=vcfg.layers_per_block),
+                                          x["image"], x["mask"], pes, pps, 30.0, STEPS, STRENGTH, x["en"], x["mn"], x["nt"], dtype=dt)
+        res_or[name] = (u8, img.float())
+        print(f"[e2e] oracle {name} done {time.time() - t0:.0f} s", flush=True)
+    return res_or
+
+
+# The oracle is two minutes of HOST time and needs nothing from the HIP path: tests/conftest.py starts it in a background thread as soon as the
+# collection is known to hold this test (torch's CPU operators release the GIL; the GPU tests in between barely use the host), and the test joins
+# it — same inputs, same oracle, same bars, ~110 s less wall clock for the `-m gpu` run (VERDICT round 5, next-8: the suite must stay well inside
+# the driver's limit).  DRAG_ORACLE_PREFETCH=0 computes it inline as before.
+_prefetch = {}
+
+
+def start_oracle_prefetch(device):
+    import threading
+    if "thread" in _prefetch:
+        return
+    box = {}
+    with_f32 = os.environ.get("DRAG_FULLSIZE_E2E") == "1"
+
+    def run():
+        try:
+            torch.cuda.set_device(device)
+            x = _inputs(device)
+            box["res"] = _oracle(x, with_f32, time.time())
+        except BaseException as e:      # handed to the test, which fails with it
+            box["err"] = e
+
+    th = threading.Thread(target=run, name="fullsize-e2e-oracle", daemon=True)
+    _prefetch.update(thread=th, box=box)
+    th.start()
+
+
+def test_fullsize_fill_pipeline_vs_oracle(gpu):
+    from domain_rag_amd import fill_pipeline as fp, redux, vae
+    from domain_rag_amd.flux import FluxTransformerHIP
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    res, steps, strength = RES, STEPS, STRENGTH
+    x = _inputs(gpu)
+    cfg, vcfg, vitcfg = x["cfg"], x["vcfg"], x["vitcfg"]
+    image, mask, bg, t5, pooled, en, mn, nt = (x[k] for k in ("image", "mask", "bg", "t5", "pooled", "en", "mn", "nt"))
     print(f"[e2e] parameters ready {time.time() - t0:.0f} s", flush=True)
 
-    prior = redux.ReduxPriorHIP(vitcfg, vitp, rp, gpu)
-    fill = fp.FluxFillHIP(FluxTransformerHIP(cfg, tp_dev, gpu), vae.FluxVaeHIP(vcfg, vp, gpu))
+    prior = redux.ReduxPriorHIP(vitcfg, x["vitp"], x["rp"], gpu)
+    fill = fp.FluxFillHIP(FluxTransformerHIP(cfg, x["tp_dev"], gpu), vae.FluxVaeHIP(vcfg, x["vp"], gpu))
     pe, pp = prior(bg.to(gpu), t5.to(gpu), pooled.to(gpu), [1.0], [1.0], group=1)
     assert pe.shape == (1, 1241, 4096)
     out = fill(image.to(gpu), mask.to(gpu), pe, pp, guidance_scale=30.0, num_inference_steps=steps, strength=strength,
                enc_noise=en.to(gpu), masked_enc_noise=mn.to(gpu), noise_tokens=nt.to(gpu)).cpu()
     torch.cuda.synchronize()
-    del fill, prior, tp_dev
-    torch.cuda.empty_cache()
+    del fill, prior
     print(f"[e2e] HIP path done {time.time() - t0:.0f} s", flush=True)
 
-    res_or = {}
-    ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
     with_f32 = os.environ.get("DRAG_FULLSIZE_E2E") == "1"
-    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32))[: 2 if with_f32 else 1]:
-        cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
-        with torch.no_grad():
-            lat = ovit.siglip_last_hidden_state(vitp, 384, 14, 1152, 16, 27, 4304, ovit.normalize_u8(bg, vitcfg.mean, vitcfg.std), dt)
-            pes, pps = ored.redux_prior(lat, cast(rp), t5.to(dt), pooled.to(dt), [1.0], [1.0])
-            u8, img = ofill.fill_pipeline(cast(tp), ocfg, cast(vp), dict(block_out=vcfg.block_out_channels, layers=vcfg.layers_per_block),
-                                          image, mask, pes, pps, 30.0, steps, strength, en, mn, nt, dtype=dt)
-        res_or[name] = (u8, img.float())
-        print(f"[e2e] oracle {name} done {time.time() - t0:.0f} s", flush=True)
+    if "thread" in _prefetch:
+        _prefetch["thread"].join()
+        if "err" in _prefetch["box"]:
+            raise _prefetch["box"]["err"]
+        res_or = _prefetch["box"]["res"]
+        print(f"[e2e] oracle joined from the background thread {time.time() - t0:.0f} s", flush=True)
+    else:
+        res_or = _oracle(x, with_f32, t0)
+    del x
+    torch.cuda.empty_cache()
     assert out.shape == (1, res, res, 3) and out.dtype == torch.uint8
     hip = out.float() / 255.0
     lv = (out.int() - res_or["bf16"][0].int()).abs()
