@@ -66,7 +66,7 @@ SIGNATURES = {
     "drag_attention_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float, c_void_p]),
     "drag_k_norm_rope_vt_bf16": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
     "drag_attention_qprep_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float] + [c_void_p] * 4 + [c_int, c_float, c_void_p]),
-    "drag_attention_bf16_choice": (c_int, [c_int, c_int]),
+    "drag_attention_bf16_choice": (c_int, [c_int, c_int, c_int]),
     "drag_attention_v_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_int64, c_int, c_int64, c_float] + [c_void_p] * 4 + [c_int, c_float, c_void_p]),
     "drag_layernorm_modulate_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_int64, c_int, c_int, c_float, c_void_p]),
     "drag_act_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),

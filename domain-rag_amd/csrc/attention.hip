@@ -14,6 +14,11 @@
 // groups of 16 so that a plain 16-byte read yields exactly the keys a lane's P registers hold
 // (no transposes, no cross-lane traffic in the loop).
 #include "drag_common.h"
+// The asm statements that write m0 (one s_add_u32 m0 per LDS-DMA piece) list "m0" as a clobber: hipcc then re-materialises m0 before its own
+// next LDS-DMA builtin (checked on a two-builtin probe: without the clobber the second builtin ran on the asm's stale m0).  clang warns that m0
+// is a reserved register on every such statement; the clobber is what is wanted here.
+#pragma clang diagnostic ignored "-Winline-asm"
+#include "attn_q64_tile.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1170,6 +1175,243 @@ __global__ __launch_bounds__(256, 1) void attention_q64_kernel(AttnArgs p) {
   }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// attention_q64g_kernel (round 6) — attention_q64_kernel's walking form with the WHOLE KV loop of an item as ONE generated asm statement
+// (scripts/gen/attn_q64_tile.py -> attn_q64_tile.h: prologue scores, every tile with its barrier, maxima, rescale decision and staging
+// pieces, the final P V), operands bound to the physical registers the text names.  hipcc's part: the item walk, the q rows / fragments,
+// the staging of an item's first tiles when nobody staged them, the epilogue.  What the generated form buys:
+// no compiler code inside a tile (round 5 counted ~60 instructions and 19 s_nop per tile between ~40 statements), the K / V^T fragments
+// in AGPRs (only ds_read and MFMA touch them: 40 VGPRs free), and with those the FOLD form: scale * log2(e) goes into the q preparation's one
+// rounding and -M (the running maximum in log2 units) into the C operand of each score chain's first MFMA, so the scores ARE the
+// exponents and the 64 v_fma per tile go (349 instead of 421 instructions per tile and wave; the old stream: 425 + ~60).
+// FOLD = false: every float operation and every accumulator's MFMA order of attention_q64_kernel: same bits
+// (test_attention_q64_generated_stream_*).  FOLD = true (QPREP only: the fold needs the q preparation's rounding point): differs by
+// design — q carries one rounding of q c instead of q; bars of the oracle tests.
+// Launched for an even number >= 4 of KV tiles (the stream's last two tiles stage the next item's first tiles); otherwise, and under
+// "attn_gen" = 1, attention_q64_kernel runs.
+// --------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(32))) float aq_f32x32_t;
+typedef __attribute__((ext_vector_type(8))) uint32_t aq_u32x8_t;
+typedef __attribute__((ext_vector_type(16))) uint32_t aq_u32x16_t;
+
+template <bool QPREP, bool FOLD>
+__global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
+  static_assert(QPREP || !FOLD, "the fold needs the q preparation");
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 K tiles | 2 V^T tiles | 4 x 16 KiB of q rows on their way to registers
+  const int w = wave_id(), l = lane_id();
+  constexpr int QB = 256, CPW = 4;
+  const int nqb = (p.S + QB - 1) / QB;
+  struct Item { int b, h, q0; };
+  auto decode = [&](int item, Item& t) -> bool {
+    const int xcd = item & 7, loc = item >> 3;
+    const int bh = (loc / nqb) * 8 + xcd;
+    t.b = bh / p.H;
+    t.h = bh - t.b * p.H;
+    t.q0 = (loc - (loc / nqb) * nqb) * QB + w * 64;
+    return bh < p.B * p.H;
+  };
+  int item = (int)blockIdx.x;
+  Item cur;
+  if (!decode(item, cur)) return;
+  auto k_descr = [&](const Item& t) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (long long)t.b * p.qk_bs + t.h * 128), 0, p.k_bytes, 0x00020000);
+  };
+  auto v_descr = [&](const Item& t) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + ((long long)(t.b * p.H + t.h) * 128) * p.s_pad), 0, p.vt_bytes, 0x00020000);
+  };
+  auto lane_now = [&]() { int v = l; asm volatile("" : "+v"(v)); return v; };
+  // per-lane constants of the stream, recomputed per item from a laundered lane id (every VGPR but v[240:255] belongs to the statement: held
+  // across it they would be spilled): [0:7] K fragment LDS addresses per k-slice | [8:11] V^T fragment addresses per key group,
+  // [12:15] / [16:19] global byte offsets of this wave's four K / V^T staging pieces
+  const unsigned lds0 = (unsigned)(size_t)(DRAG_LDS char*)smem;
+  auto lane_consts = [&](int ll, aq_u32x8_t& akl, aq_u32x16_t& misc) {
+    const int hh = ll >> 5;
+    const int krd = (ll & 31) * 256, kx = ll & 15;
+    const int vrd = (ll & 31) * 128, vx = ((ll & 31) >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) akl[ks] = lds0 + (unsigned)(krd + (((2 * ks + hh) ^ kx) << 4));
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) misc[s2] = lds0 + (unsigned)(vrd + (((2 * s2 + hh) ^ vx) << 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = w * CPW + i;
+      const int krow = c * 4 + (ll >> 4);
+      misc[4 + i] = (unsigned)krow * (unsigned)(p.ld_qk * 2) + (unsigned)(((ll & 15) ^ (krow & 15)) * 16);
+      const int vrow = c * 8 + (ll >> 3);
+      const int vslot = (ll & 7) ^ ((vrow >> 1) & 7);
+      misc[8 + i] = (unsigned)(((long long)vrow * p.s_pad + vslot * 8) * 2);
+      misc[12 + i] = 0u;
+    }
+  };
+  auto stage_first = [&](const Item& t, int ll) {       // K(0), V^T(0), K(1) of item t (compiler code: once per workgroup)
+    __amdgpu_buffer_rsrc_t rsK = k_descr(t), rsV = v_descr(t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = w * CPW + i;
+      const int krow = c * 4 + (ll >> 4);
+      const unsigned ko = (unsigned)krow * (unsigned)(p.ld_qk * 2) + (unsigned)(((ll & 15) ^ (krow & 15)) * 16);
+      const int vrow = c * 8 + (ll >> 3);
+      const int vslot = (ll & 7) ^ ((vrow >> 1) & 7);
+      const unsigned vo = (unsigned)(((long long)vrow * p.s_pad + vslot * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + c * 1024), 16, ko, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (DRAG_LDS void*)((DRAG_LDS char*)smem + 2 * KT_BYTES + c * 1024), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (DRAG_LDS void*)((DRAG_LDS char*)smem + KT_BYTES + c * 1024), 16,
+                                               ko + 64u * (unsigned)(p.ld_qk * 2), 0, 0, 0);
+    }
+  };
+  DRAG_LDS char* const qlds = (DRAG_LDS char*)smem + 2 * KT_BYTES + 2 * VT_BYTES + w * 16384;
+  auto q_request = [&](const Item& t, const int ll) {
+    __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + (long long)t.b * p.qk_bs + t.h * 128), 0, p.k_bytes, 0x00020000);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const int qr = min(t.q0 + 32 * qg + (ll & 31), p.S - 1);
+      const unsigned vo = (unsigned)qr * (unsigned)(p.ld_qk * 2) + (unsigned)((ll >> 5) * 16);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (DRAG_LDS void*)(qlds + (qg * 8 + ks) * 1024), 16, vo, ks * 32, 0, 0);
+    }
+  };
+  // the Q fragments as the statement takes them: two 32-register AGPR tuples, [group][k-slice][4]
+  auto q_fragments = [&](const Item& t, const int ll, aq_f32x32_t (&qin)[2]) {
+    const int hh = ll >> 5;
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      u32x4_t raw[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) raw[ks] = *(const DRAG_LDS u32x4_t*)(qlds + (qg * 8 + ks) * 1024 + ll * 16);
+      if constexpr (!QPREP) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) qin[qg][4 * ks + j] = __builtin_bit_cast(float, raw[ks][j]);
+      } else {
+        const int qr = min(t.q0 + 32 * qg + (ll & 31), p.S - 1);
+        const bf16_t* wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;
+        const float* cp = p.cosT + (long long)qr * 64 + hh * 4;
+        const float* sp = p.sinT + (long long)qr * 64 + hh * 4;
+        u32x4_t wr[8];
+        f32x4_t c4[8], s4[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          wr[ks] = *(const u32x4_t*)(wsel + ks * 16);
+          c4[ks] = *(const f32x4_t*)(cp + ks * 8);
+          s4[ks] = *(const f32x4_t*)(sp + ks * 8);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a0 = bf2f((bf16_t)(raw[ks][j] & 0xffff)), a1 = bf2f((bf16_t)(raw[ks][j] >> 16));
+            ss += a0 * a0;
+            ss += a1 * a1;
+          }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a0 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] & 0xffff)) * rs) * bf2f((bf16_t)(wr[ks][j] & 0xffff)));
+            const float a1 = rbf(rbf(bf2f((bf16_t)(raw[ks][j] >> 16)) * rs) * bf2f((bf16_t)(wr[ks][j] >> 16)));
+            float r0 = a0 * c4[ks][j] - a1 * s4[ks][j], r1 = a1 * c4[ks][j] + a0 * s4[ks][j];
+            if constexpr (FOLD) { r0 *= p.c; r1 *= p.c; }        // scale * log2(e) inside the rotation's one rounding
+            qin[qg][4 * ks + j] = __builtin_bit_cast(float, pack2bf(r0, r1));
+          }
+      }
+    }
+  };
+  const int nkv = p.s_pad / 64;
+  aq_f32x32_t qin[2];
+  stage_first(cur, l);
+  q_request(cur, l);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  q_fragments(cur, l, qin);
+  int stores_behind = 0;
+  auto wait_older_than_stores = [&]() {
+    if (stores_behind == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (stores_behind == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  for (;;) {                       // items of this workgroup
+    const int b = cur.b, h = cur.h, q0 = cur.q0;
+    const bool has_next = item + (int)gridDim.x < p.items;
+    Item nxt = cur;
+    const bool have = has_next && decode(item + (int)gridDim.x, nxt);
+    const __amdgpu_buffer_rsrc_t rsK = k_descr(cur), rsV = v_descr(cur);
+    // no next item: zero records, the stream's last pieces stage zeros
+    const __amdgpu_buffer_rsrc_t rsKn = have ? k_descr(nxt) : __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVn = have ? v_descr(nxt) : __builtin_amdgcn_make_buffer_rsrc((void*)p.vt, 0, 0, 0x00020000);
+    aq_u32x8_t akl;
+    aq_u32x16_t misc;
+    lane_consts(lane_now(), akl, misc);
+    const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)w * 4096u));
+    const unsigned npairs = (unsigned)(nkv - 2) / 2u;
+    const unsigned ktile = 64u * (unsigned)(p.ld_qk * 2);
+    const unsigned nvalid = (unsigned)(p.S - (nkv - 1) * 64);
+    wait_older_than_stores();                  // K(0), V^T(0), K(1) of this item landed (this wave's pieces)
+    __syncthreads();
+    aq_f32x32_t o4[4];
+    f32x2_t lrun;
+    if constexpr (FOLD) {
+      asm volatile(AQ64_ITEM_FOLD
+                   : "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={v[208:209]}"(lrun)
+                   : "{a[128:159]}"(qin[0]), "{a[160:191]}"(qin[1]), "{v[176:183]}"(akl), "{v[184:199]}"(misc), [rsk] "s"(rsK), [rsv] "s"(rsV),
+                     [rskn] "s"(rsKn), [rsvn] "s"(rsVn), [npairs] "s"(npairs), [ktile] "s"(ktile), [nvalid] "s"(nvalid), [ldsw] "s"(ldsw)
+                   : AQ64_CLOBBERS);
+    } else {
+      asm volatile(AQ64_ITEM_NOFOLD
+                   : "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={v[208:209]}"(lrun)
+                   : "{a[128:159]}"(qin[0]), "{a[160:191]}"(qin[1]), "{v[176:183]}"(akl), "{v[184:199]}"(misc), [rsk] "s"(rsK), [rsv] "s"(rsV),
+                     [rskn] "s"(rsKn), [rsvn] "s"(rsVn), [c] "s"(p.c), [npairs] "s"(npairs), [ktile] "s"(ktile), [nvalid] "s"(nvalid), [ldsw] "s"(ldsw)
+                   : AQ64_CLOBBERS);
+    }
+    const int le = lane_now();
+    if (has_next) q_request(nxt, le);          // the next item's q rows: in flight under the epilogue
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const float lt = lrun[qg] + __shfl_xor(lrun[qg], 32, 64);
+      const float inv = 1.0f / lt;
+      const int qrow = q0 + 32 * qg + (le & 31);
+      auto oa = [&](int dt, int r) -> float { return o4[2 * qg + (dt >> 1)][16 * (dt & 1) + r]; };
+      if (p.tune & 2) {
+        bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 8 * (le >> 5);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            uint32_t a0 = pack2bf(oa(dt, 4 * g) * inv, oa(dt, 4 * g + 1) * inv);
+            uint32_t a1 = pack2bf(oa(dt, 4 * g + 2) * inv, oa(dt, 4 * g + 3) * inv);
+            uint32_t b0 = pack2bf(oa(dt, 4 * g + 4) * inv, oa(dt, 4 * g + 5) * inv);
+            uint32_t b1 = pack2bf(oa(dt, 4 * g + 6) * inv, oa(dt, 4 * g + 7) * inv);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
+            if (qrow < p.S) *(u32x4_t*)(op + 32 * dt + 8 * g) = o;
+          }
+      } else if (qrow < p.S) {
+        bf16_t* op = p.out + (long long)b * p.o_bs + (long long)qrow * p.ld_o + h * 128 + 4 * (le >> 5);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            u32x2_t o;
+            o[0] = pack2bf(oa(dt, 4 * g) * inv, oa(dt, 4 * g + 1) * inv);
+            o[1] = pack2bf(oa(dt, 4 * g + 2) * inv, oa(dt, 4 * g + 3) * inv);
+            *(u32x2_t*)(op + 32 * dt + 8 * g) = o;
+          }
+      }
+    }
+    if (!has_next) break;
+    stores_behind = q0 + 64 <= p.S ? ((p.tune & 2) ? 16 : 32) : 0;
+    wait_older_than_stores();        // the next item's q rows (requested before the stores; its first tiles were staged by the stream)
+    q_fragments(nxt, le, qin);
+    item += (int)gridDim.x;
+    cur = nxt;
+  }
+}
+
 }  // namespace
 
 #if DRAG_EXP
@@ -1233,10 +1475,19 @@ static void attention_family(int32_t S, bool vrow, bool& w8, bool& q64) {
   q64 = !vrow && q64opt != 2 && ((q64opt == 1 && S >= 1024) || (q64opt == 0 && w8 && (!DRAG_EXP || drag_opt(DRAG_OPT_ATTN_PERSIST) == 0)));
 }
 
-// 64 = attention_q64_kernel, 8 / 4 = attention_d128_kernel<8 | 4 waves, ...> — for callers that account launches per kernel (bench.py)
-extern "C" int drag_attention_bf16_choice(int32_t S, int32_t v_row_major) {
+// does a 64-query launch over S keys take the generated stream (attention_q64g_kernel)?  Its last two tiles stage the next item's first
+// tiles: an even number >= 4 of KV tiles; "attn_gen" = 1 switches it off
+static bool attention_generated(int32_t S) {
+  const int nkv = (S + 63) / 64;
+  return drag_opt(DRAG_OPT_ATTN_GEN) != 1 && nkv % 2 == 0 && nkv >= 4;
+}
+
+// 64 = attention_q64_kernel, 640 = attention_q64g_kernel without the fold, 641 = with it (fused q preparation only), 8 / 4 =
+// attention_d128_kernel<8 | 4 waves, ...> — for callers that account launches per kernel (bench.py)
+extern "C" int drag_attention_bf16_choice(int32_t S, int32_t v_row_major, int32_t q_prep) {
   bool w8, q64;
   attention_family(S, v_row_major != 0, w8, q64);
+  if (q64 && attention_generated(S)) return q_prep && drag_opt(DRAG_OPT_ATTN_GEN) != 2 ? 641 : 640;
   return q64 ? 64 : (w8 ? 8 : 4);
 }
 
@@ -1363,7 +1614,22 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
     // (a forced grid also walks items whose tiles do not pair up: each item then stages its own first tiles behind a barrier — tests)
     const bool walk = popt != 2 && (B * H) % 8 == 0 && (popt >= 8 || (nkv64 % 2 == 0 && nkv64 >= 4)) && p.items > pgrid;
     const dim3 grid64(walk ? (unsigned)pgrid : grid.x);
-    if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid64, dim3(256), lds64, st, p);
+    // "attn_gen": 0 = policy — the generated stream (attention_q64g_kernel) whenever the tiles pair up, FOLD with the fused q preparation;
+    // 1 = never (attention_q64_kernel); 2 = the generated stream WITHOUT the fold (same bits as attention_q64_kernel: tests, A/B)
+    const int gen = drag_opt(DRAG_OPT_ATTN_GEN);
+    if (attention_generated(S)) {
+      static unsigned long long readyg = 0;
+      if (!((readyg >> (dev64 & 63)) & 1ull)) {
+        DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64g_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64g_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64g_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess,
+                   "drag_attention: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        readyg |= 1ull << (dev64 & 63);
+      }
+      if (qprep && gen != 2) hipLaunchKernelGGL((attention_q64g_kernel<true, true>), grid64, dim3(256), lds64, st, p);
+      else if (qprep) hipLaunchKernelGGL((attention_q64g_kernel<true, false>), grid64, dim3(256), lds64, st, p);
+      else hipLaunchKernelGGL((attention_q64g_kernel<false, false>), grid64, dim3(256), lds64, st, p);
+    } else if (qprep) hipLaunchKernelGGL((attention_q64_kernel<true>), grid64, dim3(256), lds64, st, p);
     else hipLaunchKernelGGL((attention_q64_kernel<false>), grid64, dim3(256), lds64, st, p);
 #if DRAG_EXP
   } else if (w8 && sched == 2 && drag_opt(DRAG_OPT_ATTN_PERSIST) != 0 && fits32 && (B * H) % 8 == 0 && (p.s_pad / 64) % 2 == 0 &&

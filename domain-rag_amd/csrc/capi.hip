@@ -18,8 +18,8 @@ extern "C" int drag_experiments_built(void) { return DRAG_EXP; }
 // values come from the environment ONCE; drag_set_option changes them at run time so one process can A/B kernels.
 static int g_opt[DRAG_OPT_COUNT];
 static bool g_opt_init = false;
-static const char* const g_opt_names[DRAG_OPT_COUNT] = {"attn_sched", "attn_w4", "attn_tune", "attn_q64", "gemm_kernel", "ln_generic", "gemm_group_m", "topk_grid", "topk_depth", "attn_persist", "topk_select", "topk_dense_sample", "topk_qt", "gemm_pair", "gemm_epilogue", "topk_path", "topk_qreg", "gemm_w4", "attn_walk", "gemm_splitk"};
-static const char* const g_opt_env[DRAG_OPT_COUNT] = {"DRAG_ATTN_SCHED", "DRAG_ATTN_W4", "DRAG_ATTN_TUNE", "DRAG_ATTN_Q64", "DRAG_GEMM_KERNEL", "DRAG_LN_GENERIC", "DRAG_GEMM_GROUP_M", "DRAG_TOPK_GRID", "DRAG_TOPK_DEPTH", "DRAG_ATTN_PERSIST", "DRAG_TOPK_SELECT", "DRAG_TOPK_DENSE_SAMPLE", "DRAG_TOPK_QT", "DRAG_GEMM_PAIR", "DRAG_GEMM_EPILOGUE", "DRAG_TOPK_PATH", "DRAG_TOPK_QREG", "DRAG_GEMM_W4", "DRAG_ATTN_WALK", "DRAG_GEMM_SPLITK"};
+static const char* const g_opt_names[DRAG_OPT_COUNT] = {"attn_sched", "attn_w4", "attn_tune", "attn_q64", "gemm_kernel", "ln_generic", "gemm_group_m", "topk_grid", "topk_depth", "attn_persist", "topk_select", "topk_dense_sample", "topk_qt", "gemm_pair", "gemm_epilogue", "topk_path", "topk_qreg", "gemm_w4", "attn_walk", "gemm_splitk", "attn_gen"};
+static const char* const g_opt_env[DRAG_OPT_COUNT] = {"DRAG_ATTN_SCHED", "DRAG_ATTN_W4", "DRAG_ATTN_TUNE", "DRAG_ATTN_Q64", "DRAG_GEMM_KERNEL", "DRAG_LN_GENERIC", "DRAG_GEMM_GROUP_M", "DRAG_TOPK_GRID", "DRAG_TOPK_DEPTH", "DRAG_ATTN_PERSIST", "DRAG_TOPK_SELECT", "DRAG_TOPK_DENSE_SAMPLE", "DRAG_TOPK_QT", "DRAG_GEMM_PAIR", "DRAG_GEMM_EPILOGUE", "DRAG_TOPK_PATH", "DRAG_TOPK_QREG", "DRAG_GEMM_W4", "DRAG_ATTN_WALK", "DRAG_GEMM_SPLITK", "DRAG_ATTN_GEN"};
 
 static void opt_init() {
   if (g_opt_init) return;
@@ -52,6 +52,6 @@ extern "C" int drag_set_option(const char* name, int32_t value) {
       g_opt[i] = value;
       return 0;
     }
-  drag_set_error("drag_set_option: unknown option (attn_sched, attn_w4, attn_tune, attn_q64, gemm_kernel, ln_generic, gemm_group_m, topk_grid, topk_depth, attn_persist, topk_select, topk_dense_sample, topk_qt, gemm_pair, gemm_epilogue, topk_path, topk_qreg, gemm_w4, attn_walk, gemm_splitk)");
+  drag_set_error("drag_set_option: unknown option (attn_sched, attn_w4, attn_tune, attn_q64, gemm_kernel, ln_generic, gemm_group_m, topk_grid, topk_depth, attn_persist, topk_select, topk_dense_sample, topk_qt, gemm_pair, gemm_epilogue, topk_path, topk_qreg, gemm_w4, attn_walk, gemm_splitk, attn_gen)");
   return -1;
 }

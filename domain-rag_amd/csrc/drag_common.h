@@ -87,7 +87,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // tuning switches (capi.hip): read once from the environment, changeable through drag_set_option
-enum { DRAG_OPT_ATTN_SCHED = 0, DRAG_OPT_ATTN_W4 = 1, DRAG_OPT_ATTN_TUNE = 2, DRAG_OPT_ATTN_Q64 = 3, DRAG_OPT_GEMM_KERNEL = 4, DRAG_OPT_LN_GENERIC = 5, DRAG_OPT_GEMM_GROUP_M = 6, DRAG_OPT_TOPK_GRID = 7, DRAG_OPT_TOPK_DEPTH = 8, DRAG_OPT_ATTN_PERSIST = 9, DRAG_OPT_TOPK_SELECT = 10, DRAG_OPT_TOPK_DENSE_SAMPLE = 11, DRAG_OPT_TOPK_QT = 12, DRAG_OPT_GEMM_PAIR = 13, DRAG_OPT_GEMM_EPILOGUE = 14, DRAG_OPT_TOPK_PATH = 15, DRAG_OPT_TOPK_QREG = 16, DRAG_OPT_GEMM_W4 = 17, DRAG_OPT_ATTN_WALK = 18, DRAG_OPT_GEMM_SPLITK = 19, DRAG_OPT_COUNT = 20 };
+enum { DRAG_OPT_ATTN_SCHED = 0, DRAG_OPT_ATTN_W4 = 1, DRAG_OPT_ATTN_TUNE = 2, DRAG_OPT_ATTN_Q64 = 3, DRAG_OPT_GEMM_KERNEL = 4, DRAG_OPT_LN_GENERIC = 5, DRAG_OPT_GEMM_GROUP_M = 6, DRAG_OPT_TOPK_GRID = 7, DRAG_OPT_TOPK_DEPTH = 8, DRAG_OPT_ATTN_PERSIST = 9, DRAG_OPT_TOPK_SELECT = 10, DRAG_OPT_TOPK_DENSE_SAMPLE = 11, DRAG_OPT_TOPK_QT = 12, DRAG_OPT_GEMM_PAIR = 13, DRAG_OPT_GEMM_EPILOGUE = 14, DRAG_OPT_TOPK_PATH = 15, DRAG_OPT_TOPK_QREG = 16, DRAG_OPT_GEMM_W4 = 17, DRAG_OPT_ATTN_WALK = 18, DRAG_OPT_GEMM_SPLITK = 19, DRAG_OPT_ATTN_GEN = 20, DRAG_OPT_COUNT = 21 };
 // measured defaults (scripts/bench_attn.py, B=8 S=5337: schedule 0 1112, 1 1139, 2 1165 TFLOP/s; 16-byte epilogue stores +0.1 % there,
 // +4...7 % at S = 1753 / 729; static wave priority: no gain, -5 % on short sequences).  All settings give the same bits.
 #define DRAG_ATTN_SCHED_DEFAULT 2

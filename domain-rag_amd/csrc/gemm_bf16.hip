@@ -18,6 +18,10 @@
 // which lets the text and image streams of Flux live inside one joint [B, S, D] buffer with no
 // concat copies.
 #include "drag_common.h"
+// The asm statements that write m0 (one s_add_u32 m0 per LDS-DMA piece) list "m0" as a clobber: hipcc then re-materialises m0 before its own
+// next LDS-DMA builtin (checked on a two-builtin probe: without the clobber the second builtin ran on the asm's stale m0).  clang warns that m0
+// is a reserved register on every such statement; the clobber is what is wanted here.
+#pragma clang diagnostic ignored "-Winline-asm"
 #include <stdlib.h>
 
 namespace {

@@ -192,9 +192,10 @@ def _recorded_attention(call, B, S, H, qprep, vrow):
     s_ev.record()
     call()
     e_ev.record()
-    fam = _lib.load().drag_attention_bf16_choice(S, int(vrow))
+    fam = _lib.load().drag_attention_bf16_choice(S, int(vrow), int(qprep))
     q = "true" if qprep else "false"
-    name = f"attention_q64_kernel<{q}>" if fam == 64 else f"attention_d128_kernel<{fam}, ..., {q}, ...>"
+    name = {64: f"attention_q64_kernel<{q}>", 640: f"attention_q64g_kernel<{q}, false>", 641: f"attention_q64g_kernel<{q}, true>"}.get(
+        fam, f"attention_d128_kernel<{fam}, ..., {q}, ...>")
     _recorder.attn.append((s_ev, e_ev, 4.0 * S * S * 128 * H * B, name))
 
 

@@ -187,10 +187,12 @@ int drag_attention_v_bf16(const void* q, const void* k, const void* v, void* out
                           int64_t qk_batch_stride, int32_t ld_o, int64_t o_batch_stride, float scale, const void* wq_txt,
                           const void* wq_img, const float* rope_cos, const float* rope_sin, int32_t s_txt, float eps, void* stream);
 
-/* Which kernel a drag_attention*_bf16 call over S keys is dispatched to: 64 = attention_q64_kernel (4 waves x 64 queries, the DiT's
- * calls), 8 / 4 = attention_d128_kernel with 8 / 4 waves.  A pure query (no launch) for callers that account launches per kernel —
- * bench.py's roofline.attention; nothing in the reference corresponds (SDPA picks its backend inside torch). */
-int drag_attention_bf16_choice(int32_t S, int32_t v_row_major);
+/* Which kernel a drag_attention*_bf16 call over S keys is dispatched to: 641 / 640 = attention_q64g_kernel (4 waves x 64 queries, the KV
+ * loop one generated instruction stream: the DiT's calls) with / without the scale fold (with: only under the fused q preparation),
+ * 64 = attention_q64_kernel (the hand-placed form it replaces; odd KV tile counts), 8 / 4 = attention_d128_kernel with 8 / 4 waves.
+ * A pure query (no launch) for callers that account launches per kernel — bench.py's roofline.attention; nothing in the reference
+ * corresponds (SDPA picks its backend inside torch). */
+int drag_attention_bf16_choice(int32_t S, int32_t v_row_major, int32_t q_prep);
 
 /* drag_layernorm_modulate_bf16 — y = LN(x) * (1 + scale[b]) + shift[b]   (no affine LN, eps given)
  * or, with gamma/beta != NULL, y = LN(x) * gamma + beta (affine LayerNorm, scale/shift NULL).

@@ -267,13 +267,15 @@ def test_gemm_w4p_forced_outlier_channels(gpu, M, factor):
         out = ops.gemm(a.to(gpu), w.to(gpu), bias=bias.to(gpu))
         out_act = ops.gemm(a.to(gpu), w.to(gpu), bias=bias.to(gpu), act=ops.ACT_GELU_TANH)
     _gemm_check(out, a, w, bias=bias, what=f"w4p forced, outliers x{factor:g}, M {M}")
-    # GELU(tanh) on the float32 accumulator, one rounding: against float64 of the same pre-activation.  |gelu'| <= 1.13, so the pre-activation's
-    # accumulation error passes through at most amplified by that; the tanh form itself is evaluated in float32 (~1e-6 relative).
+    # GELU(tanh) as torch applies it to a bf16 Linear's output (the reference's F.gelu(linear(x))): the pre-activation is ROUNDED to bf16, the
+    # activation evaluated in float32 on that, the result rounded again (csrc/gemm_bf16.hip act4).  Against float64 of the exact pre-activation:
+    # |gelu'| <= 1.13, so the first rounding (2^-8 |y|) and the accumulation error pass through at most amplified by that; then one output rounding.
+    # (The first run of this test had the one-rounding bar and failed at 1.9 x it in the linear region, where |y| = |gelu(y)|: the bar was wrong.)
     y = a.double() @ w.double().T + bias.double()
     mag = a.double().abs() @ w.double().abs().T + bias.double().abs()
     ref = torch.nn.functional.gelu(y, approximate="tanh")
     err = (out_act.double().cpu() - ref).abs()
-    bound = 1.01 * BAR_OUT * ref.abs() + 1.2 * BAR_ACC * mag + 1e-6 * ref.abs() + 1e-30
+    bound = 1.01 * BAR_OUT * ref.abs() + 1.13 * (1.01 * BAR_OUT * y.abs() + BAR_ACC * mag) + 1e-6 * ref.abs() + 1e-30
     assert torch.isfinite(out_act.float()).all().item() and not (err > bound).any(), (err / bound).max().item()
 
 
@@ -386,9 +388,13 @@ def test_gemm_w4p_by_policy_outliers_and_cancellation(gpu, M, N, K):
     a, w = _bf(a).to(gpu), _bf(w).to(gpu)
     bias = _bf(torch.randn(N, generator=g)).to(gpu)
     out = ops.gemm(a, w, bias=bias)
-    worst = _gemm_check_gpu(out, a, w, bias=bias, what=f"w4p by policy, outliers ({M}, {N}, {K})")
-    assert worst < 1e-6
-    del out
+    _gemm_check_gpu(out, a, w, bias=bias, what=f"w4p by policy, outliers ({M}, {N}, {K})")
+    # ... and with the output rounding taken out (float32 output): the accumulation alone, relative to sum |a w|
+    out32 = ops.gemm(a, w, bias=bias, out_f32=True)
+    mag = a.double().abs() @ w.double().abs().T + bias.double().abs()
+    acc_err = ((out32.double() - (a.double() @ w.double().T + bias.double())).abs() / mag).max().item()
+    assert acc_err < 1e-6, acc_err
+    del out, out32, mag
     # cancelling halves along K
     u = _bf(torch.randn(M, K // 2, generator=g) * 8).to(gpu)
     v = _bf(torch.randn(N, K // 2, generator=g)).to(gpu)
