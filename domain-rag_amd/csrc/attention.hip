@@ -1284,7 +1284,10 @@ __global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) qin[qg][4 * ks + j] = __builtin_bit_cast(float, raw[ks][j]);
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t word = raw[ks][j];      // (a copy first: __builtin_bit_cast applied to the vector ELEMENT expression itself was compiled
+            qin[qg][4 * ks + j] = __builtin_bit_cast(float, word);      //  as a splat of element 0 — hipcc 7.2; found by the bit comparison on the GPU)
+          }
       } else {
         const int qr = min(t.q0 + 32 * qg + (ll & 31), p.S - 1);
         const bf16_t* wsel = (qr < p.s_txt ? p.wq_txt : p.wq_img) + hh * 8;

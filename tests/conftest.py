@@ -13,7 +13,7 @@ def pytest_configure(config):
 
 
 def pytest_collection_finish(session):
-    """the full-size end-to-end test's CPU oracle (two minutes of host time, independent of the HIP path) starts in a background thread as
+    """the full-size end-to-end test's CPU oracle (two minutes of host time, independent of the HIP path) starts in a child process as
     soon as the collection holds that test, and runs under the GPU tests in front of it (tests/test_gpu_fullsize_e2e.py)"""
     if os.environ.get("DRAG_ORACLE_PREFETCH", "1") == "0" or session.config.option.collectonly:
         return
@@ -24,7 +24,7 @@ def pytest_collection_finish(session):
                 if torch.cuda.is_available():
                     import __graft_entry__ as ge
                     ge.build()
-                    it.module.start_oracle_prefetch(torch.device("cuda:0"))
+                    it.module.start_oracle_prefetch()
             except Exception as e:      # the test then computes its oracle inline
                 print(f"[conftest] oracle prefetch not started: {e!r}", file=sys.stderr)
             break

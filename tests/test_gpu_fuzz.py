@@ -99,28 +99,31 @@ def test_attention_q64_equals_the_8_wave_kernel_on_ragged_shapes(gpu):
             q2 = qkv.clone()
             ops.qk_norm_rope_vt(q2, vt, None, None, None, None, None, None, B, S, H, 3 * D, 0)
             outs = {}
-            for q64 in (2, 1):
-                ops.set_option("attn_q64", q64)
+            for q64 in (2, 1, 3):           # 3: the generated stream (no fold without the fused q preparation)
+                ops.set_option("attn_q64", 2 if q64 == 2 else 1); ops.set_option("attn_gen", 2 if q64 == 3 else 1)
                 o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
                 ops.attention(q2, q2.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128))
                 outs[q64] = o.cpu()
             assert torch.isfinite(outs[2].float()).all(), (B, S, H)
-            assert torch.equal(outs[1], outs[2]), ("two-pass", B, S, H, scale_in)
+            assert torch.equal(outs[1], outs[2]) and torch.equal(outs[3], outs[2]), ("two-pass", B, S, H, scale_in)
             if ci < 3:
                 q, k, v = (qkv.cpu()[..., i * D:(i + 1) * D].view(B, S, H, 128).transpose(1, 2).float() for i in range(3))
                 assert _rel(outs[1], ops_ref.attention_ref(q, k, v, 1 / math.sqrt(128))) < 1.5e-2, (B, S, H, scale_in)
             # fused route: k / v prepared by the pass, q inside the attention kernel
             q3 = qkv.clone()
             ops.k_norm_rope_vt(q3, vt, w[1], w[3], cos, sin, B, S, H, 3 * D, s_txt)
-            for q64 in (2, 1):
-                ops.set_option("attn_q64", q64)
+            # 2: the 8-wave kernel; 1: the hand-placed 64-query kernel; 3: round 6's generated stream without the fold (even tile counts; the
+            # hand-placed kernel elsewhere); 4: with the fold — the product's choice, its own evaluation: held to the 8-wave kernel's neighbourhood
+            for q64 in (2, 1, 3, 4):
+                ops.set_option("attn_q64", 2 if q64 == 2 else 1); ops.set_option("attn_gen", {2: 1, 1: 1, 3: 2, 4: 0}[q64])
                 o = torch.full((B, S, D), float("nan"), device=gpu, dtype=torch.bfloat16)
                 ops.attention_qprep(q3, q3.view(-1)[D:], vt, o, B, S, H, 3 * D, S * 3 * D, D, S * D, 1 / math.sqrt(128), w[0], w[2], cos, sin, s_txt)
                 outs[q64] = o.cpu()
-            assert torch.isfinite(outs[2].float()).all(), (B, S, H)
-            assert torch.equal(outs[1], outs[2]), ("fused q preparation", B, S, H, scale_in, s_txt)
+            assert all(torch.isfinite(outs[q].float()).all() for q in (1, 2, 3, 4)), (B, S, H)
+            assert torch.equal(outs[1], outs[2]) and torch.equal(outs[3], outs[2]), ("fused q preparation", B, S, H, scale_in, s_txt)
+            assert _rel(outs[4], outs[2]) < 1e-2, ("fused q preparation, fold", B, S, H, scale_in, _rel(outs[4], outs[2]))
     finally:
-        ops.set_option("attn_q64", 0)
+        ops.set_option("attn_q64", 0); ops.set_option("attn_gen", 0)
 
 
 def test_resample_random_sizes(gpu):
