@@ -1195,9 +1195,10 @@ typedef __attribute__((ext_vector_type(32))) float aq_f32x32_t;
 typedef __attribute__((ext_vector_type(8))) uint32_t aq_u32x8_t;
 typedef __attribute__((ext_vector_type(16))) uint32_t aq_u32x16_t;
 
-template <bool QPREP, bool FOLD>
+template <bool QPREP, bool FOLD, int VAR = 0>      // VAR > 0: schedule variants of the fold form (DRAG_EXPERIMENTS builds: "attn_gen" = 10 + VAR)
 __global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
   static_assert(QPREP || !FOLD, "the fold needs the q preparation");
+  static_assert(VAR == 0 || (FOLD && DRAG_EXP), "variants: fold form, experiment builds");
   extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 K tiles | 2 V^T tiles | 4 x 16 KiB of q rows on their way to registers
   const int w = wave_id(), l = lane_id();
   constexpr int QB = 256, CPW = 4;
@@ -1357,19 +1358,30 @@ __global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
     __syncthreads();
     aq_f32x32_t o4[4];
     f32x2_t lrun;
-    if constexpr (FOLD) {
-      asm volatile(AQ64_ITEM_FOLD
-                   : "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={v[208:209]}"(lrun)
-                   : "{a[128:159]}"(qin[0]), "{a[160:191]}"(qin[1]), "{v[176:183]}"(akl), "{v[184:199]}"(misc), [rsk] "s"(rsK), [rsv] "s"(rsV),
-                     [rskn] "s"(rsKn), [rsvn] "s"(rsVn), [npairs] "s"(npairs), [ktile] "s"(ktile), [nvalid] "s"(nvalid), [ldsw] "s"(ldsw)
-                   : AQ64_CLOBBERS);
-    } else {
-      asm volatile(AQ64_ITEM_NOFOLD
-                   : "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={v[208:209]}"(lrun)
-                   : "{a[128:159]}"(qin[0]), "{a[160:191]}"(qin[1]), "{v[176:183]}"(akl), "{v[184:199]}"(misc), [rsk] "s"(rsK), [rsv] "s"(rsV),
-                     [rskn] "s"(rsKn), [rsvn] "s"(rsVn), [c] "s"(p.c), [npairs] "s"(npairs), [ktile] "s"(ktile), [nvalid] "s"(nvalid), [ldsw] "s"(ldsw)
-                   : AQ64_CLOBBERS);
-    }
+#define AQ64_OUTS "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={v[208:209]}"(lrun)
+#define AQ64_INS "{a[128:159]}"(qin[0]), "{a[160:191]}"(qin[1]), "{v[176:183]}"(akl), "{v[184:199]}"(misc), [rsk] "s"(rsK), [rsv] "s"(rsV), \
+                 [rskn] "s"(rsKn), [rsvn] "s"(rsVn), [npairs] "s"(npairs), [ktile] "s"(ktile), [nvalid] "s"(nvalid), [ldsw] "s"(ldsw)
+    if constexpr (!FOLD) asm volatile(AQ64_ITEM_NOFOLD : AQ64_OUTS : AQ64_INS, [c] "s"(p.c) : AQ64_CLOBBERS);
+    else if constexpr (VAR == 0) asm volatile(AQ64_ITEM_FOLD : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+#if DRAG_EXP
+    else if constexpr (VAR == 1) asm volatile(AQ64_ITEM_FOLD_V1 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 2) asm volatile(AQ64_ITEM_FOLD_V2 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 3) asm volatile(AQ64_ITEM_FOLD_V3 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 4) asm volatile(AQ64_ITEM_FOLD_V4 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 5) asm volatile(AQ64_ITEM_FOLD_V5 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 6) asm volatile(AQ64_ITEM_FOLD_V6 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 7) asm volatile(AQ64_ITEM_FOLD_V7 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 8) asm volatile(AQ64_ITEM_FOLD_V8 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 9) asm volatile(AQ64_ITEM_FOLD_V9 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 10) asm volatile(AQ64_ITEM_FOLD_V10 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 11) asm volatile(AQ64_ITEM_FOLD_V11 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 12) asm volatile(AQ64_ITEM_FOLD_V12 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 13) asm volatile(AQ64_ITEM_FOLD_V13 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 14) asm volatile(AQ64_ITEM_FOLD_V14 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 15) asm volatile(AQ64_ITEM_FOLD_V15 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+#endif
+#undef AQ64_OUTS
+#undef AQ64_INS
     const int le = lane_now();
     if (has_next) q_request(nxt, le);          // the next item's q rows: in flight under the epilogue
 #pragma unroll
@@ -1629,6 +1641,14 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
                    "drag_attention: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         readyg |= 1ull << (dev64 & 63);
       }
+#if DRAG_EXP
+      if (qprep && gen >= 11 && gen <= 25) {
+#define DRAG_AQV(V_) case 10 + V_: DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64g_kernel<true, true, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess, "hipFuncSetAttribute"); \
+        hipLaunchKernelGGL((attention_q64g_kernel<true, true, V_>), grid64, dim3(256), lds64, st, p); break
+        switch (gen) { DRAG_AQV(1); DRAG_AQV(2); DRAG_AQV(3); DRAG_AQV(4); DRAG_AQV(5); DRAG_AQV(6); DRAG_AQV(7); DRAG_AQV(8); DRAG_AQV(9); DRAG_AQV(10); DRAG_AQV(11); DRAG_AQV(12); DRAG_AQV(13); DRAG_AQV(14); DRAG_AQV(15); }
+#undef DRAG_AQV
+      } else
+#endif
       if (qprep && gen != 2) hipLaunchKernelGGL((attention_q64g_kernel<true, true>), grid64, dim3(256), lds64, st, p);
       else if (qprep) hipLaunchKernelGGL((attention_q64g_kernel<true, false>), grid64, dim3(256), lds64, st, p);
       else hipLaunchKernelGGL((attention_q64g_kernel<false, false>), grid64, dim3(256), lds64, st, p);

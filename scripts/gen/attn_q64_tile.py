@@ -20,7 +20,7 @@ Register map of a wave (64 queries = two groups of 32; query = lane & 31, hh = l
   v[188:191]  KOFF this wave's 4 K staging pieces (global byte offsets)     v[192:195] VOFF of its 4 V^T pieces     (176..199: inputs)
   v[200:203]  softmax temporaries   v[204:205] ta tb   v[206:207] ps   v[208:209] l (outputs)   v[210:211] m / M   v[212:213] nm (no fold)
   v[214:215]  row maxima of the tile at hand   v[216:239] temporaries (maxima trees, rescale, mask, staging addresses)
-  v[240:255], a[232:255] are left to the compiler.
+  v[240:255], a[240:255] are left to the compiler.
 Scalars: %[rsk] %[rsv] descriptors of this item's K / V^T, %[rskn] %[rsvn] of the next item's (zero records when there is none),
 %[c] scale * log2(e) (no fold), %[npairs] (tiles - 2) / 2, %[ktile] bytes between K tiles, %[nvalid] valid keys of the last tile,
 %[ldsw] LDS address of this wave's first staging piece; s[84:95] temporaries.
@@ -46,9 +46,10 @@ THR = 8.0
 # ---------------------------------------------------------------------------------------------- register map
 O = lambda g, dt: ("a", 64 * g + 16 * dt, 16)
 QA = lambda g, ks: ("a", 128 + 32 * g + 4 * ks, 4)
-KFR = lambda s: ("a", 192 + 4 * (s % 3), 4)
-VFR = lambda s: ("a", 204 + 4 * (s % 3), 4)
-VTR = lambda dt: ("a", 216 + 4 * dt, 4)
+RING = [3]       # ring depth of the K / V^T fragment rings (3: reads two steps ahead; 4: three — Stream(ahead=3))
+KFR = lambda s: ("a", 192 + 4 * (s % RING[0]), 4)
+VFR = lambda s: ("a", 192 + 4 * RING[0] + 4 * (s % RING[0]), 4)
+VTR = lambda dt: ("a", 192 + 8 * RING[0] + 4 * dt, 4)
 SX = lambda g, t: ("v", 32 * g + 16 * t, 16)
 SY = lambda g, t: ("v", 64 + 32 * g + 16 * t, 16)
 CT = lambda g: ("v", 128 + 16 * g, 16)
@@ -60,6 +61,7 @@ VOFF = lambda i: ("v", 192 + i, 1)
 Y = lambda i: ("v", 200 + i, 1)            # ya0 ya1 yb0 yb1
 TA, TB = ("v", 204, 1), ("v", 205, 1)
 PS = lambda g: ("v", 206 + g, 1)
+PS2 = lambda g: ("v", 204 + 2 * g, 2)       # pk_add form: (sum of the even, sum of the odd elements) per group; TA / TB are not used then
 L = lambda g: ("v", 208 + g, 1)
 M = lambda g: ("v", 210 + g, 1)
 NM = lambda g: ("v", 212 + g, 1)
@@ -88,13 +90,23 @@ class Ins:
 class Stream:
     """instruction records + their assembly text"""
 
-    def __init__(self, fold: bool, pieces_at=None, maxima_early=False):
+    def __init__(self, fold: bool, pieces_at=None, no_dma=False, no_barrier=False, no_reads=False, no_exp=False, no_softmax=False, no_maxima=False,
+                 pk_add=False, ahead=2):
         self.fold = fold
         self.ins: list[Ins] = []
         self.nlabel = 0
-        # step -> list of ("k" | "v", piece index): where the 8 LDS-DMA pieces of a tile go
+        # slot -> list of ("k" | "v", piece index): where the 8 LDS-DMA pieces of a tile go.  slot = a step (behind its first S MFMA) or
+        # ("top", j) (behind the j-th trailing P V MFMA of the tile's top block; fold form only: the address temporaries are the softmax's)
         self.pieces_at = pieces_at or {g: [("k", g)] if g < 4 else [("v", g - 4)] for g in range(8)}
-        self.maxima_early = maxima_early
+        self.no_dma, self.no_barrier = no_dma, no_barrier      # timing ablations (wrong results)
+        self.no_reads, self.no_exp, self.no_softmax, self.no_maxima = no_reads, no_exp, no_softmax, no_maxima
+        # pk_add (fold form): the row sums as v_pk_add_f32 of the exponentials' register pairs — one instruction per pair instead of two
+        # (sum of the even + sum of the odd elements: another summation order)
+        assert not pk_add or fold
+        self.pk_add = pk_add
+        self.ahead = ahead          # fragment reads run `ahead` steps in front of their MFMAs (rings of ahead + 1 fragments)
+        RING[0] = ahead + 1
+        self.queue = []             # the wave's outstanding LDS reads, in issue order (tags): the counted waits come from here
 
     def emit(self, op, dst=None, src=(), imm=None, text=None, tag=""):
         if text is None:
@@ -107,11 +119,22 @@ class Stream:
         ctext = "0" if c is None else rs(c)
         self.emit("v_mfma_f32_32x32x16_bf16", d, [a, b] + ([c] if c is not None else []), text=f"v_mfma_f32_32x32x16_bf16 {rs(d)}, {rs(a)}, {rs(b)}, {ctext}")
 
-    def ds_read(self, d, addr, off):
+    def ds_read(self, d, addr, off, tag=None):
+        if self.no_reads and getattr(self, "in_tile", False):
+            return
+        self.queue.append(tag)
         self.emit("ds_read_b128", d, [addr], imm=off, text=f"ds_read_b128 {rs(d)}, {rs(addr)} offset:{off}")
 
     def wait_lgkm(self, n):
+        del self.queue[:max(len(self.queue) - n, 0)]
         self.emit("s_waitcnt_lgkmcnt", imm=n, text=f"s_waitcnt lgkmcnt({n})")
+
+    def wait_for(self, *tags):
+        """the counted wait that retires the reads tagged `tags` (and everything older), leaving the younger ones in flight; nothing when
+        none of them is outstanding"""
+        idx = [n for n, t in enumerate(self.queue) if t in tags]
+        if idx:
+            self.wait_lgkm(len(self.queue) - max(idx) - 1)
 
     def wait_vm(self, n):
         self.emit("s_waitcnt_vmcnt", imm=n, text=f"s_waitcnt vmcnt({n})")
@@ -133,21 +156,39 @@ class Stream:
     def nop(self, n):
         self.emit("s_nop", imm=n, text=f"s_nop {n}")
 
-    def dma(self, kind, i, buf, nxt):
-        """one LDS-DMA piece: K piece i of the tile two ahead into K buffer `buf`, or V^T piece i of the next tile into V^T buffer `buf`"""
+    def dma_m0(self, kind, i, buf):
+        base = buf * KT + i * 1024 if kind == "k" else 2 * KT + buf * VT + i * 1024
+        self.salu("s_add_u32", "m0", "%[ldsw]", base)
+        return base
+
+    def dma_piece(self, kind, i, buf, nxt, base, filler=True):
+        """one LDS-DMA piece (its m0 is written: dma_m0): K piece i of the tile two ahead into K buffer `buf`, or V^T piece i of the next tile
+        into V^T buffer `buf`.  m0 is not interlocked: one instruction between its write and the piece (K: the address add; V^T: `filler`)"""
         if kind == "k":
-            base = buf * KT + i * 1024
-            self.salu("s_add_u32", "m0", "%[ldsw]", base)
-            self.valu("v_add_u32", TMP(20 + (i & 3)), S_KOFF, KOFF(i), text=f"v_add_u32 {rs(TMP(20 + (i & 3)))}, {S_KOFF}, {rs(KOFF(i))}")
+            tmp = Y(i & 3) if self.fold else TMP(20 + (i & 3))
+            self.valu("v_add_u32", tmp, S_KOFF, KOFF(i), text=f"v_add_u32 {rs(tmp)}, {S_KOFF}, {rs(KOFF(i))}")
             rsrc = "%[rskn]" if nxt else "%[rsk]"
-            self.emit("lds_dma", None, [TMP(20 + (i & 3))], imm=("k", base, rsrc, 0),
-                      text=f"buffer_load_dwordx4 {rs(TMP(20 + (i & 3)))}, {rsrc}, 0 offen lds")
+            self.emit("lds_dma", None, [tmp], imm=("k", base, rsrc, 0), text=f"buffer_load_dwordx4 {rs(tmp)}, {rsrc}, 0 offen lds")
         else:
-            base = 2 * KT + buf * VT + i * 1024
-            self.salu("s_add_u32", "m0", "%[ldsw]", base)
             rsrc = "%[rsvn]" if nxt else "%[rsv]"
-            self.nop(0)          # m0 is not interlocked: one wait state between its write and the piece that uses it
+            if filler:
+                self.nop(0)
             self.emit("lds_dma", None, [VOFF(i)], imm=("v", base, rsrc, S_VSOFF), text=f"buffer_load_dwordx4 {rs(VOFF(i))}, {rsrc}, {S_VSOFF} offen lds")
+
+    def pieces(self, slot, par, nxt_k, nxt_v, around=None):
+        """the LDS-DMA pieces of `slot`; `around` (a callable emitting one instruction, e.g. an MFMA) is placed between the first piece's
+        m0 write and the piece itself (so a V^T piece needs no s_nop); returns whether `around` was emitted"""
+        todo = [] if self.no_dma else self.pieces_at.get(slot, [])
+        if not todo:
+            if around:
+                around()
+            return
+        for n, (kind, i) in enumerate(todo):
+            buf = par if kind == "k" else par ^ 1
+            base = self.dma_m0(kind, i, buf)
+            if n == 0 and around:
+                around()
+            self.dma_piece(kind, i, buf, nxt_k if kind == "k" else nxt_v, base, filler=not (n == 0 and around))
 
     # ---- softmax of step g (elements E0, E0 + 1 of key half T of both groups), in the old stream's operation order
     def softmax_ops(self, sc, g):
@@ -179,13 +220,22 @@ class Stream:
         ops["V12"] = ("v_add_f32", TB, yb0, yb1)
         ops["V13"] = ("v_add_f32", PS(1), PS(1), TB)
         ops["V14"] = ("v_cvt_pk_bf16_f32", wb, yb0, yb1)
+        if self.pk_add:
+            ops["V7"] = ("v_pk_add_f32", PS2(0), PS2(0), (sa0[0], sa0[1], 2))
+            ops["V12"] = ("v_pk_add_f32", PS2(1), PS2(1), (sb0[0], sb0[1], 2))
+            ops["V9"] = ops["V13"] = None
         return ops
 
     def V(self, ops, *names):
+        if self.no_softmax:
+            return
         for n in names:
             o = ops[n]
             if o is not None:
-                self.valu(o[0], o[1], *o[2:])
+                if self.no_exp and o[0] == "v_exp_f32":
+                    self.valu("v_mov_b32", o[1], o[2])
+                else:
+                    self.valu(o[0], o[1], *o[2:])
 
     # ---- one tile
     def tile(self, par, sc, sn, variant="steady"):
@@ -193,104 +243,103 @@ class Stream:
         variant: steady | prelast (K pieces = the NEXT item's K(0)) | last (mask; K pieces = next K(1), V^T pieces = next V^T(0))"""
         KN = (par ^ 1) * KT
         VB = 2 * KT + par * VT
+        self.in_tile = True
         nxt_k = variant in ("prelast", "last")
         nxt_v = variant == "last"
-        self.wait_vm(0)
-        self.emit("s_barrier", text="s_barrier")
-        self.ds_read(KFR(0), AKL(0), KN)
-        self.ds_read(KFR(1), AKL(1), KN)
-        if variant == "last":
-            self.mask_block(sc)
-        self.top_block(sc)
-        self.wait_lgkm(0)
-        self.rescale_decision(sc)
-        for g in range(2):
-            self.valu("v_mov_b32", PS(g), 0, text=f"v_mov_b32 {rs(PS(g))}, 0")
-        # staging offsets of this tile's pieces (K of tile it + 2, V^T of tile it + 1)
+        # staging offsets of this tile's pieces (K of tile it + 2, V^T of tile it + 1): the item's last two tiles stage the NEXT item's
+        # K(0) | K(1), V^T(0).  (Set before the top block: a first form set them behind the rescale decision, and the variants that
+        # stage under the trailing P V used the previous tile's offsets in these two tiles — the next item's first tiles were wrong,
+        # which only a walking launch on the GPU showed: the emulator runs one item.)
         if variant == "prelast":
             self.salu("s_mov_b32", S_KOFF, 0)
         elif variant == "last":
             self.salu("s_mov_b32", S_KOFF, "%[ktile]")
             self.salu("s_mov_b32", S_VSOFF, 0)
+        self.wait_vm(0)
+        if not self.no_barrier:
+            self.emit("s_barrier", text="s_barrier")
+        for g0 in range(self.ahead):
+            self.ds_read(KFR(g0), AKL(g0), KN, tag=("k", g0))
+        if variant == "last":
+            self.mask_block(sc)
+        self.top_block(sc, par, nxt_k, nxt_v)
+        self.wait_lgkm(0)
+        self.rescale_decision(sc)
+        for g in range(2):
+            if self.pk_add:
+                for h in range(2):
+                    self.valu("v_mov_b32", r1(PS2(g), h), 0, text=f"v_mov_b32 {rs(r1(PS2(g), h))}, 0")
+            else:
+                self.valu("v_mov_b32", PS(g), 0, text=f"v_mov_b32 {rs(PS(g))}, 0")
         for g in range(16):
             self.step(g, par, sc, sn, KN, VB, nxt_k, nxt_v)
         self.wait_lgkm(0)
         for g in range(2):
-            self.valu("v_add_f32", L(g), L(g), PS(g))
+            if self.pk_add:
+                self.valu("v_add_f32", L(g), L(g), r1(PS2(g), 0))
+                self.valu("v_add_f32", L(g), L(g), r1(PS2(g), 1))
+            else:
+                self.valu("v_add_f32", L(g), L(g), PS(g))
         if variant == "steady":
             self.salu("s_add_u32", S_KOFF, S_KOFF, "%[ktile]")
             self.salu("s_add_u32", S_VSOFF, S_VSOFF, 128)
 
     def step(self, g, par, sc, sn, KN, VB, nxt_k, nxt_v):
         T = g >> 3
-        prev = g - 1
-        younger = 0 if prev < 0 else (int(prev + 2 <= 15) + int(4 <= prev + 2 <= 15) + (2 if prev >= 14 else 0))
+        A = self.ahead
         ops = self.softmax_ops(sc, g)
         kf = KFR(g)
         c0 = None if g in (0, 8) else sn(0, T)
         c1 = None if g in (0, 8) else sn(1, T)
         if self.fold and g in (0, 8):
             c0, c1 = CT(0), CT(1)
-        KOFFS = KN + ((g + 2) >> 3) * (32 * 256)
-        VOFFS = VB + ((g + 2) & 3) * (32 * 128)
 
-        def reads():
-            out = []
-            if g >= 14:
-                f1 = VB + (2 * (g - 14)) * (32 * 128)
-                out.append((VTR(2 * (g - 14)), AVL(3), f1))
-                out.append((VTR(2 * (g - 14) + 1), AVL(3), f1 + 32 * 128))
-            else:
-                if g + 2 <= 15:
-                    out.append((KFR(g + 2), AKL((g + 2) & 7), KOFFS))
-                if 4 <= g + 2 <= 15:
-                    out.append((VFR(g + 2), AVL(((g + 2) >> 2) - 1), VOFFS))
-            return out
+        # reads issued in step g (in order): K(g + A) if it exists; V^T(g + A) if 4 <= g + A <= 15; the 4 trailing V^T fragments in steps 14 / 15
+        rd = []
+        if g + A <= 15:
+            rd.append((KFR(g + A), AKL((g + A) & 7), KN + ((g + A) >> 3) * (32 * 256), ("k", g + A)))
+        if 4 <= g + A <= 15:
+            rd.append((VFR(g + A), AVL(((g + A) >> 2) - 1), VB + ((g + A) & 3) * (32 * 128), ("v", g + A)))
+        if g >= 14:
+            f1 = VB + (2 * (g - 14)) * (32 * 128)
+            rd.append((VTR(2 * (g - 14)), AVL(3), f1, ("t", 2 * (g - 14))))
+            rd.append((VTR(2 * (g - 14) + 1), AVL(3), f1 + 32 * 128, ("t", 2 * (g - 14) + 1)))
 
-        rd = reads()
+        def read(n):
+            if n < len(rd):
+                d, a, off, tag = rd[n]
+                self.ds_read(d, a, off, tag=tag)
 
-        def pieces():
-            for kind, i in self.pieces_at.get(g, []):
-                if kind == "k":
-                    self.dma("k", i, par, nxt_k)
-                else:
-                    self.dma("v", i, par ^ 1, nxt_v)
-
+        # the step's wait: K(g) (and V^T(g)) landed; younger reads stay in flight
+        self.wait_for(("k", g), ("v", g))
         if g >= 4:
             kgc = (g >> 2) - 1
-            self.wait_lgkm(younger)
             self.V(ops, "V1", "V2")
             self.mfma(O(0, g & 3), VFR(g), PK(kgc, 0), O(0, g & 3))
-            self.ds_read(*rd[0])
+            read(0)
             self.V(ops, "V3")
             self.mfma(O(1, g & 3), VFR(g), PK(kgc, 1), O(1, g & 3))
-            if len(rd) > 1:
-                self.ds_read(*rd[1])
+            read(1)
             self.V(ops, "V4", "V5", "V6")
-            self.mfma(sn(0, T), kf, QA(0, g & 7), c0)
-            pieces()
+            self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(0, T), kf, QA(0, g & 7), c0))
             self.V(ops, "V7", "V8", "V9", "V10")
             self.mfma(sn(1, T), kf, QA(1, g & 7), c1)
             self.V(ops, "V11", "V12", "V13", "V14")
         else:
-            if g >= 1:
-                self.wait_lgkm(younger)
             self.V(ops, "V1", "V2")
             self.mfma(sn(0, T), kf, QA(0, g), c0)
-            for r in rd:
-                self.ds_read(*r)
+            read(0); read(1)
             if self.fold:       # (no v_fma between the exponentials: keep one instruction between a v_exp and the first reader of its result)
                 self.V(ops, "V3", "V5", "V8")
-                self.mfma(sn(1, T), kf, QA(1, g), c1)
-                pieces()
+                self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(1, T), kf, QA(1, g), c1))
                 self.V(ops, "V7", "V10", "V9", "V11", "V12", "V13", "V14")
             else:
                 self.V(ops, "V3", "V4", "V5", "V6", "V7")
-                self.mfma(sn(1, T), kf, QA(1, g), c1)
-                pieces()
+                self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(1, T), kf, QA(1, g), c1))
                 self.V(ops, "V8", "V9", "V10", "V11", "V12", "V13", "V14")
+        assert len(rd) <= 2
 
-    def top_block(self, sc):
+    def top_block(self, sc, par=0, nxt_k=False, nxt_v=False):
         """the previous tile's last key group P V (8 MFMAs) with the row maxima of `sc` (two v_max3 trees) under them; the lane halves are
         joined with v_permlane32_swap (no LDS round trip): MT(0) / MT(1) = the groups' maxima in both lane halves"""
         el = lambda g, i: r1(sc(g, i >> 4), i & 15)
@@ -299,16 +348,22 @@ class Stream:
         ra, rb = MT(0), MT(1)
 
         def L1(t, g, i):
-            self.valu("v_max3_f32", t[i], el(g, 3 * i), el(g, 3 * i + 1), el(g, 3 * i + 2))
+            if not self.no_maxima:
+                self.valu("v_max3_f32", t[i], el(g, 3 * i), el(g, 3 * i + 1), el(g, 3 * i + 2))
 
         def L2(t, g, i, into):
+            if self.no_maxima:
+                return
             if i < 3:
                 self.valu("v_max3_f32", into, t[3 * i], t[3 * i + 1], t[3 * i + 2])
             else:
                 self.valu("v_max3_f32", into, t[9], el(g, 30), el(g, 31))
 
+        npv = [0]
+
         def PV(dt, g):
-            self.mfma(O(g, dt), VTR(dt), PK(3, g), O(g, dt))
+            self.pieces(("top", npv[0]), par, nxt_k, nxt_v, around=lambda: self.mfma(O(g, dt), VTR(dt), PK(3, g), O(g, dt)))
+            npv[0] += 1
 
         # second-level results: group A's into TMP 20..23 (the staging-address temporaries, idle here), group B's into group A's dead first level
         u2a = [TMP(20), TMP(21), TMP(22), TMP(23)]
@@ -487,7 +542,7 @@ class Stream:
 
 def clobbers():
     v = [f"v{i}" for i in range(240) if not (176 <= i <= 199) and i not in (208, 209)]
-    a = [f"a{i}" for i in range(192, 232)]
+    a = [f"a{i}" for i in range(192, 240)]          # (rings of 3: up to a231; of 4: a239 — one list for both)
     s = [f"s{i}" for i in range(84, 96)]
     return v + a + s + ["vcc", "scc", "m0", "memory"]
 
@@ -498,6 +553,11 @@ def build(fold: bool, **kw) -> Stream:
     return s
 
 
+def product(fold: bool) -> Stream:
+    """the stream the product kernel carries (AQ64_ITEM_FOLD / AQ64_ITEM_NOFOLD)"""
+    return build(fold, **(FOLD_PRODUCT if fold else {}))
+
+
 def emit_macro(name, stream, out):
     lines = [i.text for i in stream.ins]
     out.write(f"#define {name} \\\n")
@@ -505,11 +565,40 @@ def emit_macro(name, stream, out):
     out.write("\n\n")
 
 
+# the product's fold stream: the staging pieces under the trailing P V MFMAs of the tile's top block (+0.2 ... +0.8 % over one piece per step in
+# steps 0..7, three boxes: profiles/r06_attn_gen_variants_and_ablations.log, r06_attn_gen_pk_add_and_read_ahead_nulls.log)
+FOLD_PRODUCT = dict(pieces_at={("top", j): [("k", j)] if j < 4 else [("v", j - 4)] for j in range(8)})
+# schedule variants of the fold form for the A/B records (DRAG_EXPERIMENTS builds: "attn_gen" = 10 + index)
+VARIANTS = {
+    0: dict(),                                                                                                                   # one piece per step, steps 0..7 (the first product form)
+    1: dict(pieces_at={0: [("k", 0), ("k", 1)], 1: [("k", 2), ("k", 3)], 2: [("v", 0), ("v", 1)], 3: [("v", 2), ("v", 3)]}),     # two pieces per step
+    2: dict(pieces_at={4 + g: [("k", g)] if g < 4 else [("v", g - 4)] for g in range(8)}),                                        # steps 4..11
+    3: dict(pieces_at={("top", j): [("k", j)] if j < 4 else [("v", j - 4)] for j in range(8)}),                                   # under the trailing P V
+    4: dict(pieces_at={**{("top", 2 * j): [("k", j)] for j in range(4)}, **{g: [("v", g)] for g in range(4)}}),                    # K at the top, V^T in steps 0..3
+    5: dict(pieces_at={**{("top", j): [("k", j)] for j in range(4)}, **{4 + g: [("v", g)] for g in range(4)}}),                    # K at the top, V^T in steps 4..7
+    6: dict(no_dma=True),                                                                                                        # ablation: no staging
+    7: dict(no_barrier=True),                                                                                                    # ablation: no barrier
+    8: dict(no_reads=True),                                                                                                      # ablation: no fragment reads
+    9: dict(no_exp=True),                                                                                                        # ablation: v_mov for v_exp
+    10: dict(no_softmax=True),                                                                                                   # ablation: no softmax VALU
+    11: dict(no_maxima=True),                                                                                                    # ablation: no maxima trees
+    12: dict(no_dma=True, no_reads=True, no_softmax=True, no_maxima=True, no_barrier=True),                                      # ablation: MFMAs (+ waits) only
+    13: dict(pk_add=True),                                                                                                       # row sums by v_pk_add_f32
+    14: dict(ahead=3),                                                                                                           # fragment reads three steps ahead
+    15: dict(pk_add=True, ahead=3),
+}
+
+
 def main(out=sys.stdout):
     out.write("// generated by scripts/gen/attn_q64_tile.py — do not edit; the generator holds the register map, the schedule and the emulator\n")
     out.write("#define AQ64_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n\n")
-    emit_macro("AQ64_ITEM_NOFOLD", build(False), out)
-    emit_macro("AQ64_ITEM_FOLD", build(True), out)
+    emit_macro("AQ64_ITEM_NOFOLD", product(False), out)
+    emit_macro("AQ64_ITEM_FOLD", product(True), out)
+    out.write("#ifdef DRAG_EXPERIMENTS\n")
+    for k, kw in VARIANTS.items():
+        if k:
+            emit_macro(f"AQ64_ITEM_FOLD_V{k}", build(True, **kw), out)
+    out.write("#endif\n")
 
 
 if __name__ == "__main__":
@@ -806,6 +895,12 @@ class Emu:
                 res = np.exp2(F(0)).astype(np.float32).view(np.uint32)
             elif op == "v_add_f32":
                 res = (F(0) + F(1)).astype(np.float32).view(np.uint32)
+            elif op == "v_pk_add_f32":
+                d = i.dst
+                x, y = self.rd(wv, i.src[0]).view(np.float32), self.rd(wv, i.src[1]).view(np.float32)
+                self.note_write(wv, i, [d])
+                wv.v[d[1]:d[1] + 2] = (x + y).astype(np.float32).view(np.uint32)
+                return
             elif op == "v_sub_f32":
                 res = (F(0) - F(1)).astype(np.float32).view(np.uint32)
             elif op == "v_mul_f32":
@@ -889,7 +984,7 @@ def emulate_item(fold, S, ld_qk, q, k, v, scale, seed_pieces=None, stream_kw=Non
         vt[:, pos] = vb[key]
     vmem = vt.reshape(-1).view(np.uint8).copy()
     glob = {"%[rsk]": (kmem, kbytes), "%[rsv]": (vmem, vmem.size), "%[rskn]": (kmem, 0), "%[rsvn]": (vmem, 0)}
-    st = build(fold, **(stream_kw or {}))
+    st = build(fold, **stream_kw) if stream_kw is not None else product(fold)
     qs = np.asarray(q, np.float32)
     if fold:
         qs = bf16_to_f32(bf16_round(qs * c))          # scale * log2(e) folded into the q fragments (one more bf16 rounding here; the

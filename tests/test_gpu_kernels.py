@@ -352,8 +352,8 @@ def test_attention_q64_walking_its_items_equals_one_item_per_workgroup(gpu, B, S
 def test_attention_q64_fold_is_as_close_to_float64_as_the_unfolded_kernels(gpu, B, S, H, s_txt, hot):
     """round 6: the generated 64-query stream's FOLD form (the product's choice under the fused q preparation: scale * log2(e) inside the q
     rotation's one rounding, -M as the score MFMAs' C operand, no v_fma in the softmax) is not bit-comparable with anything — its yardstick
-    is float64 attention over the bf16 q / k the two-pass route prepares, next to the unfolded kernel's own distance from it: within 2 x of
-    that (measured 1.3-1.8 x: q c carries a bf16 rounding of a non-power-of-two multiple), never worse than 1e-2 of the value range;
+    is float64 attention over the UNROUNDED prepared q (and the bf16 k / v), next to the unfolded kernel's own distance from it: the same
+    distance on average (one bf16 rounding of q there, one of q c here), never worse than 1e-2 of the value range;
     keys tens of octaves above their rows' running maxima early, in the middle and in the ragged last tile (the rescale blocks of every
     tile variant, the first tile's forced one included)"""
     from domain_rag_amd import ops
@@ -372,7 +372,19 @@ def test_attention_q64_fold_is_as_close_to_float64_as_the_unfolded_kernels(gpu, 
     two = qkv.clone()
     vt = torch.empty(B, H, 128, s_pad, device=gpu, dtype=torch.bfloat16)
     ops.qk_norm_rope_vt(two, vt, w[0], w[1], w[2], w[3], cos, sin, B, S, H, 3 * D, s_txt)
-    q, k, v = (two[..., i * D:(i + 1) * D].view(B, S, H, 128).transpose(1, 2).double() for i in range(3))
+    q2, k, v = (two[..., i * D:(i + 1) * D].view(B, S, H, 128).transpose(1, 2).double() for i in range(3))
+    # the yardstick's q is the q preparation's result BEFORE its last rounding (RMSNorm with diffusers' two bf16 roundings, then the rotation in
+    # float64): the unfolded kernels round that to bf16, the fold rounds that times scale * log2(e) to bf16 — one rounding each, so they
+    # must sit at the same distance from it.  (Against float64 over the ROUNDED q the unfolded kernels have no q error at all and the fold
+    # looks 1.4 x worse on average: the first form of this test.)
+    xq = qkv[..., :D].view(B, S, H, 128).float()
+    rs_ = torch.rsqrt((xq * xq).mean(-1, keepdim=True) + 1e-6)
+    wsel = torch.where((torch.arange(S, device=gpu) < s_txt)[None, :, None, None], w[0].float(), w[2].float())
+    a = ((xq * rs_).bfloat16().float() * wsel).bfloat16().double()
+    a0, a1 = a[..., 0::2], a[..., 1::2]
+    c64, s64 = cos.double()[None, :, None, :], sin.double()[None, :, None, :]
+    q = torch.stack([a0 * c64 - a1 * s64, a1 * c64 + a0 * s64], -1).flatten(-2).transpose(1, 2)          # [B, H, S, 128]
+    assert (q.bfloat16().double() - q2).abs().max() <= 2.0 ** -7 * q2.abs().max()                        # the same q up to the rounding
     ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, S, D)
     x = qkv.clone()
     ops.k_norm_rope_vt(x, vt, w[1], w[3], cos, sin, B, S, H, 3 * D, s_txt)
@@ -393,11 +405,11 @@ def test_attention_q64_fold_is_as_close_to_float64_as_the_unfolded_kernels(gpu, 
     vmax = ref.abs().max().item()
     e_plain = (plain.double() - ref).abs().max().item() / vmax
     e_fold = (fold.double() - ref).abs().max().item() / vmax
-    assert e_fold <= max(2.0 * e_plain, 4e-3) and e_fold < 1e-2, (e_fold, e_plain)
+    assert e_fold <= max(1.5 * e_plain, 4e-3) and e_fold < 1e-2, (e_fold, e_plain)
     # and on average the two are the same distance away (the fold is not a systematic loss)
     m_plain = (plain.double() - ref).abs().mean().item()
     m_fold = (fold.double() - ref).abs().mean().item()
-    assert m_fold <= 1.25 * m_plain + 1e-6, (m_fold, m_plain)
+    assert m_fold <= 1.15 * m_plain + 1e-6, (m_fold, m_plain)
 
 
 @pytest.mark.parametrize("S", [1087, 4160])
