@@ -375,7 +375,7 @@ def _pmc_mfma_util():
             with open(path) as f:
                 pm = json.load(f)
             out = {"source": os.path.relpath(path, ROOT)}
-            for label, subs in (("gemm", ("gemm_bf16_w4p", "gemm_bf16_t256ILi0")), ("attention", ("attention_q64_kernel", "attention_d128_kernelILi8"))):
+            for label, subs in (("gemm", ("gemm_bf16_w4p", "gemm_bf16_t256ILi0")), ("attention", ("attention_q64g_kernel", "attention_q64_kernel", "attention_d128_kernelILi8"))):
                 key = next(k for sub in subs for k in pm if sub in k)          # (the 64-query kernel since round 4)
                 r = pm[key]
                 out[label] = {"kernel": key.split("(")[0][-60:], "mfma_util": r["mfma_util"], "clock_ghz": r["clock_ghz"], "avg_us_profiled": r["avg_us_profiled"],

@@ -67,7 +67,7 @@ M = lambda g: ("v", 210 + g, 1)
 NM = lambda g: ("v", 212 + g, 1)
 MT = lambda g: ("v", 214 + g, 1)
 TMP = lambda i: ("v", 216 + i, 1)          # 24 temporaries
-S_KOFF, S_VSOFF, S_CNT, S_THR, S_FLOOR, S_T0, S_T1 = "s84", "s85", "s86", "s87", "s88", "s89", "s90"
+S_KOFF, S_VSOFF, S_CNT, S_THR, S_FLOOR, S_T0, S_ONES = "s84", "s85", "s86", "s87", "s88", "s89", "s90"
 NEG_INF = 0xff800000
 
 
@@ -91,7 +91,7 @@ class Stream:
     """instruction records + their assembly text"""
 
     def __init__(self, fold: bool, pieces_at=None, no_dma=False, no_barrier=False, no_reads=False, no_exp=False, no_softmax=False, no_maxima=False,
-                 pk_add=False, ahead=2):
+                 pk_add=False, ahead=2, dot2=False):
         self.fold = fold
         self.ins: list[Ins] = []
         self.nlabel = 0
@@ -104,6 +104,10 @@ class Stream:
         # (sum of the even + sum of the odd elements: another summation order)
         assert not pk_add or fold
         self.pk_add = pk_add
+        # dot2 (fold form): the row sums from the PACKED probabilities, ps += p0 + p1 as one v_dot2c_f32_bf16 with (1, 1) — one instruction
+        # per pair instead of two adds, and the normaliser is the sum of exactly the bf16 values the P V MFMAs multiply
+        assert not dot2 or (fold and not pk_add)
+        self.dot2 = dot2
         self.ahead = ahead          # fragment reads run `ahead` steps in front of their MFMAs (rings of ahead + 1 fragments)
         RING[0] = ahead + 1
         self.queue = []             # the wave's outstanding LDS reads, in issue order (tags): the counted waits come from here
@@ -220,6 +224,10 @@ class Stream:
         ops["V12"] = ("v_add_f32", TB, yb0, yb1)
         ops["V13"] = ("v_add_f32", PS(1), PS(1), TB)
         ops["V14"] = ("v_cvt_pk_bf16_f32", wb, yb0, yb1)
+        if self.dot2:
+            ops["V7"] = ops["V9"] = ops["V12"] = ops["V13"] = None
+            ops["D_a"] = ("v_dot2c_f32_bf16", PS(0), S_ONES, wa)
+            ops["D_b"] = ("v_dot2c_f32_bf16", PS(1), S_ONES, wb)
         if self.pk_add:
             ops["V7"] = ("v_pk_add_f32", PS2(0), PS2(0), (sa0[0], sa0[1], 2))
             ops["V12"] = ("v_pk_add_f32", PS2(1), PS2(1), (sb0[0], sb0[1], 2))
@@ -322,9 +330,14 @@ class Stream:
             read(1)
             self.V(ops, "V4", "V5", "V6")
             self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(0, T), kf, QA(0, g & 7), c0))
-            self.V(ops, "V7", "V8", "V9", "V10")
-            self.mfma(sn(1, T), kf, QA(1, g & 7), c1)
-            self.V(ops, "V11", "V12", "V13", "V14")
+            if self.dot2:
+                self.V(ops, "V8", "V11", "V10")
+                self.mfma(sn(1, T), kf, QA(1, g & 7), c1)
+                self.V(ops, "D_a", "V14", "D_b")
+            else:
+                self.V(ops, "V7", "V8", "V9", "V10")
+                self.mfma(sn(1, T), kf, QA(1, g & 7), c1)
+                self.V(ops, "V11", "V12", "V13", "V14")
         else:
             self.V(ops, "V1", "V2")
             self.mfma(sn(0, T), kf, QA(0, g), c0)
@@ -332,7 +345,10 @@ class Stream:
             if self.fold:       # (no v_fma between the exponentials: keep one instruction between a v_exp and the first reader of its result)
                 self.V(ops, "V3", "V5", "V8")
                 self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(1, T), kf, QA(1, g), c1))
-                self.V(ops, "V7", "V10", "V9", "V11", "V12", "V13", "V14")
+                if self.dot2:
+                    self.V(ops, "V11", "V10", "D_a", "V14", "D_b")
+                else:
+                    self.V(ops, "V7", "V10", "V9", "V11", "V12", "V13", "V14")
             else:
                 self.V(ops, "V3", "V4", "V5", "V6", "V7")
                 self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(1, T), kf, QA(1, g), c1))
@@ -498,6 +514,8 @@ class Stream:
         self.salu("s_lshl_b32", S_KOFF, "%[ktile]", 1)
         self.salu("s_movk_i32", S_VSOFF, 128)
         self.salu("s_mov_b32", S_CNT, "%[npairs]")
+        if self.dot2:
+            self.salu("s_mov_b32", S_ONES, "0x3f803f80")          # (1.0, 1.0) as a bf16 pair
         for half in range(2):                 # ks 0..3, then 4..7: 8 fragments in flight (the rings' and the trailing fragments' registers)
             frags = {}
             slots = [("a", 192 + 4 * i, 4) for i in range(8)]
@@ -586,6 +604,7 @@ VARIANTS = {
     13: dict(pk_add=True),                                                                                                       # row sums by v_pk_add_f32
     14: dict(ahead=3),                                                                                                           # fragment reads three steps ahead
     15: dict(pk_add=True, ahead=3),
+    16: dict(dot2=True, **FOLD_PRODUCT),                                                                                         # row sums by v_dot2c_f32_bf16 of the packed P
 }
 
 
@@ -895,6 +914,11 @@ class Emu:
                 res = np.exp2(F(0)).astype(np.float32).view(np.uint32)
             elif op == "v_add_f32":
                 res = (F(0) + F(1)).astype(np.float32).view(np.uint32)
+            elif op == "v_dot2c_f32_bf16":
+                a, b = U(0), U(1)
+                acc = self.rd(wv, i.dst).view(np.float32).astype(np.float64)
+                res = (acc + bf16_to_f32(a & 0xFFFF).astype(np.float64) * bf16_to_f32(b & 0xFFFF) +
+                       bf16_to_f32(a >> 16).astype(np.float64) * bf16_to_f32(b >> 16)).astype(np.float32).view(np.uint32)
             elif op == "v_pk_add_f32":
                 d = i.dst
                 x, y = self.rd(wv, i.src[0]).view(np.float32), self.rd(wv, i.src[1]).view(np.float32)

@@ -12,22 +12,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_e2e = {"module": None, "started": False}
+
+
 def pytest_collection_finish(session):
-    """the full-size end-to-end test's CPU oracle (two minutes of host time, independent of the HIP path) starts in a child process as
-    soon as the collection holds that test, and runs under the GPU tests in front of it (tests/test_gpu_fullsize_e2e.py)"""
+    """the full-size end-to-end test's CPU oracle (two minutes of host time, independent of the HIP path) runs in a child process under the
+    GPU tests in front of that test (tests/test_gpu_fullsize_e2e.py): remember whether the collection holds it"""
     if os.environ.get("DRAG_ORACLE_PREFETCH", "1") == "0" or session.config.option.collectonly:
         return
     for it in session.items:
         if it.name == "test_fullsize_fill_pipeline_vs_oracle":
-            try:
-                import torch
-                if torch.cuda.is_available():
-                    import __graft_entry__ as ge
-                    ge.build()
-                    it.module.start_oracle_prefetch()
-            except Exception as e:      # the test then computes its oracle inline
-                print(f"[conftest] oracle prefetch not started: {e!r}", file=sys.stderr)
+            _e2e["module"] = it.module
             break
+
+
+def pytest_runtest_setup(item):
+    """... and start it once the host-bound tests at the head of the run are over (test_gpu_adversarial's Student-t chain and
+    test_gpu_chained_steps compute their own oracles on the same cores: a child started at collection time doubled their wall clock and
+    saved nothing — profiles/r06_gputests_*.log): from test_gpu_checkpoints.py on, ~100 s of mostly GPU-bound tests precede the join"""
+    if _e2e["module"] is None or _e2e["started"]:
+        return
+    if os.path.basename(str(item.fspath)) < "test_gpu_checkpoints.py":
+        return
+    _e2e["started"] = True
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import __graft_entry__ as ge
+            ge.build()
+            _e2e["module"].start_oracle_prefetch()
+    except Exception as e:      # the test then computes its oracle inline
+        print(f"[conftest] oracle prefetch not started: {e!r}", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")
