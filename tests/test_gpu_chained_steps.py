@@ -85,18 +85,18 @@ def _setup(in_channels, layers, single_layers, seed, gpu, guidance_embeds=True):
     return cfg, ocfg, tp_dev, tp, vcfg, vp
 
 
-def test_fill_30_chained_steps_vs_oracle_per_step(gpu):
+def _fill_chain(gpu, name, what, res, steps, St, layers, single_layers, seed, box):
     from domain_rag_amd import fill_pipeline as fp, vae
     from domain_rag_amd.flux import FluxTransformerHIP
     from oracle import fill as ofill
     t_start = time.time()
-    res, steps, strength, St = 256, 30, 1.0, 48
-    cfg, ocfg, tp_dev, tp, vcfg, vp = _setup(384, 4, 8, 20, gpu)
-    g = torch.Generator().manual_seed(21)
+    strength = 1.0
+    cfg, ocfg, tp_dev, tp, vcfg, vp = _setup(384, layers, single_layers, seed, gpu)
+    g = torch.Generator().manual_seed(seed + 1)
     yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
     base = torch.stack([128 + 90 * torch.sin(xx / 23.0 + c) * torch.cos(yy / 17.0 - c) for c in range(3)], -1)
     image = (base + 8 * torch.randn(res, res, 3, generator=g)).clamp(0, 255).to(torch.uint8)[None]
-    mask = torch.full((1, res, res), 255, dtype=torch.uint8); mask[:, 90:166, 80:170] = 0
+    mask = torch.full((1, res, res), 255, dtype=torch.uint8); mask[:, box[0]:box[1], box[2]:box[3]] = 0
     pe = torch.randn(1, St, 4096, generator=g).bfloat16(); pp = torch.randn(1, 768, generator=g).bfloat16()
     en = torch.randn(1, 16, res // 8, res // 8, generator=g).bfloat16()
     mn = torch.randn(1, 16, res // 8, res // 8, generator=g).bfloat16()
@@ -111,21 +111,40 @@ def test_fill_30_chained_steps_vs_oracle_per_step(gpu):
     torch.cuda.empty_cache()
     assert sorted(hip_lat) == list(range(steps))
     taps, imgs = {}, {}
-    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for oname, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
         cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
-        taps[name] = {}
+        taps[oname] = {}
         with torch.no_grad():
             _, img = ofill.fill_pipeline(cast(tp), ocfg, cast(vp), dict(block_out=vcfg.block_out_channels, layers=vcfg.layers_per_block),
-                                         image, mask, pe, pp, 30.0, steps, strength, en, mn, nt, dtype=dt, taps=taps[name])
-        imgs[name] = img.float()
+                                         image, mask, pe, pp, 30.0, steps, strength, en, mn, nt, dtype=dt, taps=taps[oname])
+        imgs[oname] = img.float()
     rows = _curves(hip_lat, taps["f32"], taps["bf16"], range(steps))
     hip = out.float() / 255.0
     e = (hip - imgs["f32"].permute(0, 2, 3, 1)).abs().max().item()
     e_or = (imgs["bf16"] - imgs["f32"]).abs().max().item()
-    _report("fill30", rows, {"pipeline": "Fill, 30 steps, strength 1.0, 256x256, 4 double + 8 single blocks at D=3072", "pixels_hip_vs_f32": e,
-                             "pixels_bf16_oracle_vs_f32": e_or, "pixel_ratio": e / max(e_or, 1e-30), "seconds": time.time() - t_start})
-    _check(rows, "Fill x30")
+    _report(name, rows, {"pipeline": what, "pixels_hip_vs_f32": e,
+                         "pixels_bf16_oracle_vs_f32": e_or, "pixel_ratio": e / max(e_or, 1e-30), "seconds": time.time() - t_start})
+    _check(rows, what)
     assert e <= max(1e-2 + 0.5 / 255, 1.3 * e_or), f"pixels: HIP vs f32 {e:.4f}, bf16 oracle vs f32 {e_or:.4f}, ratio {e / max(e_or, 1e-30):.2f}"
+
+
+def test_fill_30_chained_steps_vs_oracle_per_step(gpu):
+    _fill_chain(gpu, "fill30", "Fill, 30 steps, strength 1.0, 256x256, 4 double + 8 single blocks at D=3072", 256, 30, 48, 4, 8, 20, (90, 166, 80, 170))
+
+
+def test_fill_chained_steps_through_the_folded_64_query_attention(gpu):
+    """round 6: the product's attention kernel at the headline's sequence lengths — attention_q64g_kernel with the scale fold — has its own
+    rounding points (q c rounded once; -M in the score MFMAs' C operand), so the chained loop is taken through it as well: 512 x 512 pixels
+    (1024 image + 100 text tokens = 18 KV tiles, the last one ragged), "attn_q64" = 1 (the policy takes the 64-query kernel from 4096 keys on),
+    8 Fill steps over 2 double + 4 single blocks at the real width, the same per-step bars as the 30-step run"""
+    from domain_rag_amd import _lib, ops
+    try:
+        ops.set_option("attn_q64", 1)
+        assert _lib.load().drag_attention_bf16_choice(1024 + 100, 0, 1) == 641
+        _fill_chain(gpu, "fill8_q64_fold", "Fill, 8 steps, strength 1.0, 512x512 (S = 1124), 2 double + 4 single blocks at D=3072, attention_q64g_kernel<true, true>",
+                    512, 8, 100, 2, 4, 40, (180, 332, 160, 340))
+    finally:
+        ops.set_option("attn_q64", 0)
 
 
 def test_txt2img_50_chained_steps_vs_oracle_per_step(gpu):
