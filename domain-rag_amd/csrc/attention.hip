@@ -1358,6 +1358,7 @@ __global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
     __syncthreads();
     aq_f32x32_t o4[4];
     f32x2_t lrun;
+    [[maybe_unused]] f32x16_t lacc[2];
 #define AQ64_OUTS "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={v[208:209]}"(lrun)
 #define AQ64_INS "{a[128:159]}"(qin[0]), "{a[160:191]}"(qin[1]), "{v[176:183]}"(akl), "{v[184:199]}"(misc), [rsk] "s"(rsK), [rsv] "s"(rsV), \
                  [rskn] "s"(rsKn), [rsvn] "s"(rsVn), [npairs] "s"(npairs), [ktile] "s"(ktile), [nvalid] "s"(nvalid), [ldsw] "s"(ldsw)
@@ -1380,6 +1381,11 @@ __global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
     else if constexpr (VAR == 14) asm volatile(AQ64_ITEM_FOLD_V14 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
     else if constexpr (VAR == 15) asm volatile(AQ64_ITEM_FOLD_V15 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
     else if constexpr (VAR == 16) asm volatile(AQ64_ITEM_FOLD_V16 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 17) asm volatile(AQ64_ITEM_FOLD_V17 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 18)         // row sums on the matrix core: two more accumulator tuples come back instead of the l registers
+      asm volatile(AQ64_ITEM_FOLD_V18
+                   : "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={a[224:239]}"(lacc[0]), "={a[240:255]}"(lacc[1])
+                   : AQ64_INS : AQ64_CLOBBERS_LSUM);
 #endif
 #undef AQ64_OUTS
 #undef AQ64_INS
@@ -1387,7 +1393,9 @@ __global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
     if (has_next) q_request(nxt, le);          // the next item's q rows: in flight under the epilogue
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
-      const float lt = lrun[qg] + __shfl_xor(lrun[qg], 32, 64);
+      float lt;
+      if constexpr (VAR == 18) lt = lacc[qg][0];          // (the whole row's sum, in both lane halves)
+      else lt = lrun[qg] + __shfl_xor(lrun[qg], 32, 64);
       const float inv = 1.0f / lt;
       const int qrow = q0 + 32 * qg + (le & 31);
       auto oa = [&](int dt, int r) -> float { return o4[2 * qg + (dt >> 1)][16 * (dt & 1) + r]; };
@@ -1643,10 +1651,10 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
         readyg |= 1ull << (dev64 & 63);
       }
 #if DRAG_EXP
-      if (qprep && gen >= 11 && gen <= 26) {
+      if (qprep && gen >= 11 && gen <= 28) {
 #define DRAG_AQV(V_) case 10 + V_: DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64g_kernel<true, true, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess, "hipFuncSetAttribute"); \
         hipLaunchKernelGGL((attention_q64g_kernel<true, true, V_>), grid64, dim3(256), lds64, st, p); break
-        switch (gen) { DRAG_AQV(1); DRAG_AQV(2); DRAG_AQV(3); DRAG_AQV(4); DRAG_AQV(5); DRAG_AQV(6); DRAG_AQV(7); DRAG_AQV(8); DRAG_AQV(9); DRAG_AQV(10); DRAG_AQV(11); DRAG_AQV(12); DRAG_AQV(13); DRAG_AQV(14); DRAG_AQV(15); DRAG_AQV(16); }
+        switch (gen) { DRAG_AQV(1); DRAG_AQV(2); DRAG_AQV(3); DRAG_AQV(4); DRAG_AQV(5); DRAG_AQV(6); DRAG_AQV(7); DRAG_AQV(8); DRAG_AQV(9); DRAG_AQV(10); DRAG_AQV(11); DRAG_AQV(12); DRAG_AQV(13); DRAG_AQV(14); DRAG_AQV(15); DRAG_AQV(16); DRAG_AQV(17); DRAG_AQV(18); }
 #undef DRAG_AQV
       } else
 #endif

@@ -61,6 +61,8 @@ VOFF = lambda i: ("v", 192 + i, 1)
 Y = lambda i: ("v", 200 + i, 1)            # ya0 ya1 yb0 yb1
 TA, TB = ("v", 204, 1), ("v", 205, 1)
 PS = lambda g: ("v", 206 + g, 1)
+LA = lambda g: ("a", 224 + 16 * g, 16)      # lsum form: the row sums as accumulators of ONES x P MFMAs (rings of 2: fragments end at a223)
+ONES = ("v", 200, 4)                        # lsum form: an A fragment of bf16 ones (the softmax temporaries' registers: the fold does not use them)
 PS2 = lambda g: ("v", 204 + 2 * g, 2)       # pk_add form: (sum of the even, sum of the odd elements) per group; TA / TB are not used then
 L = lambda g: ("v", 208 + g, 1)
 M = lambda g: ("v", 210 + g, 1)
@@ -91,7 +93,7 @@ class Stream:
     """instruction records + their assembly text"""
 
     def __init__(self, fold: bool, pieces_at=None, no_dma=False, no_barrier=False, no_reads=False, no_exp=False, no_softmax=False, no_maxima=False,
-                 pk_add=False, ahead=2, dot2=False):
+                 pk_add=False, ahead=2, dot2=False, lsum=False):
         self.fold = fold
         self.ins: list[Ins] = []
         self.nlabel = 0
@@ -108,6 +110,11 @@ class Stream:
         # per pair instead of two adds, and the normaliser is the sum of exactly the bf16 values the P V MFMAs multiply
         assert not dot2 or (fold and not pk_add)
         self.dot2 = dot2
+        # lsum (fold form): the row sums on the matrix core — per 16-key group and query group ONE more MFMA, ones[32 x 16] x P^T, whose
+        # accumulator holds the sum of the packed probabilities in every row (both lane halves: no cross-lane add at the end) — instead of
+        # 64 v_add per tile: the stream is bound by a lone wave's instruction issue, not by the matrix pipe.  Needs 32 AGPRs: fragment rings of 2
+        assert not lsum or (fold and not pk_add and not dot2 and ahead == 1)
+        self.lsum = lsum
         self.ahead = ahead          # fragment reads run `ahead` steps in front of their MFMAs (rings of ahead + 1 fragments)
         RING[0] = ahead + 1
         self.queue = []             # the wave's outstanding LDS reads, in issue order (tags): the counted waits come from here
@@ -169,7 +176,7 @@ class Stream:
         """one LDS-DMA piece (its m0 is written: dma_m0): K piece i of the tile two ahead into K buffer `buf`, or V^T piece i of the next tile
         into V^T buffer `buf`.  m0 is not interlocked: one instruction between its write and the piece (K: the address add; V^T: `filler`)"""
         if kind == "k":
-            tmp = Y(i & 3) if self.fold else TMP(20 + (i & 3))
+            tmp = (("v", 204 + (i & 3), 1) if self.lsum else Y(i & 3)) if self.fold else TMP(20 + (i & 3))
             self.valu("v_add_u32", tmp, S_KOFF, KOFF(i), text=f"v_add_u32 {rs(tmp)}, {S_KOFF}, {rs(KOFF(i))}")
             rsrc = "%[rskn]" if nxt else "%[rsk]"
             self.emit("lds_dma", None, [tmp], imm=("k", base, rsrc, 0), text=f"buffer_load_dwordx4 {rs(tmp)}, {rsrc}, 0 offen lds")
@@ -224,6 +231,8 @@ class Stream:
         ops["V12"] = ("v_add_f32", TB, yb0, yb1)
         ops["V13"] = ("v_add_f32", PS(1), PS(1), TB)
         ops["V14"] = ("v_cvt_pk_bf16_f32", wb, yb0, yb1)
+        if self.lsum:
+            ops["V7"] = ops["V9"] = ops["V12"] = ops["V13"] = None
         if self.dot2:
             ops["V7"] = ops["V9"] = ops["V12"] = ops["V13"] = None
             ops["D_a"] = ("v_dot2c_f32_bf16", PS(0), S_ONES, wa)
@@ -274,7 +283,9 @@ class Stream:
         self.wait_lgkm(0)
         self.rescale_decision(sc)
         for g in range(2):
-            if self.pk_add:
+            if self.lsum:
+                pass
+            elif self.pk_add:
                 for h in range(2):
                     self.valu("v_mov_b32", r1(PS2(g), h), 0, text=f"v_mov_b32 {rs(r1(PS2(g), h))}, 0")
             else:
@@ -283,7 +294,9 @@ class Stream:
             self.step(g, par, sc, sn, KN, VB, nxt_k, nxt_v)
         self.wait_lgkm(0)
         for g in range(2):
-            if self.pk_add:
+            if self.lsum:
+                pass
+            elif self.pk_add:
                 self.valu("v_add_f32", L(g), L(g), r1(PS2(g), 0))
                 self.valu("v_add_f32", L(g), L(g), r1(PS2(g), 1))
             else:
@@ -313,9 +326,8 @@ class Stream:
             rd.append((VTR(2 * (g - 14)), AVL(3), f1, ("t", 2 * (g - 14))))
             rd.append((VTR(2 * (g - 14) + 1), AVL(3), f1 + 32 * 128, ("t", 2 * (g - 14) + 1)))
 
-        def read(n):
-            if n < len(rd):
-                d, a, off, tag = rd[n]
+        def read(n):          # (n = 1: the second read and whatever else the step has — with reads one step ahead, step 14 has four)
+            for d, a, off, tag in (rd[n:n + 1] if n == 0 else rd[1:]):
                 self.ds_read(d, a, off, tag=tag)
 
         # the step's wait: K(g) (and V^T(g)) landed; younger reads stay in flight
@@ -338,6 +350,8 @@ class Stream:
                 self.V(ops, "V7", "V8", "V9", "V10")
                 self.mfma(sn(1, T), kf, QA(1, g & 7), c1)
                 self.V(ops, "V11", "V12", "V13", "V14")
+            if self.lsum and (g & 3) < 2:        # the row sums of key group kgc, query group g & 1 (its packed words are a step or more old)
+                self.mfma(LA(g & 1), ONES, PK(kgc, g & 1), LA(g & 1))
         else:
             self.V(ops, "V1", "V2")
             self.mfma(sn(0, T), kf, QA(0, g), c0)
@@ -353,7 +367,6 @@ class Stream:
                 self.V(ops, "V3", "V4", "V5", "V6", "V7")
                 self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(1, T), kf, QA(1, g), c1))
                 self.V(ops, "V8", "V9", "V10", "V11", "V12", "V13", "V14")
-        assert len(rd) <= 2
 
     def top_block(self, sc, par=0, nxt_k=False, nxt_v=False):
         """the previous tile's last key group P V (8 MFMAs) with the row maxima of `sc` (two v_max3 trees) under them; the lane halves are
@@ -412,6 +425,9 @@ class Stream:
         self.nop(0)
         self.emit("v_permlane32_swap_b32", None, [ra, rb], text=f"v_permlane32_swap_b32 {rs(ra)}, {rs(rb)}")
         PV(3, 1)
+        if self.lsum:
+            for g in range(2):
+                self.mfma(LA(g), ONES, PK(3, g), LA(g))
 
     def mask_block(self, sc):
         """the ragged last tile: keys >= %[nvalid] do not exist (staged as zero rows): their scores become -inf before the maxima"""
@@ -465,7 +481,15 @@ class Stream:
                 self.valu("v_min_f32", alpha, 0, alpha, text=f"v_min_f32 {rs(alpha)}, 0, {rs(alpha)}")
                 self.valu("v_exp_f32", alpha, alpha)
                 self.valu("v_add_f32", M(g), M(g), TMP(18))
-                self.valu("v_mul_f32", L(g), L(g), alpha)
+                if self.lsum:
+                    for i in range(16):
+                        self.emit("v_accvgpr_read_b32", TMP(i), [r1(LA(g), i)], text=f"v_accvgpr_read_b32 {rs(TMP(i))}, {rs(r1(LA(g), i))}")
+                    for i in range(16):
+                        self.valu("v_mul_f32", TMP(i), TMP(i), alpha)
+                    for i in range(16):
+                        self.emit("v_accvgpr_write_b32", r1(LA(g), i), [TMP(i)], text=f"v_accvgpr_write_b32 {rs(r1(LA(g), i))}, {rs(TMP(i))}")
+                else:
+                    self.valu("v_mul_f32", L(g), L(g), alpha)
                 for i in range(16):
                     self.valu("v_sub_f32", r1(CT(g), i), r1(CT(g), i), TMP(18))
                 for t in range(2):
@@ -500,7 +524,11 @@ class Stream:
         for g in range(2):
             for i in range(4):
                 self.valu("v_mov_b32", r1(PK(3, g), i), 0, text=f"v_mov_b32 {rs(r1(PK(3, g), i))}, 0")
-            self.valu("v_mov_b32", L(g), 0, text=f"v_mov_b32 {rs(L(g))}, 0")
+            if self.lsum:
+                for i in range(16):
+                    self.emit("v_accvgpr_write_b32", r1(LA(g), i), [0], text=f"v_accvgpr_write_b32 {rs(r1(LA(g), i))}, 0")
+            else:
+                self.valu("v_mov_b32", L(g), 0, text=f"v_mov_b32 {rs(L(g))}, 0")
             if self.fold:
                 self.valu("v_mov_b32", M(g), 0, text=f"v_mov_b32 {rs(M(g))}, 0")
                 for i in range(16):
@@ -514,6 +542,9 @@ class Stream:
         self.salu("s_lshl_b32", S_KOFF, "%[ktile]", 1)
         self.salu("s_movk_i32", S_VSOFF, 128)
         self.salu("s_mov_b32", S_CNT, "%[npairs]")
+        if self.lsum:
+            for i in range(4):
+                self.valu("v_mov_b32", r1(ONES, i), "0x3f803f80", text=f"v_mov_b32 {rs(r1(ONES, i))}, 0x3f803f80")
         if self.dot2:
             self.salu("s_mov_b32", S_ONES, "0x3f803f80")          # (1.0, 1.0) as a bf16 pair
         for half in range(2):                 # ks 0..3, then 4..7: 8 fragments in flight (the rings' and the trailing fragments' registers)
@@ -551,6 +582,9 @@ class Stream:
         for dt in range(4):
             for g in range(2):
                 self.mfma(O(g, dt), VTR(dt), PK(3, g), O(g, dt))
+        if self.lsum:
+            for g in range(2):
+                self.mfma(LA(g), ONES, PK(3, g), LA(g))
         done = self.new_label("done")
         self.emit("s_branch", imm=done, text=f"s_branch {done}")
         self.rescale_blocks()
@@ -558,9 +592,9 @@ class Stream:
         self.nop(15); self.nop(7)                # O settles before compiler code reads it
 
 
-def clobbers():
-    v = [f"v{i}" for i in range(240) if not (176 <= i <= 199) and i not in (208, 209)]
-    a = [f"a{i}" for i in range(192, 240)]          # (rings of 3: up to a231; of 4: a239 — one list for both)
+def clobbers(lsum=False):
+    v = [f"v{i}" for i in range(240) if not (176 <= i <= 199) and (lsum or i not in (208, 209))]
+    a = [f"a{i}" for i in range(192, 224 if lsum else 240)]          # (rings of 3: up to a231; of 4: a239 — one list for both; lsum: a[224:255] are outputs)
     s = [f"s{i}" for i in range(84, 96)]
     return v + a + s + ["vcc", "scc", "m0", "memory"]
 
@@ -604,13 +638,16 @@ VARIANTS = {
     13: dict(pk_add=True),                                                                                                       # row sums by v_pk_add_f32
     14: dict(ahead=3),                                                                                                           # fragment reads three steps ahead
     15: dict(pk_add=True, ahead=3),
+    17: dict(ahead=1, **FOLD_PRODUCT),                                                                                           # fragment reads ONE step ahead (rings of 2)
+    18: dict(lsum=True, ahead=1, **FOLD_PRODUCT),                                                                                # row sums by ones x P MFMAs
     16: dict(dot2=True, **FOLD_PRODUCT),                                                                                         # row sums by v_dot2c_f32_bf16 of the packed P
 }
 
 
 def main(out=sys.stdout):
     out.write("// generated by scripts/gen/attn_q64_tile.py — do not edit; the generator holds the register map, the schedule and the emulator\n")
-    out.write("#define AQ64_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n\n")
+    out.write("#define AQ64_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+    out.write("#define AQ64_CLOBBERS_LSUM " + ", ".join(f'"{c}"' for c in clobbers(True)) + "\n\n")
     emit_macro("AQ64_ITEM_NOFOLD", product(False), out)
     emit_macro("AQ64_ITEM_FOLD", product(True), out)
     out.write("#ifdef DRAG_EXPERIMENTS\n")
@@ -1068,6 +1105,8 @@ def emulate_item(fold, S, ld_qk, q, k, v, scale, seed_pieces=None, stream_kw=Non
     for w, wv in enumerate(emu.waves):
         for g in range(2):
             lsum = wv.v[L(g)[1]].view(np.float32)
+            if getattr(st, "lsum", False):          # the accumulator of the ones x P MFMAs: the whole row's sum in every lane half
+                lsum = wv.a[LA(g)[1]].view(np.float32) * 0.5
             for l in range(64):
                 qrow = w * 64 + 32 * g + (l & 31)
                 if l < 32:
