@@ -136,13 +136,13 @@ def test_fill_chained_steps_through_the_folded_64_query_attention(gpu):
     """round 6: the product's attention kernel at the headline's sequence lengths — attention_q64g_kernel with the scale fold — has its own
     rounding points (q c rounded once; -M in the score MFMAs' C operand), so the chained loop is taken through it as well: 512 x 512 pixels
     (1024 image + 100 text tokens = 18 KV tiles, the last one ragged), "attn_q64" = 1 (the policy takes the 64-query kernel from 4096 keys on),
-    8 Fill steps over 2 double + 4 single blocks at the real width, the same per-step bars as the 30-step run"""
+    6 Fill steps over 2 double + 4 single blocks at the real width, the same per-step bars as the 30-step run"""
     from domain_rag_amd import _lib, ops
     try:
         ops.set_option("attn_q64", 1)
         assert _lib.load().drag_attention_bf16_choice(1024 + 100, 0, 1) == 641
-        _fill_chain(gpu, "fill8_q64_fold", "Fill, 8 steps, strength 1.0, 512x512 (S = 1124), 2 double + 4 single blocks at D=3072, attention_q64g_kernel<true, true>",
-                    512, 8, 100, 2, 4, 40, (180, 332, 160, 340))
+        _fill_chain(gpu, "fill6_q64_fold", "Fill, 6 steps, strength 1.0, 512x512 (S = 1124), 2 double + 4 single blocks at D=3072, attention_q64g_kernel<true, true>",
+                    512, 6, 100, 2, 4, 40, (180, 332, 160, 340))
     finally:
         ops.set_option("attn_q64", 0)
 
