@@ -80,6 +80,7 @@ struct GemmKArgs {
   int ldw;          // W's row stride in elements (= K, except in a split-K launch: the whole K of the Linear)
   long long w_boff; // split-K launch (gemm_bf16_w4p only): what row batch b of A adds to W's base (elements): batch b multiplies columns b K .. b K + K - 1
   int split_m1;     // split-K launch of a PAIR: rows >= split_m1 of every K slice are the second problem's (operands A2 / W2, same row stride); 0: one problem
+  int w4_late_state;   // "gemm_epilogue" = 2 (measurement): gemm_bf16_w4p computes tile t + 2's state between tile t's K loop and its epilogue instead of in front of tile t + 1's K loop
   int epi_generic; // "gemm_epilogue" = 1: every tile takes the general staged epilogue (tests compare it with the specialised one bit for bit)
   // optional second row segment (drag_gemm_bf16_pair): M tiles >= seg_tiles_m belong to a second problem with its own operands and
   // row maps but the same N, K and epilogue form — a double block's text and image Linears as ONE launch of the non-persistent kernels
@@ -1175,11 +1176,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
                : "{v[128:143]}"(cur.vo), [rsa] "s"(cur.rsA), [rsw] "s"(cur.rsW), [ldsw] "s"(ldsw) : "scc", "m0", "memory");
   int stores_behind = 0;
   [[maybe_unused]] int tile_no = 0;
+  const bool late = DRAG_EXP && p.w4_late_state != 0;      // (experiment builds only: the product kernel must not carry the variant's 64 B of scratch)
+  if (late) w4_tile_state(args_now(), vb + P < nwg ? vb + P : vb, w, lane_now(), vb + P < nwg, nxt);
   for (;;) {
     W4_STAMP(0);
     const bool have_next = vb + P < nwg;
     const int lt = lane_now();
-    w4_tile_state(args_now(), have_next ? vb + P : vb, w, lt, have_next, nxt);
+    if (!late) w4_tile_state(args_now(), have_next ? vb + P : vb, w, lt, have_next, nxt);
     const u32x8_t rd = read_addrs(lt);
     W4_STAMP(1);
     // K-steps 0 and 1 of this tile landed (this wave's pieces; the statement below opens with the barrier).  Behind an interior tile's fast
@@ -1197,6 +1200,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
                    [rsa2] "s"(nxt.rsA), [rsw2] "s"(nxt.rsW), [ldsw] "s"(ldsw)
                  : G4W_CLOBBERS, "scc", "memory");
     W4_STAMP(3);
+    W4Tile nn;
+    if (late) {            // (measurement) the state of the tile after next, in front of this tile's epilogue
+      const bool have2 = vb + 2 * P < nwg;
+      w4_tile_state(args_now(), have2 ? vb + 2 * P : vb, w, lane_now(), have2, nn);
+    }
     const int le = lane_now();
     f32x4_t acc[8][8];
 #pragma unroll
@@ -1216,6 +1224,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4p(GemmKArgs p) {
     ++tile_no;
     if (!have_next) break;
     cur = nxt;
+    if (late) nxt = nn;
     vb += P;
   }
 }
@@ -1577,6 +1586,7 @@ static int fill_common(GemmKArgs& k, const void* A, const void* W, void* C, cons
   // the K = 3072 shapes (8 ahead by 1-3 % at N = 3072), 4 is 2-3 % ahead at K >= 12288; 16 / 32 (towards W-stationary) lose 5-10 %
   // everywhere (scripts/bench_gemm_group_m.py, two boxes).  Order only: the bits do not depend on it.
   k.epi_generic = drag_opt(DRAG_OPT_GEMM_EPILOGUE) == 1;
+  k.w4_late_state = drag_opt(DRAG_OPT_GEMM_EPILOGUE) == 2;
   // Round 5 (profiles/r05_gemm_tile_walk_fetch_clock.txt: bytes the L2s pull per launch and the clock the launch gets, per setting): the
   // fabric traffic of a launch is A x tiles_n / (32 / g) + W x tiles_m / g and the chip — at its 1400 W socket cap in this kernel — pays for
   // it in clock (g = 1 on (42696, 21504, 3072): 23.4 GB and 1.48 GHz; g = 4: 11.5 GB and 1.77 GHz).  4 | 8 are the two minima; the wide
