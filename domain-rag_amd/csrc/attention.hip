@@ -1382,6 +1382,7 @@ __global__ __launch_bounds__(256, 1) void attention_q64g_kernel(AttnArgs p) {
     else if constexpr (VAR == 15) asm volatile(AQ64_ITEM_FOLD_V15 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
     else if constexpr (VAR == 16) asm volatile(AQ64_ITEM_FOLD_V16 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
     else if constexpr (VAR == 17) asm volatile(AQ64_ITEM_FOLD_V17 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
+    else if constexpr (VAR == 19) asm volatile(AQ64_ITEM_FOLD_V19 : AQ64_OUTS : AQ64_INS : AQ64_CLOBBERS);
     else if constexpr (VAR == 18)         // row sums on the matrix core: two more accumulator tuples come back instead of the l registers
       asm volatile(AQ64_ITEM_FOLD_V18
                    : "={a[0:31]}"(o4[0]), "={a[32:63]}"(o4[1]), "={a[64:95]}"(o4[2]), "={a[96:127]}"(o4[3]), "={a[224:239]}"(lacc[0]), "={a[240:255]}"(lacc[1])
@@ -1651,10 +1652,10 @@ static int attention_launch(const void* q, const void* k, const void* vt, void* 
         readyg |= 1ull << (dev64 & 63);
       }
 #if DRAG_EXP
-      if (qprep && gen >= 11 && gen <= 28) {
+      if (qprep && gen >= 11 && gen <= 29) {
 #define DRAG_AQV(V_) case 10 + V_: DRAG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_q64g_kernel<true, true, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64) == hipSuccess, "hipFuncSetAttribute"); \
         hipLaunchKernelGGL((attention_q64g_kernel<true, true, V_>), grid64, dim3(256), lds64, st, p); break
-        switch (gen) { DRAG_AQV(1); DRAG_AQV(2); DRAG_AQV(3); DRAG_AQV(4); DRAG_AQV(5); DRAG_AQV(6); DRAG_AQV(7); DRAG_AQV(8); DRAG_AQV(9); DRAG_AQV(10); DRAG_AQV(11); DRAG_AQV(12); DRAG_AQV(13); DRAG_AQV(14); DRAG_AQV(15); DRAG_AQV(16); DRAG_AQV(17); DRAG_AQV(18); }
+        switch (gen) { DRAG_AQV(1); DRAG_AQV(2); DRAG_AQV(3); DRAG_AQV(4); DRAG_AQV(5); DRAG_AQV(6); DRAG_AQV(7); DRAG_AQV(8); DRAG_AQV(9); DRAG_AQV(10); DRAG_AQV(11); DRAG_AQV(12); DRAG_AQV(13); DRAG_AQV(14); DRAG_AQV(15); DRAG_AQV(16); DRAG_AQV(17); DRAG_AQV(18); DRAG_AQV(19); }
 #undef DRAG_AQV
       } else
 #endif

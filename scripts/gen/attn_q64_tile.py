@@ -93,7 +93,7 @@ class Stream:
     """instruction records + their assembly text"""
 
     def __init__(self, fold: bool, pieces_at=None, no_dma=False, no_barrier=False, no_reads=False, no_exp=False, no_softmax=False, no_maxima=False,
-                 pk_add=False, ahead=2, dot2=False, lsum=False):
+                 pk_add=False, ahead=2, dot2=False, lsum=False, early_max=False):
         self.fold = fold
         self.ins: list[Ins] = []
         self.nlabel = 0
@@ -115,6 +115,9 @@ class Stream:
         # 64 v_add per tile: the stream is bound by a lone wave's instruction issue, not by the matrix pipe.  Needs 32 AGPRs: fragment rings of 2
         assert not lsum or (fold and not pk_add and not dot2 and ahead == 1)
         self.lsum = lsum
+        # early_max: the maxima of the NEXT tile's first key half (complete after step 7) are taken in steps 9..15, whose MFMAs leave issue slots
+        # free, instead of in the next tile's issue-bound top block; MT(g) carries the partial maximum across the barrier
+        self.early_max = early_max
         self.ahead = ahead          # fragment reads run `ahead` steps in front of their MFMAs (rings of ahead + 1 fragments)
         RING[0] = ahead + 1
         self.queue = []             # the wave's outstanding LDS reads, in issue order (tags): the counted waits come from here
@@ -254,6 +257,19 @@ class Stream:
                 else:
                     self.valu(o[0], o[1], *o[2:])
 
+    def half_tree(self, regs16, tmp, out, extra=None):
+        """the maximum of 16 registers (+ `extra`) into `out` as v_max3 trees: returns the instructions as thunks (8, or 9 with `extra`)"""
+        e = regs16
+        t = tmp
+        ops = [lambda i=i: self.valu("v_max3_f32", t[i], e[3 * i], e[3 * i + 1], e[3 * i + 2]) for i in range(5)]
+        ops.append(lambda: self.valu("v_max3_f32", t[5], t[0], t[1], t[2]))
+        ops.append(lambda: self.valu("v_max3_f32", t[6], t[3], t[4], e[15]))
+        if extra is None:
+            ops.append(lambda: self.valu("v_max_f32", out, t[5], t[6]))
+        else:
+            ops.append(lambda: self.valu("v_max3_f32", out, t[5], t[6], extra))
+        return ops
+
     # ---- one tile
     def tile(self, par, sc, sn, variant="steady"):
         """par: parity of the tile (its V^T buffer; the next tile's K is in K buffer par ^ 1); sc / sn: score sets of this / the next tile;
@@ -279,7 +295,7 @@ class Stream:
             self.ds_read(KFR(g0), AKL(g0), KN, tag=("k", g0))
         if variant == "last":
             self.mask_block(sc)
-        self.top_block(sc, par, nxt_k, nxt_v)
+        self.top_block(sc, par, nxt_k, nxt_v, full=not self.early_max or variant == "last")
         self.wait_lgkm(0)
         self.rescale_decision(sc)
         for g in range(2):
@@ -290,8 +306,13 @@ class Stream:
                     self.valu("v_mov_b32", r1(PS2(g), h), 0, text=f"v_mov_b32 {rs(r1(PS2(g), h))}, 0")
             else:
                 self.valu("v_mov_b32", PS(g), 0, text=f"v_mov_b32 {rs(PS(g))}, 0")
+        self.early = []
+        if self.early_max and not self.no_maxima:       # the next tile's first-key-half maxima, for steps 9..15
+            for grp in range(2):
+                self.early += self.half_tree([r1(sn(grp, 0), i) for i in range(16)], [TMP(8 * grp + i) for i in range(7)], MT(grp))
         for g in range(16):
             self.step(g, par, sc, sn, KN, VB, nxt_k, nxt_v)
+        assert not self.early
         self.wait_lgkm(0)
         for g in range(2):
             if self.lsum:
@@ -350,6 +371,10 @@ class Stream:
                 self.V(ops, "V7", "V8", "V9", "V10")
                 self.mfma(sn(1, T), kf, QA(1, g & 7), c1)
                 self.V(ops, "V11", "V12", "V13", "V14")
+            if g >= 9 and self.early:            # (steps 9..15: 16 instructions, 3 3 2 2 2 2 2)
+                for _ in range(3 if g <= 10 else 2):
+                    if self.early:
+                        self.early.pop(0)()
             if self.lsum and (g & 3) < 2:        # the row sums of key group kgc, query group g & 1 (its packed words are a step or more old)
                 self.mfma(LA(g & 1), ONES, PK(kgc, g & 1), LA(g & 1))
         else:
@@ -368,7 +393,7 @@ class Stream:
                 self.pieces(g, par, nxt_k, nxt_v, around=lambda: self.mfma(sn(1, T), kf, QA(1, g), c1))
                 self.V(ops, "V8", "V9", "V10", "V11", "V12", "V13", "V14")
 
-    def top_block(self, sc, par=0, nxt_k=False, nxt_v=False):
+    def top_block(self, sc, par=0, nxt_k=False, nxt_v=False, full=True):
         """the previous tile's last key group P V (8 MFMAs) with the row maxima of `sc` (two v_max3 trees) under them; the lane halves are
         joined with v_permlane32_swap (no LDS round trip): MT(0) / MT(1) = the groups' maxima in both lane halves"""
         el = lambda g, i: r1(sc(g, i >> 4), i & 15)
@@ -394,6 +419,31 @@ class Stream:
             self.pieces(("top", npv[0]), par, nxt_k, nxt_v, around=lambda: self.mfma(O(g, dt), VTR(dt), PK(3, g), O(g, dt)))
             npv[0] += 1
 
+        if not full:
+            # early_max: MT(g) holds the first key half's maximum (taken in the previous tile's steps 9..15): the second half's tree, joined with it
+            todo = []
+            if not self.no_maxima:
+                for grp in range(2):
+                    todo += self.half_tree([el(grp, 16 + i) for i in range(16)], [TMP(8 * grp + i) for i in range(7)], MT(grp), extra=MT(grp))
+            for j, (dt, g) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1), (2, 0))):
+                PV(dt, g)
+                for _ in range(4 if j < 3 else 3):
+                    if todo:
+                        todo.pop(0)()
+            assert not todo
+            PV(2, 1)
+            self.nop(0)
+            self.emit("v_permlane32_swap_b32", None, [ra, rb], text=f"v_permlane32_swap_b32 {rs(ra)}, {rs(rb)}")
+            self.valu("v_max_f32", ra, ra, rb)
+            self.valu("v_mov_b32", rb, ra)
+            PV(3, 0)
+            self.nop(0)
+            self.emit("v_permlane32_swap_b32", None, [ra, rb], text=f"v_permlane32_swap_b32 {rs(ra)}, {rs(rb)}")
+            PV(3, 1)
+            if self.lsum:
+                for g in range(2):
+                    self.mfma(LA(g), ONES, PK(3, g), LA(g))
+            return
         # second-level results: group A's into TMP 20..23 (the staging-address temporaries, idle here), group B's into group A's dead first level
         u2a = [TMP(20), TMP(21), TMP(22), TMP(23)]
         u2b = [TMP(0), TMP(1), TMP(2), TMP(3)]
@@ -567,6 +617,10 @@ class Stream:
         for dt in range(4):
             for i in range(4):
                 self.emit("v_accvgpr_write_b32", r1(VTR(dt), i), [0], text=f"v_accvgpr_write_b32 {rs(r1(VTR(dt), i))}, 0")
+        if self.early_max and not self.no_maxima:      # tile 0's first-key-half maxima (every later tile's come from its predecessor's steps 9..15)
+            for grp in range(2):
+                for op in self.half_tree([r1(SX(grp, 0), i) for i in range(16)], [TMP(8 * grp + i) for i in range(7)], MT(grp)):
+                    op()
 
     def item(self):
         self.prologue()
@@ -639,6 +693,7 @@ VARIANTS = {
     14: dict(ahead=3),                                                                                                           # fragment reads three steps ahead
     15: dict(pk_add=True, ahead=3),
     17: dict(ahead=1, **FOLD_PRODUCT),                                                                                           # fragment reads ONE step ahead (rings of 2)
+    19: dict(early_max=True, **FOLD_PRODUCT),                                                                                    # first-key-half maxima in steps 9..15 of the previous tile
     18: dict(lsum=True, ahead=1, **FOLD_PRODUCT),                                                                                # row sums by ones x P MFMAs
     16: dict(dot2=True, **FOLD_PRODUCT),                                                                                         # row sums by v_dot2c_f32_bf16 of the packed P
 }
