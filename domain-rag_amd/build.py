@@ -92,6 +92,16 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
+    exp_header = os.path.join(CSRC, "attn_q64_tile_exp.h")
+    if "-DDRAG_EXPERIMENTS" in FLAGS:
+        # the generated attention stream's schedule variants (3 MB of asm text): written here, from the generator, for experiment builds only
+        gen = os.path.join(HERE, "..", "scripts", "gen", "attn_q64_tile.py")
+        r = subprocess.run([sys.executable, gen, "--experiments"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{gen} --experiments failed:\n{r.stderr}")
+        if not os.path.exists(exp_header) or open(exp_header).read() != r.stdout:
+            with open(exp_header, "w") as f:
+                f.write(r.stdout)
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     headers.append(os.path.join(HERE, "..", "include", "domainrag_hip.h"))
     isa = ISA

@@ -699,21 +699,23 @@ VARIANTS = {
 }
 
 
-def main(out=sys.stdout):
+def main(out=sys.stdout, experiments=False):
+    """the product header (attn_q64_tile.h: committed), or with --experiments the schedule variants' header (attn_q64_tile_exp.h: generated
+    by build.py for DRAG_EXPERIMENTS builds, 3 MB of text, not committed)"""
     out.write("// generated by scripts/gen/attn_q64_tile.py — do not edit; the generator holds the register map, the schedule and the emulator\n")
+    if experiments:
+        for k, kw in VARIANTS.items():
+            if k:
+                emit_macro(f"AQ64_ITEM_FOLD_V{k}", build(True, **kw), out)
+        return
     out.write("#define AQ64_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
     out.write("#define AQ64_CLOBBERS_LSUM " + ", ".join(f'"{c}"' for c in clobbers(True)) + "\n\n")
     emit_macro("AQ64_ITEM_NOFOLD", product(False), out)
     emit_macro("AQ64_ITEM_FOLD", product(True), out)
-    out.write("#ifdef DRAG_EXPERIMENTS\n")
-    for k, kw in VARIANTS.items():
-        if k:
-            emit_macro(f"AQ64_ITEM_FOLD_V{k}", build(True, **kw), out)
-    out.write("#endif\n")
 
 
 if __name__ == "__main__":
-    main()
+    main(experiments="--experiments" in sys.argv)
 
 
 # ================================================================================================ emulator + hazard checker
