@@ -8,6 +8,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def oracle_threads(dtype=None):
+    """host threads for a CPU oracle evaluation on the GPU box: 32.  Measured there (scripts/probe/cpu_threads_probe.py, profiles/
+    r06_cpu_threads_probe.log): torch's float32 linear takes 20-24 ms at 16-32 threads and 38 ms at 64 for the chained tests' 304 tokens (S = 5337:
+    230-264 vs 306 ms), bf16 linear and SDPA at S = 1124 6.4 / 5.2 ms at 32 threads against 20 / 31 ms at 64, the VAE's 3 x 3 convolutions
+    99 vs 121 ms (256 channels at 512^2); the default (every hardware thread: 256) is several times slower still.  The GPU suite's wall clock IS
+    these oracles: 686 s with 64 threads, 480 s with this."""
+    import torch
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+
+
+def pytest_sessionstart(session):
+    try:
+        oracle_threads(None)          # a sane default for every test that does not choose: 32, not the machine's 256
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

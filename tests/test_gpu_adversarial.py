@@ -676,7 +676,7 @@ def test_blocks_on_student_t_weights_and_outlier_hidden_states(gpu):
     from domain_rag_amd.flux import FluxTransformerHIP, latent_image_ids
     from domain_rag_amd.flux_params import FluxConfig, init_params
     from oracle import flux as oflux
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     cfg = FluxConfig(in_channels=384, num_layers=1, num_single_layers=1)
     params = _heavy_tailed(init_params(cfg, seed=41), 42)
     g = _g(43)
@@ -690,8 +690,11 @@ def test_blocks_on_student_t_weights_and_outlier_hidden_states(gpu):
     ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
     taps_ref, taps32, taps = {}, {}, {}
     p32 = {k: v.float() for k, v in params.items()}
+    from conftest import oracle_threads
     with torch.no_grad():
+        oracle_threads(torch.bfloat16)
         ref = oflux.flux_forward(params, ocfg, hidden, enc, pooled, t, img_ids, txt_ids, gd, taps=taps_ref)
+        oracle_threads(torch.float32)
         ref32 = oflux.flux_forward(p32, ocfg, hidden.float(), enc.float(), pooled.float(), t, img_ids, txt_ids, gd, taps=taps32, time_dtype=torch.bfloat16)
     out = FluxTransformerHIP(cfg, params, gpu)(hidden.to(gpu), enc.to(gpu), pooled.to(gpu), t, img_ids, txt_ids, gd, taps=taps)
     rows = []
@@ -737,7 +740,9 @@ def test_fill_30_chained_steps_on_student_t_weights(gpu):
     del fill, tp_dev
     torch.cuda.empty_cache()
     taps, imgs = {}, {}
+    from conftest import oracle_threads
     for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        oracle_threads(dt)
         cast = (lambda d: {k: v.to(dt) for k, v in d.items()})
         taps[name] = {}
         with torch.no_grad():
@@ -797,7 +802,7 @@ def test_vae_on_extreme_images_and_latents(gpu):
     and float32 oracles on the same weights, bar 1.3 x the reference dtype's own distance from float32"""
     from domain_rag_amd import vae
     from oracle import vae as ov
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     cfg = vae.VaeConfig()
     p = vae.init_params(cfg, seed=5)
     p32 = {k: v.float() for k, v in p.items()}

@@ -31,8 +31,11 @@ def test_full_size_flux_blocks_vs_oracle(gpu):
     ocfg = oflux.FluxConfig(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
     taps_ref, taps32, taps = {}, {}, {}
     p32 = {k: v.float() for k, v in params.items()}
+    from conftest import oracle_threads
     with torch.no_grad():
+        oracle_threads(torch.bfloat16)
         ref = oflux.flux_forward(params, ocfg, hidden, enc, pooled, t, img_ids, txt_ids, gd, taps=taps_ref)
+        oracle_threads(torch.float32)
         ref32 = oflux.flux_forward(p32, ocfg, hidden.float(), enc.float(), pooled.float(), t, img_ids, txt_ids, gd, taps=taps32,
                                    time_dtype=torch.bfloat16)
     out = FluxTransformerHIP(cfg, params, gpu)(hidden.to(gpu), enc.to(gpu), pooled.to(gpu), t, img_ids, txt_ids, gd, taps=taps)

@@ -74,7 +74,7 @@ def _oracle(x, with_f32, t0):
 # process oversubscribe the cores — the other oracle-bound tests ran 3 x slower and the suite 200 s LONGER.)
 # DRAG_ORACLE_PREFETCH=0 computes it inline as before; so does a child that fails.
 _prefetch = {}
-PREFETCH_THREADS = 48
+PREFETCH_THREADS = 32      # (the bf16 oracle's best thread count on the GPU box: tests/conftest.py oracle_threads)
 
 
 def start_oracle_prefetch():
@@ -113,7 +113,8 @@ def _join_prefetch():
 def test_fullsize_fill_pipeline_vs_oracle(gpu):
     from domain_rag_amd import fill_pipeline as fp, redux, vae
     from domain_rag_amd.flux import FluxTransformerHIP
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    from conftest import oracle_threads
+    oracle_threads(torch.bfloat16)
     t0 = time.time()
     res, steps, strength = RES, STEPS, STRENGTH
     x = _inputs(gpu)

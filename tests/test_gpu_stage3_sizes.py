@@ -36,8 +36,11 @@ def test_stage3_size_flux_blocks_vs_oracle(gpu, h, w):
     taps_ref, taps32, taps = {}, {}, {}
     p32 = {k: v.float() for k, v in params.items()}
     t0 = time.perf_counter()
+    from conftest import oracle_threads
     with torch.no_grad():
+        oracle_threads(torch.bfloat16)
         ref = oflux.flux_forward(params, ocfg, hidden, enc, pooled, t, img_ids, txt_ids, gd, taps=taps_ref)
+        oracle_threads(torch.float32)
         ref32 = oflux.flux_forward(p32, ocfg, hidden.float(), enc.float(), pooled.float(), t, img_ids, txt_ids, gd, taps=taps32,
                                    time_dtype=torch.bfloat16)
     t_or = time.perf_counter() - t0
