@@ -1079,7 +1079,7 @@ class Emu:
         raise RuntimeError("emulator did not finish")
 
 
-def emulate_item(fold, S, ld_qk, q, k, v, scale, seed_pieces=None, stream_kw=None):
+def emulate_item(fold, S, ld_qk, q, k, v, scale, seed_pieces=None, stream_kw=None, next_kv=None, lds_from=None):
     """run the generated stream for ONE item (256 queries q[256, 128], keys k[S, 128], values v[S, 128]; bf16-representable float32 arrays)
     on the emulator; returns (O [256, 128] float32 unnormalised, l [256] float32, emulator).  The first three tiles' staging (K(0), V^T(0),
     K(1)) is done here the way the kernel's stage_first does it."""
@@ -1102,6 +1102,18 @@ def emulate_item(fold, S, ld_qk, q, k, v, scale, seed_pieces=None, stream_kw=Non
         vt[:, pos] = vb[key]
     vmem = vt.reshape(-1).view(np.uint8).copy()
     glob = {"%[rsk]": (kmem, kbytes), "%[rsv]": (vmem, vmem.size), "%[rskn]": (kmem, 0), "%[rsvn]": (vmem, 0)}
+    if next_kv is not None:          # a walking workgroup: this item's last two tiles stage the NEXT item's K(0), K(1), V^T(0)
+        nk, nv = next_kv
+        nkmem = np.zeros(kbytes, np.uint8)
+        nkb = bf16_round(nk).astype(np.uint16)
+        for r in range(S):
+            nkmem[r * ld_qk * 2: r * ld_qk * 2 + 256] = nkb[r].view(np.uint8)
+        nvt = np.zeros((128, s_pad), np.uint16)
+        nvb = bf16_round(nv).astype(np.uint16)
+        for key in range(S):
+            nvt[:, (key & ~15) + PERM16.index(key & 15)] = nvb[key]
+        nvmem = nvt.reshape(-1).view(np.uint8).copy()
+        glob["%[rskn]"], glob["%[rsvn]"] = (nkmem, kbytes), (nvmem, nvmem.size)
     st = build(fold, **stream_kw) if stream_kw is not None else product(fold)
     qs = np.asarray(q, np.float32)
     if fold:
@@ -1144,8 +1156,14 @@ def emulate_item(fold, S, ld_qk, q, k, v, scale, seed_pieces=None, stream_kw=Non
         return out
 
     emu = Emu(st, glob, scalars, lane_inputs, q_frags)
+    if lds_from is not None:
+        # the previous item of a walking workgroup left this item's first tiles in the LDS (the kernel waits for them and passes a barrier
+        # in front of the statement): take the LDS image as it is
+        emu.lds[:] = lds_from.lds
+        for reg in range((2 * KT + 2 * VT) // 1024):
+            emu.region_write[reg] = dict(epoch=-1, landed_epoch=-1)
     # stage_first: K(0) -> K buffer 0, V^T(0) -> V^T buffer 0, K(1) -> K buffer 1 (every wave its four pieces each), landed + barrier
-    for w in range(4):
+    for w in range(4 if lds_from is None else 0):
         li = lane_inputs(w)
         for i in range(4):
             for (mem, nrec, base, off) in ((kmem, kbytes, 0 * KT + (w * 4 + i) * 1024, li[KOFF(i)].astype(np.int64)),
