@@ -35,12 +35,13 @@ diffusers cannot be imported here, but `transformers` ships code of the same lin
   flux.py adaln_zero()  (6-chunk order)          qwen2_5_omni Qwen2_5_OmniAdaLayerNormZero, fp32 and bf16       bit-exact
   flux.py adaln_continuous() (scale, shift)      qwen2_5_omni Qwen2_5_OmniAdaLayerNormZero_Final                bit-exact
   flux.py gated_mlp_residual()                   qwen2_5_omni DiTDecoderLayer around a stand-in attention       bit-exact
+  vae.py  pack_latents / unpack_latents / pack_mask  torch's own pixel_unshuffle(2) / pixel_shuffle(2) / pixel_unshuffle(8)   bit-exact
   vit.py, stem.py                                CLIP / SigLIP vision towers, ResNetEmbeddings (rounds 1-3)     see those tests
 
 STILL REVIEW-ONLY (no importable twin; restated from diffusers 0.33.1's published code, anchored on the reference's call sites):
 the joint `[txt, img]` concatenation order and the q/k RMSNorm -> RoPE -> SDPA composition inside the double / single blocks; the
 single block's 3-chunk (shift, scale, gate) order and its cat([attn, mlp]) -> proj_out; `timestep_proj` (cos first, 256-d,
 downscale shift 0) and the bf16-rounded x1000 timestep / guidance; `flow_sigmas` (dynamic shift, float32 table) and `euler_step`;
-Fill's mask / masked-image packing (fill.py, vae.pack_mask); the Redux concatenation (redux.py); DiagonalGaussian sampling and
+Fill's concatenation order [masked-image latents | mask] (fill.py; the packing index maps themselves are pinned on torch's pixel_unshuffle); the Redux concatenation (redux.py); DiagonalGaussian sampling and
 the (z - shift) * scaling constants; lama.py's FFC network; topk.c's tie order (faiss defines none).
 """

@@ -331,3 +331,22 @@ def test_gated_residual_and_mlp_half_of_a_block_equals_upstream_twin(dtype):
         n, g_msa, sh_mlp, sc_mlp, g_mlp = oflux.adaln_zero(p, "n", temb, x)
         got = oflux.gated_mlp_residual(p, "ff.", x, layer.attn.lin(n), g_msa, sh_mlp, sc_mlp, g_mlp)
     assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ packing (torch's own pixel (un)shuffle)
+def test_latent_and_mask_packing_equal_torch_pixel_unshuffle():
+    """FluxPipeline._pack_latents / _unpack_latents and FluxFillPipeline.prepare_mask_latents are view / permute / reshape chains in diffusers;
+    torch ships the same index maps as operators of its own: pack = pixel_unshuffle(2) flattened to tokens (channel c * 4 + dy * 2 + dx),
+    unpack = pixel_shuffle(2), the mask's 8 x 8 fold = pixel_unshuffle(8) on the single mask channel"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(2, 16, 12, 20, generator=g)
+    tok = ovae.pack_latents(z)
+    assert tok.shape == (2, 6 * 10, 64)
+    assert torch.equal(tok, F.pixel_unshuffle(z, 2).flatten(2).transpose(1, 2))
+    assert torch.equal(ovae.unpack_latents(tok, 6, 10), z)
+    assert torch.equal(ovae.unpack_latents(tok, 6, 10), F.pixel_shuffle(tok.transpose(1, 2).reshape(2, 64, 6, 10), 2))
+    m = (torch.rand(2, 1, 32, 48, generator=g) > 0.5).float()
+    pm = ovae.pack_mask(m)
+    assert pm.shape == (2, 2 * 3, 256)
+    assert torch.equal(pm, ovae.pack_latents(F.pixel_unshuffle(m, 8)))
